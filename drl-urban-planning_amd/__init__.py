@@ -1,0 +1,8 @@
+"""MI355X-native SGNN policy/value + PPO-update hot path (drop-in for the reference's
+``urban_planning.models.model.create_sgnn_model`` and ``UrbanPlanningAgent.update_params``).
+
+Sub-modules are imported lazily: ``synth`` (synthetic replay), ``native`` (ctypes binding of
+the C-ABI library ``csrc/libupamd.so``), ``packer`` (ragged/CSR replay packer), ``models``
+(nn.Module surface), ``agent`` (PPO update surface), ``dist`` (data-parallel helpers).
+"""
+__version__ = '0.1.0'
