@@ -1,0 +1,62 @@
+// C-ABI entry points of the PPO minibatch math (loss, GAE, first-step clip, Adam).
+#include "kernels.h"
+
+using namespace upamd;
+
+extern "C" int upamd_ppo_loss(int32_t B, const float *value_dev, const float *logp_dev, const float *ent_dev,
+                              const float *adv_dev, const float *ret_dev, const float *old_logp_dev,
+                              const float *exps_dev, float clip_epsilon, float value_pred_coef, float entropy_coef,
+                              float inv_rows, float inv_ind, float *dvalue_dev, float *dlogp_dev, float *dent_dev,
+                              float *losses_dev, void *stream) {
+    if (B <= 0) return fail(UPAMD_E_INVALID, "upamd_ppo_loss: B must be > 0");
+    if (!value_dev || !logp_dev || !ent_dev || !adv_dev || !ret_dev || !old_logp_dev || !exps_dev || !dvalue_dev ||
+        !dlogp_dev || !dent_dev || !losses_dev)
+        return fail(UPAMD_E_INVALID, "upamd_ppo_loss: null pointer");
+    return launch_ppo_loss(B, value_dev, logp_dev, ent_dev, adv_dev, ret_dev, old_logp_dev, exps_dev, clip_epsilon,
+                           value_pred_coef, entropy_coef, inv_rows, inv_ind, dvalue_dev, dlogp_dev, dent_dev, losses_dev,
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int upamd_gae(int64_t T, const float *rewards_dev, const float *masks_dev, const float *values_dev,
+                         double gamma, double tau, float *adv_dev, float *ret_dev, void *stream) {
+    if (T <= 0) return fail(UPAMD_E_INVALID, "upamd_gae: T must be > 0");
+    if (!rewards_dev || !masks_dev || !values_dev || !adv_dev || !ret_dev) return fail(UPAMD_E_INVALID, "upamd_gae: null pointer");
+    return launch_gae(T, rewards_dev, masks_dev, values_dev, gamma, tau, adv_dev, ret_dev, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int upamd_clip_first_step(const upamd_model_desc *desc, float *grads_dev, float max_norm,
+                                     float *scratch_dev, void *stream) {
+    ParamLayout P;
+    int rc = build_param_layout(desc, &P);
+    if (rc) return rc;
+    if (!grads_dev || !scratch_dev) return fail(UPAMD_E_INVALID, "upamd_clip_first_step: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // encoder range = group 0 minus the value head (the value head is the tail of group 0)
+    const int64_t enc_b = P.group_begin[0];
+    const int64_t enc_e = P.off(P.value_w[0]);
+    const int64_t val_e = P.group_end[0];
+    float *acc = scratch_dev + 2048;   // two accumulators behind the per-block partials
+    UPAMD_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(float), st));
+    // 1) clip_grad_norm_(policy_net.parameters()) : shared encoder + both pointer heads
+    rc = launch_sumsq(grads_dev + enc_b, enc_e - enc_b, scratch_dev, acc, st);
+    if (rc) return rc;
+    rc = launch_sumsq(grads_dev + P.group_begin[1], P.group_end[2] - P.group_begin[1], scratch_dev, acc, st);
+    if (rc) return rc;
+    rc = launch_clip_scale(grads_dev + enc_b, enc_e - enc_b, acc, max_norm, st);
+    if (rc) return rc;
+    rc = launch_clip_scale(grads_dev + P.group_begin[1], P.group_end[2] - P.group_begin[1], acc, max_norm, st);
+    if (rc) return rc;
+    // 2) clip_grad_norm_(value_net.parameters()) : (already scaled) shared encoder + value head
+    rc = launch_sumsq(grads_dev + enc_b, val_e - enc_b, scratch_dev, acc + 1, st);
+    if (rc) return rc;
+    return launch_clip_scale(grads_dev + enc_b, val_e - enc_b, acc + 1, max_norm, st);
+}
+
+extern "C" int upamd_adam_step(int64_t begin, int64_t end, float *params_dev, const float *grads_dev, float *m_dev,
+                               float *v_dev, int32_t step, double lr, double beta1, double beta2, double eps,
+                               double weight_decay, void *stream) {
+    if (end < begin || step < 1) return fail(UPAMD_E_INVALID, "upamd_adam_step: bad range or step");
+    if (!params_dev || !grads_dev || !m_dev || !v_dev) return fail(UPAMD_E_INVALID, "upamd_adam_step: null pointer");
+    return launch_adam(end - begin, params_dev + begin, grads_dev + begin, m_dev + begin, v_dev + begin, step, lr, beta1,
+                       beta2, eps, weight_decay, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,531 @@
+// Engine: sequences the kernels of one minibatch forward / backward on a stream.
+// The order of operations mirrors tests/csr_model.py (the executable spec) step by step.
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "kernels.h"
+
+using namespace upamd;
+
+struct upamd_engine {
+    upamd_model_desc d;
+    ParamLayout P;
+    Profiler prof;
+};
+
+namespace {
+
+struct Plan {
+    std::map<std::string, int64_t> off;     // float offsets
+    std::map<std::string, int64_t> len;
+    int64_t total = 0;                      // floats
+};
+
+struct Dims {
+    int D, L, heads, dh, F, Fn, S_last, W;   // W = width of state_value
+    int h0l, h0r;                            // hidden sizes of the two pointer heads
+    int maxdim;                              // widest per-sample activation
+};
+
+Dims dims_of(const upamd_model_desc &d) {
+    Dims x;
+    x.D = d.D; x.L = d.L; x.heads = d.heads; x.dh = d.D / d.heads; x.F = d.node_dim; x.Fn = d.numerical_dim;
+    x.S_last = d.num_hidden[d.n_num - 1];
+    x.W = 3 * d.D + x.S_last + 3;
+    x.h0l = d.land_hidden[0];
+    x.h0r = d.road_hidden[0];
+    x.maxdim = std::max(x.W, std::max(x.Fn, d.D));
+    for (int i = 0; i < d.n_num; ++i) x.maxdim = std::max(x.maxdim, d.num_hidden[i]);
+    for (int i = 0; i < d.n_value; ++i) x.maxdim = std::max(x.maxdim, d.value_hidden[i]);
+    return x;
+}
+
+int64_t slab_floats(const Dims &x, int64_t M, int64_t Nhe, int64_t Nrn) {
+    int64_t s = 0;
+    s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, x.D, M) * 2 * x.D * x.D);          // GCN weight grads
+    s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, 32, M) * x.D * 32);                    // node encoder
+    s = std::max<int64_t>(s, (int64_t)tn_splits(4 * x.D, x.h0l, Nhe) * 4 * x.D * x.h0l);    // land head
+    s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.h0r, Nrn) * x.D * x.h0r);            // road head
+    return s;
+}
+
+void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
+    const Dims x = dims_of(d);
+    const int64_t B = mb.B, M = std::max<int64_t>(mb.n_nodes, 1), NH = std::max<int64_t>(mb.n_he, 1),
+                  NR = std::max<int64_t>(mb.n_rn, 1);
+    const int D = x.D;
+    int64_t off = 0;
+    auto add = [&](const std::string &name, int64_t n) {
+        pl->off[name] = off;
+        pl->len[name] = n;
+        off = align_up(off + std::max<int64_t>(n, 1), 64);
+    };
+    add("We_pad", (int64_t)D * 32);
+    for (int l = 0; l < x.L; ++l) {
+        add("Wcat" + std::to_string(l), 2LL * D * D);
+        add("WcatT" + std::to_string(l), 2LL * D * D);
+    }
+    add("Wkk", (int64_t)D * D); add("Wvv", (int64_t)D * D); add("bvv", D);
+    add("W1T", 4LL * D * x.h0l); add("R1T", (int64_t)D * x.h0r);
+    add("Xp", 2 * M * 16);
+    add("U0", B * x.Fn);
+    for (int i = 0; i < d.n_num; ++i) add("U" + std::to_string(i + 1), B * d.num_hidden[i]);
+    add("curg", B * UPAMD_NODE_PAD);
+    add("C", B * D);
+    for (int l = 0; l <= x.L; ++l) add("H" + std::to_string(l), M * D);
+    for (int l = 1; l <= x.L; ++l) add("PQ" + std::to_string(l), M * 2 * D);
+    add("hbarV", B * D); add("hbarE", B * D);
+    add("q0", B * D); add("q1", B * D); add("r", B * x.heads * D); add("alpha", (int64_t)x.heads * M);
+    add("s", B * x.heads * D); add("o", B * D); add("att", B * D);
+    add("SV", B * x.W);
+    for (int i = 0; i < d.n_value; ++i) add("V" + std::to_string(i + 1), B * d.value_hidden[i]);
+    add("FE", NH * 4 * D); add("hidl", NH * x.h0l); add("z_he", NH); add("p_he", NH);
+    add("XR", NR * D); add("hidr", NR * x.h0r); add("z_rn", NR); add("p_rn", NR);
+    add("lse", B); add("entk", B);
+    // backward temporaries
+    add("dzA", B * x.maxdim); add("dzB", B * x.maxdim); add("dnA", B * x.maxdim); add("dnB", B * x.maxdim);
+    add("do", B * D); add("ds", B * x.heads * D); add("dr", B * x.heads * D);
+    add("dq1", B * D); add("dq0", B * D); add("dC", B * D); add("dC_head", B * D);
+    add("dWkk", (int64_t)D * D); add("dWvv", (int64_t)D * D); add("dbvv", D);
+    add("dz_he", NH); add("dz_rn", NR); add("dprel", NH * x.h0l); add("dFE", NH * 4 * D); add("dMhe", NH * D);
+    add("dprer", NR * x.h0r); add("dXR", NR * D);
+    add("G0", M * D); add("G1", M * D); add("dPQ", M * 2 * D); add("dbias_part", B * D);
+    add("slabs", slab_floats(x, M, NH, NR));
+    const int64_t maxrows = std::max(M, std::max(NH, NR));
+    add("cs_part", (int64_t)colsum_pm_blocks(maxrows) * std::max(4 * D, 64));
+    pl->total = off;
+}
+
+PackedView make_view(const void *packed_dev, const upamd_pack_layout &L) {
+    const char *b = static_cast<const char *>(packed_dev);
+    PackedView v;
+    v.meta = reinterpret_cast<const int32_t *>(b + L.off_meta);
+    v.X = reinterpret_cast<const float *>(b + L.off_x);
+    v.nmask = reinterpret_cast<const uint8_t *>(b + L.off_nmask);
+    v.rowptr = reinterpret_cast<const int32_t *>(b + L.off_rowptr);
+    v.inc_nbr = reinterpret_cast<const uint16_t *>(b + L.off_inc_nbr);
+    v.inc_he = reinterpret_cast<const uint16_t *>(b + L.off_inc_he);
+    v.he_src = reinterpret_cast<const uint16_t *>(b + L.off_he_src);
+    v.he_dst = reinterpret_cast<const uint16_t *>(b + L.off_he_dst);
+    v.he_live = reinterpret_cast<const uint8_t *>(b + L.off_he_live);
+    v.rn_node = reinterpret_cast<const uint16_t *>(b + L.off_rn_node);
+    v.numerical = reinterpret_cast<const float *>(b + L.off_numerical);
+    v.cur = reinterpret_cast<const float *>(b + L.off_cur);
+    v.Fn = L.numerical_dim;
+    return v;
+}
+
+MbView make_mb(const upamd_minibatch &mb) {
+    MbView v;
+    v.B = mb.B; v.M = mb.n_nodes; v.Nhe = mb.n_he; v.Nrn = mb.n_rn; v.max_n = mb.max_n; v.max_inc = mb.max_inc;
+    v.idx = mb.idx_dev; v.node_off = mb.node_off_dev; v.he_off = mb.he_off_dev; v.rn_off = mb.rn_off_dev;
+    return v;
+}
+
+int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *layout, const upamd_minibatch *mb,
+               const float *params, void *ws, int64_t ws_bytes, Plan *pl) {
+    if (!eng || !packed || !layout || !mb || !params || !ws) return fail(UPAMD_E_INVALID, "null argument");
+    if (mb->B <= 0 || mb->n_nodes <= 0) return fail(UPAMD_E_INVALID, "empty minibatch (B=%d, nodes=%lld)", mb->B, (long long)mb->n_nodes);
+    if (!mb->idx_dev || !mb->node_off_dev || !mb->he_off_dev || !mb->rn_off_dev) return fail(UPAMD_E_INVALID, "minibatch schedule pointers are null");
+    if (layout->node_dim != eng->d.node_dim || layout->numerical_dim != eng->d.numerical_dim)
+        return fail(UPAMD_E_INVALID, "packed replay feature sizes (%d,%d) do not match the model (%d,%d)", layout->node_dim,
+                    layout->numerical_dim, eng->d.node_dim, eng->d.numerical_dim);
+    if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return fail(UPAMD_E_INVALID, "workspace must be 256-byte aligned");
+    make_plan(eng->d, *mb, pl);
+    if (pl->total * 4 > ws_bytes) return fail(UPAMD_E_WORKSPACE, "workspace too small: need %lld bytes, got %lld", (long long)pl->total * 4, (long long)ws_bytes);
+    return 0;
+}
+
+#define CK(expr)            \
+    do {                    \
+        int _rc = (expr);   \
+        if (_rc) return _rc; \
+    } while (0)
+
+// Y[R,N] = act(X[R,K] W[N,K]^T + b)
+int lin_fwd(const float *X, int64_t ldx, int R, int K, const float *W, const float *b, int N, float *Y, int64_t ldy,
+            int act, float scale, hipStream_t st) {
+    return launch_smm(R, N, K, X, ldx, 1, W, 1, K, b, Y, ldy, 0, act, scale, st);
+}
+// dX[R,K] = dY[R,N] W[N,K]
+int lin_dx(const float *dY, int64_t ldy, int R, int N, const float *W, int K, float *dX, int64_t ldx, int accumulate,
+           hipStream_t st) {
+    return launch_smm(R, K, N, dY, ldy, 1, W, K, 1, nullptr, dX, ldx, accumulate, 0, 1.f, st);
+}
+// dW[N,K] += dY[R,N]^T X[R,K];  db[N] += colsum(dY)
+int lin_dw(const float *dY, int64_t ldy, int R, int N, const float *X, int64_t ldx, int K, float *dW, float *db,
+           hipStream_t st) {
+    CK(launch_smm(N, K, R, dY, 1, ldy, X, ldx, 1, nullptr, dW, K, 1, 0, 1.f, st));
+    if (db) CK(launch_colsum_rm(dY, R, N, ldy, db, st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
+    if (!out) return fail(UPAMD_E_INVALID, "upamd_engine_create: out is null");
+    ParamLayout P;
+    int rc = build_param_layout(desc, &P);
+    if (rc) return rc;
+    if (desc->n_land != 2 || desc->n_road != 2)
+        return fail(UPAMD_E_INVALID, "this build supports pointer heads of the form [hidden, 1] only (got %d and %d layers)", desc->n_land, desc->n_road);
+    upamd_engine *e = new upamd_engine();
+    e->d = *desc;
+    e->P = P;
+    *out = e;
+    return UPAMD_OK;
+}
+
+extern "C" int upamd_profile_reset(upamd_engine *eng) {
+    if (!eng) return fail(UPAMD_E_INVALID, "null engine");
+    for (KernelStat *k : {&eng->prof.gemm_nt, &eng->prof.gemm_tn, &eng->prof.edge_fwd, &eng->prof.edge_bwd}) {
+        for (hipEvent_t e : k->ev) hipEventDestroy(e);
+        *k = KernelStat();
+    }
+    return UPAMD_OK;
+}
+
+extern "C" void upamd_engine_destroy(upamd_engine *eng) {
+    if (!eng) return;
+    upamd_profile_reset(eng);
+    delete eng;
+}
+
+extern "C" int upamd_profile_enable(upamd_engine *eng, int32_t on) {
+    if (!eng) return fail(UPAMD_E_INVALID, "null engine");
+    eng->prof.on = on != 0;
+    return UPAMD_OK;
+}
+
+extern "C" int upamd_profile_read(upamd_engine *eng, const char *name, int64_t *launches, double *total_ms,
+                                  double *total_flops, double *total_bytes) {
+    if (!eng || !name) return fail(UPAMD_E_INVALID, "null argument");
+    KernelStat *k = nullptr;
+    if (!std::strcmp(name, "gemm_nt")) k = &eng->prof.gemm_nt;
+    else if (!std::strcmp(name, "gemm_tn")) k = &eng->prof.gemm_tn;
+    else if (!std::strcmp(name, "edge_fwd")) k = &eng->prof.edge_fwd;
+    else if (!std::strcmp(name, "edge_bwd")) k = &eng->prof.edge_bwd;
+    else return fail(UPAMD_E_INVALID, "unknown kernel name '%s'", name);
+    double ms = 0;
+    for (size_t i = 0; i + 1 < k->ev.size(); i += 2) {
+        UPAMD_HIP(hipEventSynchronize(k->ev[i + 1]));
+        float t = 0;
+        UPAMD_HIP(hipEventElapsedTime(&t, k->ev[i], k->ev[i + 1]));
+        ms += t;
+    }
+    if (launches) *launches = k->launches;
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = k->flops;
+    if (total_bytes) *total_bytes = k->bytes;
+    return UPAMD_OK;
+}
+
+extern "C" int upamd_workspace_bytes(upamd_engine *eng, const upamd_minibatch *mb, int32_t training, int64_t *bytes) {
+    (void)training;
+    if (!eng || !mb || !bytes) return fail(UPAMD_E_INVALID, "null argument");
+    Plan pl;
+    make_plan(eng->d, *mb, &pl);
+    *bytes = pl.total * 4 + 256;
+    return UPAMD_OK;
+}
+
+extern "C" int upamd_ws_tensor(upamd_engine *eng, const upamd_minibatch *mb, const char *name, int64_t *byte_offset,
+                               int64_t *rows, int64_t *cols, int32_t *kind) {
+    if (!eng || !mb || !name) return fail(UPAMD_E_INVALID, "null argument");
+    Plan pl;
+    make_plan(eng->d, *mb, &pl);
+    auto it = pl.off.find(name);
+    if (it == pl.off.end()) return fail(UPAMD_E_INVALID, "unknown workspace tensor '%s'", name);
+    const Dims x = dims_of(eng->d);
+    const std::string n(name);
+    int64_t r = 0, c = 0;
+    int k = 0;
+    const int64_t B = mb->B, M = mb->n_nodes, NH = mb->n_he, NR = mb->n_rn;
+    if (n[0] == 'H' && isdigit(n[1])) { r = M; c = x.D; k = 1; }
+    else if (n.rfind("PQ", 0) == 0 || n == "dPQ") { r = M; c = 2 * x.D; k = 1; }
+    else if (n == "G0" || n == "G1") { r = M; c = x.D; k = 1; }
+    else if (n == "Xp") { r = M; c = 32; k = 1; }
+    else if (n == "FE" || n == "dFE") { r = NH; c = 4 * x.D; k = 1; }
+    else if (n == "hidl" || n == "dprel") { r = NH; c = x.h0l; k = 1; }
+    else if (n == "dMhe") { r = NH; c = x.D; k = 1; }
+    else if (n == "XR" || n == "dXR") { r = NR; c = x.D; k = 1; }
+    else if (n == "hidr" || n == "dprer") { r = NR; c = x.h0r; k = 1; }
+    else if (n == "z_he" || n == "p_he" || n == "dz_he") { r = NH; c = 1; }
+    else if (n == "z_rn" || n == "p_rn" || n == "dz_rn") { r = NR; c = 1; }
+    else if (n == "alpha") { r = x.heads; c = M; }
+    else if (n == "SV") { r = B; c = x.W; }
+    else if (n == "r" || n == "s" || n == "ds" || n == "dr") { r = B; c = (int64_t)x.heads * x.D; }
+    else if (n == "lse") { r = B; c = 1; }
+    else if (n == "U0") { r = B; c = x.Fn; }
+    else if (n == "curg") { r = B; c = UPAMD_NODE_PAD; }
+    else if (n == "Wkk" || n == "Wvv" || n == "dWkk" || n == "dWvv") { r = x.D; c = x.D; }
+    else if (n[0] == 'U' || n[0] == 'V') { r = B; c = pl.len[n] / std::max<int64_t>(B, 1); }
+    else { r = B; c = x.D; }     // C, hbarV, hbarE, q0, q1, o, att, do, dq*, dC*
+    if (byte_offset) *byte_offset = it->second * 4;
+    if (rows) *rows = r;
+    if (cols) *cols = c;
+    if (kind) *kind = k;
+    return UPAMD_OK;
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout,
+                             const upamd_minibatch *mbp, const float *prm, void *ws_dev, int64_t ws_bytes,
+                             float *value_dev, float *logp_dev, float *ent_dev, int32_t keep, void *stream) {
+    (void)keep;
+    Plan pl;
+    CK(check_args(eng, packed_dev, layout, mbp, prm, ws_dev, ws_bytes, &pl));
+    if (!value_dev || !logp_dev || !ent_dev) return fail(UPAMD_E_INVALID, "output pointers are null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const upamd_model_desc &d = eng->d;
+    const ParamLayout &P = eng->P;
+    const Dims x = dims_of(d);
+    const int D = x.D, B = mbp->B;
+    const PackedView pk = make_view(packed_dev, *layout);
+    const MbView mb = make_mb(*mbp);
+    float *ws = static_cast<float *>(ws_dev);
+    auto W = [&](const std::string &n) { return ws + pl.off.at(n); };
+    auto PR = [&](int idx) { return prm + P.off(idx); };
+    Profiler *prof = &eng->prof;
+
+    // -- per-step weight preparation (tiny)
+    CK(launch_pad_cols(PR(P.node_w), D, x.F, 32, W("We_pad"), st));
+    for (int l = 0; l < x.L; ++l)
+        CK(launch_prep_wcat(PR(P.edge_w[l]), D, W("Wcat" + std::to_string(l)), W("WcatT" + std::to_string(l)), st));
+    const float *Win = PR(P.inproj_w), *bin = PR(P.inproj_b);
+    const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
+    const float *biq = bin, *biv = bin + 2 * D;
+    // Wkk = Wik Wk, Wvv = Wiv Wv, bvv = Wiv bv + biv
+    CK(launch_smm(D, D, D, Wik, D, 1, PR(P.k_w), D, 1, nullptr, W("Wkk"), D, 0, 0, 1.f, st));
+    CK(launch_smm(D, D, D, Wiv, D, 1, PR(P.v_w), D, 1, nullptr, W("Wvv"), D, 0, 0, 1.f, st));
+    CK(launch_smm(1, D, D, PR(P.v_b), D, 1, Wiv, 1, D, biv, W("bvv"), D, 0, 0, 1.f, st));
+
+    // -- inputs
+    CK(launch_gather_inputs(pk, mb, W("Xp"), W("U0"), W("curg"), st));
+    // numerical encoder (state_encoder.py:35-57,187)
+    {
+        int prev = x.Fn;
+        for (int i = 0; i < d.n_num; ++i) {
+            CK(lin_fwd(W("U" + std::to_string(i)), prev, B, prev, PR(P.num_w[i]), PR(P.num_b[i]), d.num_hidden[i],
+                       W("U" + std::to_string(i + 1)), d.num_hidden[i], 1, 1.f, st));
+            prev = d.num_hidden[i];
+        }
+    }
+    // node encoder on all nodes and on the current node (state_encoder.py:189-191)
+    CK(launch_gemm_nt(W("Xp"), mb.M, 32, W("We_pad"), D, PR(P.node_b), nullptr, W("H0"), 0, st, prof));
+    CK(launch_smm(B, D, x.F, W("curg"), UPAMD_NODE_PAD, 1, PR(P.node_w), 1, x.F, PR(P.node_b), W("C"), D, 0, 0, 1.f, st));
+    // GCN layers (state_encoder.py:194-197)
+    for (int l = 1; l <= x.L; ++l) {
+        const std::string sl = std::to_string(l);
+        CK(launch_gemm_nt(W("H" + std::to_string(l - 1)), mb.M, D, W("Wcat" + std::to_string(l - 1)), 2 * D, nullptr, nullptr,
+                          W("PQ" + sl), 0, st, prof));
+        CK(launch_edge_fwd(pk, mb, D, l == x.L, W("PQ" + sl), PR(P.edge_b[l - 1]), W("H" + std::to_string(l - 1)), W("H" + sl),
+                           W("hbarV"), W("hbarE"), st, prof));
+    }
+    const float *HL = W("H" + std::to_string(x.L));
+    // attention (state_encoder.py:150-161)
+    const float scale = 1.0f / std::sqrt((float)x.dh);
+    CK(lin_fwd(W("C"), D, B, D, PR(P.q_w), PR(P.q_b), D, W("q0"), D, 0, 1.f, st));
+    CK(lin_fwd(W("q0"), D, B, D, Wiq, biq, D, W("q1"), D, 0, scale, st));
+    for (int h = 0; h < x.heads; ++h)   // r[b,h,:] = q1[b, h-slice] @ Wkk[h-slice, :]
+        CK(launch_smm(B, D, x.dh, W("q1") + h * x.dh, D, 1, W("Wkk") + (int64_t)h * x.dh * D, D, 1, nullptr,
+                      W("r") + (int64_t)h * D, (int64_t)x.heads * D, 0, 0, 1.f, st));
+    CK(launch_attn_fwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("s"), st));
+    for (int h = 0; h < x.heads; ++h)   // o[b, h-slice] = s[b,h,:] @ Wvv[h-slice,:]^T + bvv[h-slice]
+        CK(launch_smm(B, x.dh, D, W("s") + (int64_t)h * D, (int64_t)x.heads * D, 1, W("Wvv") + (int64_t)h * x.dh * D, 1, D,
+                      W("bvv") + h * x.dh, W("o") + h * x.dh, D, 0, 0, 1.f, st));
+    CK(lin_fwd(W("o"), D, B, D, PR(P.outproj_w), PR(P.outproj_b), D, W("att"), D, 0, 1.f, st));
+    // value head (value.py:15-39)
+    CK(launch_assemble_sv(pk, mb, D, x.S_last, W("U" + std::to_string(d.n_num)), W("hbarV"), W("hbarE"), W("att"), W("SV"), st));
+    {
+        const float *prevp = W("SV");
+        int prev = x.W;
+        for (int i = 0; i < d.n_value; ++i) {
+            float *out = (i == d.n_value - 1) ? value_dev : W("V" + std::to_string(i + 1));
+            CK(lin_fwd(prevp, prev, B, prev, PR(P.value_w[i]), PR(P.value_b[i]), d.value_hidden[i], out, d.value_hidden[i],
+                       i < d.n_value - 1, 1.f, st));
+            prevp = out;
+            prev = d.value_hidden[i];
+        }
+    }
+    // pointer heads (policy.py:19-65)
+    if (mb.Nhe > 0) {
+        CK(launch_he_feat_fwd(pk, mb, D, W("PQ" + std::to_string(x.L)), PR(P.edge_b[x.L - 1]), W("C"), W("FE"), st));
+        CK(launch_gemm_nt(W("FE"), mb.Nhe, 4 * D, PR(P.land_w[0]), x.h0l, PR(P.land_b0), nullptr, W("hidl"), 1, st, prof));
+        CK(launch_rowdot_pm(W("hidl"), mb.Nhe, x.h0l, PR(P.land_w[1]), W("z_he"), st));
+    }
+    if (mb.Nrn > 0) {
+        CK(launch_road_gather(pk, mb, D, HL, W("XR"), st));
+        CK(launch_gemm_nt(W("XR"), mb.Nrn, D, PR(P.road_w[0]), x.h0r, PR(P.road_b0), nullptr, W("hidr"), 1, st, prof));
+        CK(launch_rowdot_pm(W("hidr"), mb.Nrn, x.h0r, PR(P.road_w[1]), W("z_rn"), st));
+    }
+    CK(launch_pointer_fwd(pk, mb, W("z_he"), W("z_rn"), W("p_he"), W("p_rn"), logp_dev, ent_dev, W("lse"), st));
+    // the entropy is needed again by the backward: keep a copy next to lse
+    UPAMD_HIP(hipMemcpyAsync(W("entk"), ent_dev, sizeof(float) * (size_t)B, hipMemcpyDeviceToDevice, st));
+    return UPAMD_OK;
+}
+
+// =============================================================================================
+// backward
+// =============================================================================================
+extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout,
+                              const upamd_minibatch *mbp, const float *prm, void *ws_dev, int64_t ws_bytes,
+                              const float *dvalue_dev, const float *dlogp_dev, const float *dent_dev,
+                              float *grads, void *stream) {
+    Plan pl;
+    CK(check_args(eng, packed_dev, layout, mbp, prm, ws_dev, ws_bytes, &pl));
+    if (!dvalue_dev || !dlogp_dev || !dent_dev || !grads) return fail(UPAMD_E_INVALID, "null seed/grad pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const upamd_model_desc &d = eng->d;
+    const ParamLayout &P = eng->P;
+    const Dims x = dims_of(d);
+    const int D = x.D, B = mbp->B;
+    const PackedView pk = make_view(packed_dev, *layout);
+    const MbView mb = make_mb(*mbp);
+    float *ws = static_cast<float *>(ws_dev);
+    auto W = [&](const std::string &n) { return ws + pl.off.at(n); };
+    auto PR = [&](int idx) { return prm + P.off(idx); };
+    auto GR = [&](int idx) { return grads + P.off(idx); };
+    Profiler *prof = &eng->prof;
+    const float *Win = PR(P.inproj_w);
+    const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
+    float *gWin = GR(P.inproj_w), *gbin = GR(P.inproj_b);
+    const float *HL = W("H" + std::to_string(x.L));
+
+    // ---- value head
+    float *dzA = W("dzA"), *dzB = W("dzB");
+    {
+        // dz for the last layer is the seed itself ([B,1])
+        const float *dz = dvalue_dev;
+        int64_t ldz = 1;
+        for (int i = d.n_value - 1; i >= 0; --i) {
+            const int N = d.value_hidden[i];
+            const int K = (i == 0) ? x.W : d.value_hidden[i - 1];
+            const float *Xin = (i == 0) ? W("SV") : W("V" + std::to_string(i));
+            float *dzw = const_cast<float *>(dz);
+            if (i < d.n_value - 1) CK(launch_tanh_bwd(dzw, W("V" + std::to_string(i + 1)), (int64_t)B * N, st));
+            CK(lin_dw(dz, ldz, B, N, Xin, K, K, GR(P.value_w[i]), GR(P.value_b[i]), st));
+            float *dnext = (dz == dzA) ? dzB : dzA;
+            CK(lin_dx(dz, ldz, B, N, PR(P.value_w[i]), K, dnext, K, 0, st));
+            dz = dnext;
+            ldz = K;
+        }
+        // dz now holds dSV [B, W]; keep it in dzA
+        if (dz != dzA) UPAMD_HIP(hipMemcpyAsync(dzA, dz, sizeof(float) * (size_t)B * x.W, hipMemcpyDeviceToDevice, st));
+    }
+    const float *dSV = dzA;
+    const float *dUlast = dSV;                       // cols [0, S_last)
+    const float *dhbarV = dSV + x.S_last;            // ld = W
+    const float *dhbarE = dSV + x.S_last + D;
+    const float *datt = dSV + x.S_last + 2 * D;
+
+    // ---- numerical encoder backward
+    {
+        float *bufA = W("dnA"), *bufB = W("dnB");
+        // compact the dUlast column slice of dSV into a dense [B, S_last] buffer
+        UPAMD_HIP(hipMemcpy2DAsync(bufA, sizeof(float) * x.S_last, dUlast, sizeof(float) * x.W, sizeof(float) * x.S_last, B,
+                                   hipMemcpyDeviceToDevice, st));
+        float *dz = bufA;
+        for (int i = d.n_num - 1; i >= 0; --i) {
+            const int N = d.num_hidden[i];
+            const int K = (i == 0) ? x.Fn : d.num_hidden[i - 1];
+            CK(launch_tanh_bwd(dz, W("U" + std::to_string(i + 1)), (int64_t)B * N, st));
+            CK(lin_dw(dz, N, B, N, W("U" + std::to_string(i)), K, K, GR(P.num_w[i]), GR(P.num_b[i]), st));
+            if (i > 0) {
+                float *dnext = (dz == bufA) ? bufB : bufA;
+                CK(lin_dx(dz, N, B, N, PR(P.num_w[i]), K, dnext, K, 0, st));
+                dz = dnext;
+            }
+        }
+    }
+
+    // ---- attention, dense part
+    CK(lin_dw(datt, x.W, B, D, W("o"), D, D, GR(P.outproj_w), GR(P.outproj_b), st));
+    CK(lin_dx(datt, x.W, B, D, PR(P.outproj_w), D, W("do"), D, 0, st));
+    UPAMD_HIP(hipMemsetAsync(W("dWvv"), 0, sizeof(float) * (size_t)D * D, st));
+    UPAMD_HIP(hipMemsetAsync(W("dWkk"), 0, sizeof(float) * (size_t)D * D, st));
+    UPAMD_HIP(hipMemsetAsync(W("dbvv"), 0, sizeof(float) * (size_t)D, st));
+    CK(launch_colsum_rm(W("do"), B, D, D, W("dbvv"), st));
+    for (int h = 0; h < x.heads; ++h) {
+        // dWvv[h-slice,:] += do[:,h-slice]^T s[:,h,:]
+        CK(launch_smm(x.dh, D, B, W("do") + h * x.dh, 1, D, W("s") + (int64_t)h * D, (int64_t)x.heads * D, 1, nullptr,
+                      W("dWvv") + (int64_t)h * x.dh * D, D, 1, 0, 1.f, st));
+        // ds[:,h,:] = do[:,h-slice] Wvv[h-slice,:]
+        CK(launch_smm(B, D, x.dh, W("do") + h * x.dh, D, 1, W("Wvv") + (int64_t)h * x.dh * D, D, 1, nullptr,
+                      W("ds") + (int64_t)h * D, (int64_t)x.heads * D, 0, 0, 1.f, st));
+    }
+    // ---- attention core: writes G^L (mean + attention terms) and dr
+    float *G = W("G0"), *Gn = W("G1");
+    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("ds"), dhbarV, x.W, G, W("dr"), st));
+    for (int h = 0; h < x.heads; ++h) {
+        // dq1[:,h-slice] = dr[:,h,:] Wkk[h-slice,:]^T
+        CK(launch_smm(B, x.dh, D, W("dr") + (int64_t)h * D, (int64_t)x.heads * D, 1, W("Wkk") + (int64_t)h * x.dh * D, 1, D,
+                      nullptr, W("dq1") + h * x.dh, D, 0, 0, 1.f, st));
+        // dWkk[h-slice,:] += q1[:,h-slice]^T dr[:,h,:]
+        CK(launch_smm(x.dh, D, B, W("q1") + h * x.dh, 1, D, W("dr") + (int64_t)h * D, (int64_t)x.heads * D, 1, nullptr,
+                      W("dWkk") + (int64_t)h * x.dh * D, D, 1, 0, 1.f, st));
+    }
+    const float scale = 1.0f / std::sqrt((float)x.dh);
+    // dpre = dq1 * scale (in place)
+    CK(launch_scale(W("dq1"), (int64_t)B * D, scale, st));
+    CK(lin_dw(W("dq1"), D, B, D, W("q0"), D, D, gWin, gbin, st));                      // in_proj q rows
+    CK(lin_dx(W("dq1"), D, B, D, Wiq, D, W("dq0"), D, 0, st));
+    CK(lin_dw(W("dq0"), D, B, D, W("C"), D, D, GR(P.q_w), GR(P.q_b), st));
+    CK(lin_dx(W("dq0"), D, B, D, PR(P.q_w), D, W("dC"), D, 0, st));
+    // collapsed products: Wkk = Wik Wk ; Wvv = Wiv Wv ; bvv = Wiv bv + biv
+    CK(launch_smm(D, D, D, W("dWkk"), D, 1, PR(P.k_w), 1, D, nullptr, gWin + (int64_t)D * D, D, 1, 0, 1.f, st));      // dWik += dWkk Wk^T
+    CK(launch_smm(D, D, D, Wik, 1, D, W("dWkk"), D, 1, nullptr, GR(P.k_w), D, 1, 0, 1.f, st));                         // dWk  += Wik^T dWkk
+    CK(launch_smm(D, D, D, W("dWvv"), D, 1, PR(P.v_w), 1, D, nullptr, gWin + 2LL * D * D, D, 1, 0, 1.f, st));         // dWiv += dWvv Wv^T
+    CK(launch_smm(D, D, 1, W("dbvv"), 1, 1, PR(P.v_b), 1, 1, nullptr, gWin + 2LL * D * D, D, 1, 0, 1.f, st));         // dWiv += dbvv (x) bv
+    CK(launch_smm(D, D, D, Wiv, 1, D, W("dWvv"), D, 1, nullptr, GR(P.v_w), D, 1, 0, 1.f, st));                         // dWv  += Wiv^T dWvv
+    CK(launch_smm(1, D, D, W("dbvv"), D, 1, Wiv, D, 1, nullptr, GR(P.v_b), D, 1, 0, 1.f, st));                         // dbv  += Wiv^T dbvv
+    CK(launch_axpy(gbin + 2 * D, W("dbvv"), D, 1.f, st));                                                            // dbiv += dbvv
+
+    // ---- pointer heads
+    CK(launch_pointer_bwd(pk, mb, W("z_he"), W("z_rn"), W("p_he"), W("p_rn"), W("entk"), W("lse"), dlogp_dev, dent_dev,
+                          W("dz_he"), W("dz_rn"), st));
+    int S = 1;
+    if (mb.Nhe > 0) {
+        CK(launch_colsum_pm(W("hidl"), mb.Nhe, x.h0l, W("dz_he"), W("cs_part"), GR(P.land_w[1]), st));          // dw2 += sum dz * hid
+        CK(launch_rowdot_bwd_pm(W("hidl"), mb.Nhe, x.h0l, PR(P.land_w[1]), W("dz_he"), W("dprel"), st));
+        CK(launch_colsum_pm(W("dprel"), mb.Nhe, x.h0l, nullptr, W("cs_part"), GR(P.land_b0), st));
+        CK(launch_gemm_tn(W("FE"), 4 * D, W("dprel"), x.h0l, mb.Nhe, W("slabs"), &S, st, prof));
+        CK(launch_reduce_slabs(W("slabs"), S, 4 * D, x.h0l, 1, x.h0l, GR(P.land_w[0]), 4 * D, st));
+        CK(launch_transpose(PR(P.land_w[0]), x.h0l, 4 * D, W("W1T"), st));
+        CK(launch_gemm_nt(W("dprel"), mb.Nhe, x.h0l, W("W1T"), 4 * D, nullptr, nullptr, W("dFE"), 0, st, prof));
+        CK(launch_he_feat_bwd(pk, mb, D, W("FE"), W("C"), W("dFE"), W("dMhe"), W("dC_head"), st));
+        CK(launch_axpy(W("dC"), W("dC_head"), (int64_t)B * D, 1.f, st));
+    }
+    if (mb.Nrn > 0) {
+        CK(launch_colsum_pm(W("hidr"), mb.Nrn, x.h0r, W("dz_rn"), W("cs_part"), GR(P.road_w[1]), st));
+        CK(launch_rowdot_bwd_pm(W("hidr"), mb.Nrn, x.h0r, PR(P.road_w[1]), W("dz_rn"), W("dprer"), st));
+        CK(launch_colsum_pm(W("dprer"), mb.Nrn, x.h0r, nullptr, W("cs_part"), GR(P.road_b0), st));
+        CK(launch_gemm_tn(W("XR"), D, W("dprer"), x.h0r, mb.Nrn, W("slabs"), &S, st, prof));
+        CK(launch_reduce_slabs(W("slabs"), S, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D, st));
+        CK(launch_transpose(PR(P.road_w[0]), x.h0r, D, W("R1T"), st));
+        CK(launch_gemm_nt(W("dprer"), mb.Nrn, x.h0r, W("R1T"), D, nullptr, nullptr, W("dXR"), 0, st, prof));
+        CK(launch_road_scatter_add(pk, mb, D, W("dXR"), G, st));
+    }
+
+    // ---- GCN layers, last to first
+    for (int l = x.L; l >= 1; --l) {
+        const std::string sl = std::to_string(l), sp = std::to_string(l - 1);
+        const bool last = (l == x.L);
+        CK(launch_edge_bwd(pk, mb, D, last, W("PQ" + sl), PR(P.edge_b[l - 1]), G, dhbarE, x.W,
+                           (last && mb.Nhe > 0) ? W("dMhe") : nullptr, W("dPQ"), W("dbias_part"), st, prof));
+        CK(launch_reduce_rows_add(W("dbias_part"), B, D, GR(P.edge_b[l - 1]), st));
+        CK(launch_gemm_tn(W("dPQ"), 2 * D, W("H" + sp), D, mb.M, W("slabs"), &S, st, prof));
+        CK(launch_reduce_slabs(W("slabs"), S, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D, st));
+        CK(launch_gemm_nt(W("dPQ"), mb.M, 2 * D, W("WcatT" + sp), D, nullptr, G, Gn, 0, st, prof));
+        std::swap(G, Gn);
+    }
+    // ---- node encoder
+    CK(launch_gemm_tn(G, D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
+    CK(launch_reduce_slabs(W("slabs"), S, D, 32, 0, x.F, GR(P.node_w), x.F, st));
+    CK(launch_colsum_pm(G, mb.M, D, nullptr, W("cs_part"), GR(P.node_b), st));
+    CK(lin_dw(W("dC"), D, B, D, W("curg"), UPAMD_NODE_PAD, x.F, GR(P.node_w), GR(P.node_b), st));
+    return UPAMD_OK;
+}

@@ -1,0 +1,425 @@
+// fp32 MFMA GEMMs for the dense per-node / per-candidate MLP layers (gfx950, wave64).
+//
+// Both kernels use v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak):
+// operand A: lane l holds A[i = l & 31][k = l >> 5]; operand B: lane l holds B[k = l >> 5][j = l & 31];
+// accumulator reg r of lane l is D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31].
+//
+//   gemm_nt : C[M,N](pm) = act(A[M,K](pm) * W[N,K]^T + bias + R)       M = nodes (~10^5..10^6), K,N <= ~1024
+//             forward P/Q projection, node encoder, pointer-head hidden layers, all "dgrad"s.
+//   gemm_tn : slabs[s][I][J] = A[rows_s, I](pm)^T * B[rows_s, J](pm)     reduction over nodes, split-K
+//             all weight gradients; slabs are summed by reduce_slabs in a fixed order (deterministic,
+//             no float atomics).
+//
+// Replaces the reference's nn.Linear calls on padded [B,E,2D] / [B,N,D] tensors
+// (urban_planning/models/state_encoder.py:19,59-82,110-130; policy.py:19-43) and their autograd.
+#include "kernels.h"
+
+namespace upamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); v_exp_f32 + v_rcp_f32, abs error ~1e-7, saturates cleanly
+    float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------ NT
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K,
+                                                           const float *__restrict__ W, int N,
+                                                           const float *__restrict__ bias,
+                                                           const float *__restrict__ R, float *__restrict__ C,
+                                                           int act_tanh, int MT, int NT) {
+    constexpr int BM = 128, LD = 17;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TI = WM / 32, TJ = WN / 32;
+    constexpr int NB = (BN * 4 + 255) / 256;
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
+    __shared__ float As[2][BM * LD];
+    __shared__ float Bs[2][BN * LD];
+
+    // XCD-aware mapping: workgroup id -> XCD id % 8 (observed dispatch); all N-tiles of an M-tile
+    // land on one XCD so the A panel is fetched from HBM once and re-read from that XCD's L2.
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int mt = (slot / NT) * 8 + xcd, nt = slot % NT;
+    if (mt >= MT) return;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w / WAVES_N, wc = w % WAVES_N;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KP = K >> 4;
+    float4 ra[2], rb[NB];
+    auto load_tiles = [&](int kp) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
+            const int64_t gm = m0 + row;
+            ra[q] = gm < M ? *reinterpret_cast<const float4 *>(A + ((int64_t)kp * M + gm) * 16 + c4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
+            if (e < BN * 4) rb[q] = *reinterpret_cast<const float4 *>(W + (int64_t)(n0 + row) * K + kp * 16 + c4);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
+            float *d = &As[buf][row * LD + c4];
+            d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
+            if (e < BN * 4) {
+                float *d = &Bs[buf][row * LD + c4];
+                d[0] = rb[q].x; d[1] = rb[q].y; d[2] = rb[q].z; d[3] = rb[q].w;
+            }
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kp = 0; kp < KP; ++kp) {
+        const int buf = kp & 1;
+        if (kp + 1 < KP) load_tiles(kp + 1);
+        const float *as = &As[buf][(wr * WM + l31) * LD + lhi];
+        const float *bs = &Bs[buf][(wc * WN + l31) * LD + lhi];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = as[i * 32 * LD + 2 * s];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = bs[j * 32 * LD + 2 * s];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kp + 1 < KP) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int gn = n0 + wc * WN + j * 32 + l31;
+            const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int64_t gm = m0 + wr * WM + i * 32 + row;
+                if (gm < M) {
+                    const int64_t o = ((int64_t)(gn >> 4) * M + gm) * 16 + (gn & 15);
+                    float v = acc[i][j][r] + bv;
+                    if (R) v += R[o];
+                    if (act_tanh) v = fast_tanh(v);
+                    C[o] = v;
+                }
+            }
+        }
+}
+
+// generic fallback (any N % 16 == 0): one thread per output element
+__global__ void gemm_nt_generic_kernel(const float *__restrict__ A, int64_t M, int K, const float *__restrict__ W,
+                                       int N, const float *__restrict__ bias, const float *__restrict__ R,
+                                       float *__restrict__ C, int act_tanh) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M * N) return;
+    const int64_t m = g / N;
+    const int n = (int)(g % N);
+    float acc = bias ? bias[n] : 0.f;
+    const float *w = W + (int64_t)n * K;
+    for (int kp = 0; kp < (K >> 4); ++kp) {
+        const float4 *a4 = reinterpret_cast<const float4 *>(A + ((int64_t)kp * M + m) * 16);
+        const float4 *w4 = reinterpret_cast<const float4 *>(w + kp * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = a4[q], b = w4[q];
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        }
+    }
+    const int64_t o = ((int64_t)(n >> 4) * M + m) * 16 + (n & 15);
+    if (R) acc += R[o];
+    if (act_tanh) acc = fast_tanh(acc);
+    C[o] = acc;
+}
+
+static int prof_begin(Profiler *prof, KernelStat Profiler::*which, hipStream_t st, double flops, double bytes) {
+    if (!prof || !prof->on) return 0;
+    KernelStat &k = prof->*which;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
+    hipEventRecord(e0, st);
+    k.ev.push_back(e0);
+    k.ev.push_back(e1);
+    k.launches++;
+    k.flops += flops;
+    k.bytes += bytes;
+    return 1;
+}
+static void prof_end(Profiler *prof, KernelStat Profiler::*which, hipStream_t st, int began) {
+    if (began == 1) hipEventRecord((prof->*which).ev.back(), st);
+}
+
+int launch_gemm_nt(const float *A, int64_t M, int K, const float *W, int N, const float *bias, const float *R,
+                   float *C, int act_tanh, hipStream_t st, Profiler *prof) {
+    if (M <= 0) return 0;
+    if (K % 16 != 0 || N % 16 != 0) return fail(UPAMD_E_INVALID, "gemm_nt: K and N must be multiples of 16 (K=%d N=%d)", K, N);
+    const double flops = 2.0 * (double)M * K * N;
+    const double bytes = 4.0 * ((double)M * K + (double)M * N * (R ? 2 : 1) + (double)N * K);
+    int began = prof_begin(prof, &Profiler::gemm_nt, st, flops, bytes);
+    if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
+    if (N % 32 == 0) {
+        const int MT = (int)((M + 127) / 128);
+        const int MT8 = (MT + 7) / 8 * 8;
+        if (N % 128 == 0) {
+            const int NT = N / 128;
+            hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64>), dim3(MT8 * NT), dim3(256), 0, st, A, M, K, W, N, bias, R, C, act_tanh, MT, NT);
+        } else if (N % 64 == 0) {
+            const int NT = N / 64;
+            hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64, 32>), dim3(MT8 * NT), dim3(256), 0, st, A, M, K, W, N, bias, R, C, act_tanh, MT, NT);
+        } else {
+            const int NT = N / 32;
+            hipLaunchKernelGGL((gemm_nt_mfma_kernel<32, 32, 32>), dim3(MT8 * NT), dim3(256), 0, st, A, M, K, W, N, bias, R, C, act_tanh, MT, NT);
+        }
+    } else {
+        const int64_t total = M * N;
+        hipLaunchKernelGGL(gemm_nt_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A, M, K, W, N, bias, R, C, act_tanh);
+    }
+    prof_end(prof, &Profiler::gemm_nt, st, began);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ TN
+template <int BJ, int WI, int WJ>
+__global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restrict__ A, int I,
+                                                           const float *__restrict__ Bm, int J, int64_t M,
+                                                           int64_t chunk, float *__restrict__ slabs, int IT, int JT) {
+    constexpr int BI = 128, PS = 272;   // panel stride in LDS: 16 rows * 16 + 16 pad (bank shift 16)
+    constexpr int WAVES_J = BJ / WJ;
+    constexpr int TI = WI / 32, TJ = WJ / 32;
+    constexpr int PA = BI / 16, PB = BJ / 16;
+    constexpr int NBL = (PB * 64 + 255) / 256;
+    static_assert((BI / WI) * WAVES_J == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float As[2][PA * PS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][PB * PS];
+
+    const int tiles = IT * JT;
+    const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int it = tile / JT, jt = tile % JT;
+    const int i0 = it * BI, j0 = jt * BJ;
+    const int64_t r0 = (int64_t)split * chunk;
+    const int64_t r1 = (r0 + chunk < M) ? r0 + chunk : M;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w / WAVES_J, wc = w % WAVES_J;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[NBL];
+    auto load_tiles = [&](int64_t rr) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q, panel = e >> 6, rem = e & 63, row = rem >> 2, c4 = (rem & 3) * 4;
+            const int64_t gr = rr + row;
+            ra[q] = gr < r1 ? *reinterpret_cast<const float4 *>(A + ((int64_t)(i0 / 16 + panel) * M + gr) * 16 + c4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NBL; ++q) {
+            const int e = tid + 256 * q, panel = e >> 6, rem = e & 63, row = rem >> 2, c4 = (rem & 3) * 4;
+            const int64_t gr = rr + row;
+            if (e < PB * 64)
+                rb[q] = gr < r1 ? *reinterpret_cast<const float4 *>(Bm + ((int64_t)(j0 / 16 + panel) * M + gr) * 16 + c4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q, panel = e >> 6, rem = e & 63, row = rem >> 2, c4 = (rem & 3) * 4;
+            *reinterpret_cast<float4 *>(&As[buf][panel * PS + row * 16 + c4]) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NBL; ++q) {
+            const int e = tid + 256 * q, panel = e >> 6, rem = e & 63, row = rem >> 2, c4 = (rem & 3) * 4;
+            if (e < PB * 64) *reinterpret_cast<float4 *>(&Bs[buf][panel * PS + row * 16 + c4]) = rb[q];
+        }
+    };
+
+    int aoff[TI], boff[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int ci = wr * WI + i * 32 + l31;
+        aoff[i] = (ci >> 4) * PS + (ci & 15) + lhi * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int cj = wc * WJ + j * 32 + l31;
+        boff[j] = (cj >> 4) * PS + (cj & 15) + lhi * 16;
+    }
+
+    if (r0 < r1) {
+        load_tiles(r0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    int it_k = 0;
+    for (int64_t rr = r0; rr < r1; rr += 16, ++it_k) {
+        const int buf = it_k & 1;
+        const bool more = rr + 16 < r1;
+        if (more) load_tiles(rr + 16);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = As[buf][aoff[i] + 32 * s];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = Bs[buf][boff[j] + 32 * s];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    float *slab = slabs + (int64_t)split * I * J;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int gj = j0 + wc * WJ + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int gi = i0 + wr * WI + i * 32 + row;
+                slab[(int64_t)gi * J + gj] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void gemm_tn_generic_kernel(const float *__restrict__ A, int I, const float *__restrict__ Bm, int J,
+                                       int64_t M, int64_t chunk, float *__restrict__ slabs) {
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    const int split = blockIdx.y;
+    if (ij >= I * J) return;
+    const int i = ij / J, j = ij % J;
+    const int64_t r0 = (int64_t)split * chunk;
+    const int64_t r1 = (r0 + chunk < M) ? r0 + chunk : M;
+    const float *a = A + ((int64_t)(i >> 4) * M) * 16 + (i & 15);
+    const float *b = Bm + ((int64_t)(j >> 4) * M) * 16 + (j & 15);
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc = fmaf(a[r * 16], b[r * 16], acc);
+    slabs[(int64_t)split * I * J + ij] = acc;
+}
+
+static bool tn_use_mfma(int I, int J) { return I % 128 == 0 && J % 32 == 0; }
+
+int tn_splits(int I, int J, int64_t M) {
+    if (M <= 0) return 1;
+    int64_t tiles;
+    if (tn_use_mfma(I, J)) {
+        const int BJ = (J % 128 == 0) ? 128 : (J % 64 == 0 ? 64 : 32);
+        tiles = (int64_t)(I / 128) * (J / BJ);
+    } else {
+        tiles = ((int64_t)I * J + 255) / 256;
+    }
+    int64_t S = (1024 + tiles - 1) / tiles;
+    const int64_t max_s = (M + 511) / 512;   // at least 512 rows per split
+    if (S > max_s) S = max_s;
+    if (S < 1) S = 1;
+    if (S > 1024) S = 1024;
+    return (int)S;
+}
+
+int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, float *slabs, int *S_out,
+                   hipStream_t st, Profiler *prof) {
+    if (I % 16 != 0 || J % 16 != 0) return fail(UPAMD_E_INVALID, "gemm_tn: I and J must be multiples of 16 (I=%d J=%d)", I, J);
+    const int S = tn_splits(I, J, M);
+    *S_out = S;
+    if (M <= 0) {
+        UPAMD_HIP(hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)I * J, st));
+        return 0;
+    }
+    int64_t chunk = (M + S - 1) / S;
+    chunk = (chunk + 15) / 16 * 16;
+    const double flops = 2.0 * (double)M * I * J;
+    const double bytes = 4.0 * ((double)M * (I + J) + (double)S * I * J);
+    int began = prof_begin(prof, &Profiler::gemm_tn, st, flops, bytes);
+    if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
+    if (tn_use_mfma(I, J)) {
+        const int IT = I / 128;
+        if (J % 128 == 0) {
+            const int JT = J / 128;
+            hipLaunchKernelGGL((gemm_tn_mfma_kernel<128, 64, 64>), dim3(S * IT * JT), dim3(256), 0, st, A, I, Bm, J, M, chunk, slabs, IT, JT);
+        } else if (J % 64 == 0) {
+            const int JT = J / 64;
+            hipLaunchKernelGGL((gemm_tn_mfma_kernel<64, 64, 32>), dim3(S * IT * JT), dim3(256), 0, st, A, I, Bm, J, M, chunk, slabs, IT, JT);
+        } else {
+            const int JT = J / 32;
+            hipLaunchKernelGGL((gemm_tn_mfma_kernel<32, 32, 32>), dim3(S * IT * JT), dim3(256), 0, st, A, I, Bm, J, M, chunk, slabs, IT, JT);
+        }
+    } else {
+        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((I * J + 255) / 256, S), dim3(256), 0, st, A, I, Bm, J, M, chunk, slabs);
+    }
+    prof_end(prof, &Profiler::gemm_tn, st, began);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int S, int I, int J, int mode, int jkeep,
+                                    float *__restrict__ dst, int ldd) {
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= I * J) return;
+    const int i = ij / J, j = ij % J;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += slabs[(int64_t)s * I * J + ij];
+    if (mode == 0) {
+        if (j < jkeep) dst[(int64_t)i * ldd + j] += acc;
+    } else if (mode == 1) {
+        dst[(int64_t)j * ldd + i] += acc;
+    } else {
+        // slab row i = permuted P/Q column j' of the layer; slab col j = input feature k
+        const int row = (i >> 5) * 16 + (i & 15);
+        const int half = (i >> 4) & 1;
+        dst[(int64_t)row * ldd + half * J + j] += acc;
+    }
+}
+
+int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int jkeep, float *dst, int ldd,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, slabs, S, I, J, mode, jkeep, dst, ldd);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace upamd

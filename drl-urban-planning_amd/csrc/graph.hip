@@ -1,0 +1,728 @@
+// Ragged-graph kernels (gfx950, wave64): message passing, single-query attention, pointer heads.
+//
+// One workgroup handles one (graph, 16-column panel): the graph's P/Q projections for those 16
+// columns are a contiguous n*64 B run in the panel-major layout and are staged into LDS once
+// (coalesced 16 B loads); every neighbour gather then hits LDS.  A wave processes one node at a
+// time: lanes = 16 columns x 4 neighbour slots, the 4 partial sums are combined with two
+// __shfl_xor steps -- CSR-by-destination segment sums in a fixed order, no atomics, so results
+// are run-to-run deterministic.
+//
+// Reference math (urban_planning/models/state_encoder.py:110-148,194-197): for a live edge (i,j)
+//   m_ij = 1/2 [ tanh(W [h_i;h_j] + b) + tanh(W [h_j;h_i] + b) ],  h_v += sum_{e touches v} m_e / (deg_v + 1e-6)
+// with W [h_i;h_j] = P_i + Q_j where P = H Wa^T, Q = H Wb^T (W = [Wa | Wb]) come from the node GEMM.
+#include "kernels.h"
+
+namespace upamd {
+
+__device__ __forceinline__ float fast_tanh(float x) {
+    float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+#define META(t) (pk.meta + (int64_t)(t) * UPAMD_META_STRIDE)
+
+// ------------------------------------------------------------------------------------------
+// inputs of a minibatch: node features -> panel-major (K padded to 32), numerical + current node
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_inputs_kernel(PackedView pk, MbView mb, float *__restrict__ Xp,
+                                                            float *__restrict__ U0, float *__restrict__ curg) {
+    const int b = blockIdx.x;
+    const int t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int n = m[0];
+    const int64_t src0 = m[9], o = mb.node_off[b], M = mb.M;
+    // 8 threads per node row: thread q copies floats [4q, 4q+4) of the 32-wide padded row
+    for (int i = threadIdx.x; i < n * 8; i += 256) {
+        const int v = i >> 3, q = i & 7;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < 6) val = *reinterpret_cast<const float4 *>(pk.X + (src0 + v) * UPAMD_NODE_PAD + q * 4);
+        const int panel = q >> 2, c4 = (q & 3) * 4;
+        *reinterpret_cast<float4 *>(Xp + ((int64_t)panel * M + o + v) * 16 + c4) = val;
+    }
+    for (int i = threadIdx.x; i < pk.Fn; i += 256) U0[(int64_t)b * pk.Fn + i] = pk.numerical[(int64_t)t * pk.Fn + i];
+    if (threadIdx.x < UPAMD_NODE_PAD) curg[(int64_t)b * UPAMD_NODE_PAD + threadIdx.x] = pk.cur[(int64_t)t * UPAMD_NODE_PAD + threadIdx.x];
+}
+
+int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st) {
+    hipLaunchKernelGGL(gather_inputs_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, Xp, U0, curg);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// GCN layer forward: H_out = H_in + S / (deg + 1e-6);  last layer also emits the masked node mean
+// and the edge mean (= 1/2 sum_v S_v / e, each message is counted at both endpoints).
+// ------------------------------------------------------------------------------------------
+constexpr int64_t LDS_LIMIT = 160 * 1024;
+
+int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage) {
+    int64_t b = 0;
+    if (stage) b += (int64_t)max_n * 64 * (bwd ? 3 : 2);      // P, Q (, dS) slices
+    b += ((int64_t)max_n + 1) * 4;                            // row_ptr
+    b += (int64_t)max_inc * 2 * ((bwd && last) ? 2 : 1);      // neighbour ids (, head-edge ids)
+    b = (b + 15) / 16 * 16;
+    b += 4 * 2 * 16 * 4;                                      // cross-wave reduction scratch
+    return b;
+}
+
+template <bool LAST, bool STAGE>
+__global__ __launch_bounds__(256) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
+                                                       const float *__restrict__ PQ, const float *__restrict__ bias,
+                                                       const float *__restrict__ Hin, float *__restrict__ Hout,
+                                                       float *__restrict__ hbarV, float *__restrict__ hbarE) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x / NP, p = blockIdx.x % NP;
+    const int t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int n = m[0], e = m[1];
+    const int64_t o = mb.node_off[b], M = mb.M;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+
+    unsigned char *sp = smem;
+    float *Pl = nullptr, *Ql = nullptr;
+    if (STAGE) {
+        Pl = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
+        Ql = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
+    }
+    int *rp = reinterpret_cast<int *>(sp); sp += ((int64_t)n + 1) * 4;
+    uint16_t *nb = reinterpret_cast<uint16_t *>(sp); sp += (int64_t)e * 4;
+    float *red = reinterpret_cast<float *>(smem + (((sp - smem) + 15) / 16 * 16));
+
+    const float *Pg = PQ + ((int64_t)(2 * p) * M + o) * 16;
+    const float *Qg = PQ + ((int64_t)(2 * p + 1) * M + o) * 16;
+    if (STAGE) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(Pg);
+        const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
+        for (int i = tid; i < n * 4; i += 256) {
+            reinterpret_cast<float4 *>(Pl)[i] = s4[i];
+            reinterpret_cast<float4 *>(Ql)[i] = q4[i];
+        }
+    }
+    const int32_t *rpg = pk.rowptr + m[13];
+    for (int i = tid; i <= n; i += 256) rp[i] = rpg[i];
+    const uint32_t *nbg = reinterpret_cast<const uint32_t *>(pk.inc_nbr + 2 * (int64_t)m[10]);
+    for (int i = tid; i < e; i += 256) reinterpret_cast<uint32_t *>(nb)[i] = nbg[i];
+    __syncthreads();
+
+    const float *Ps = STAGE ? Pl : Pg;
+    const float *Qs = STAGE ? Ql : Qg;
+    const float bc = bias[p * 16 + c];
+    const uint8_t *nmask = pk.nmask + m[9];
+    float sumS = 0.f, sumH = 0.f;
+    for (int v = w; v < n; v += 4) {
+        const float pv = Ps[v * 16 + c] + bc, qv = Qs[v * 16 + c] + bc;
+        const int k0 = rp[v], k1 = rp[v + 1];
+        float acc = 0.f;
+        for (int k = k0 + g; k < k1; k += 4) {
+            const int u = nb[k];
+            const float pu = Ps[u * 16 + c], qu = Qs[u * 16 + c];
+            acc += fast_tanh(pv + qu) + fast_tanh(pu + qv);
+        }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        const float S = 0.5f * acc;
+        const float a = S / ((float)(k1 - k0) + 1e-6f);
+        const int64_t go = ((int64_t)p * M + o + v) * 16 + c;
+        const float h = Hin[go] + a;
+        if (g == 0) Hout[go] = h;
+        if (LAST) {
+            sumS += S;
+            if (nmask[v]) sumH += h;
+        }
+    }
+    if (LAST) {
+        if (g == 0) {
+            red[(w * 2 + 0) * 16 + c] = sumS;
+            red[(w * 2 + 1) * 16 + c] = sumH;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, cc = tid & 15;
+            const float tot = red[(0 * 2 + which) * 16 + cc] + red[(1 * 2 + which) * 16 + cc] +
+                              red[(2 * 2 + which) * 16 + cc] + red[(3 * 2 + which) * 16 + cc];
+            const int D = NP * 16;
+            if (which == 0) hbarE[(int64_t)b * D + p * 16 + cc] = 0.5f * tot / (float)e;
+            else hbarV[(int64_t)b * D + p * 16 + cc] = tot / (float)m[6];
+        }
+    }
+}
+
+int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
+                    const float *Hin, float *Hout, float *hbarV, float *hbarE, hipStream_t st, Profiler *prof) {
+    const int NP = D / 16;
+    bool stage = true;
+    int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, true);
+    if (lds > LDS_LIMIT) {
+        stage = false;
+        lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, false);
+        if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_fwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof && prof->on) {
+        hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st);
+        prof->edge_fwd.ev.push_back(e0); prof->edge_fwd.ev.push_back(e1); prof->edge_fwd.launches++;
+    }
+    dim3 grid((unsigned)(mb.B * NP)), block(256);
+#define UPAMD_EF(L_, S_)                                                                                              \
+    do {                                                                                                              \
+        if (lds > 64 * 1024)                                                                                          \
+            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_>),                   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        hipLaunchKernelGGL((edge_fwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, Hout,  \
+                           hbarV, hbarE);                                                                             \
+    } while (0)
+    if (last && stage) UPAMD_EF(true, true);
+    else if (last) UPAMD_EF(true, false);
+    else if (stage) UPAMD_EF(false, true);
+    else UPAMD_EF(false, false);
+#undef UPAMD_EF
+    if (e1) hipEventRecord(e1, st);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// GCN layer backward w.r.t. P and Q (node-centric, recomputes the tanh's):
+//   dS_v = G_v / (deg_v + 1e-6) (+ 1/2 dhbarE / e on the last layer)
+//   dm_(v,u) = dS_v + dS_u (+ pointer-head gradient of that edge on the last layer)
+//   dP_v = sum_u 1/2 dm (1 - tanh^2(P_v + Q_u + b)),  dQ_v = sum_u 1/2 dm (1 - tanh^2(P_u + Q_v + b))
+// ------------------------------------------------------------------------------------------
+template <bool LAST, bool STAGE>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(PackedView pk, MbView mb, int NP,
+                                                       const float *__restrict__ PQ, const float *__restrict__ bias,
+                                                       const float *__restrict__ G, const float *__restrict__ dhbarE,
+                                                       int ld_dhbarE, const float *__restrict__ dMhe,
+                                                       float *__restrict__ dPQ, float *__restrict__ dbias_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x / NP, p = blockIdx.x % NP;
+    const int t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int n = m[0], e = m[1];
+    const int64_t o = mb.node_off[b], M = mb.M;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+
+    unsigned char *sp = smem;
+    float *Pl = nullptr, *Ql = nullptr, *Sl = nullptr;
+    if (STAGE) {
+        Pl = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
+        Ql = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
+        Sl = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
+    }
+    int *rp = reinterpret_cast<int *>(sp); sp += ((int64_t)n + 1) * 4;
+    uint16_t *nb = reinterpret_cast<uint16_t *>(sp); sp += (int64_t)e * 4;
+    uint16_t *he = nullptr;
+    if (LAST) { he = reinterpret_cast<uint16_t *>(sp); sp += (int64_t)e * 4; }
+    float *red = reinterpret_cast<float *>(smem + (((sp - smem) + 15) / 16 * 16));
+
+    const float *Pg = PQ + ((int64_t)(2 * p) * M + o) * 16;
+    const float *Qg = PQ + ((int64_t)(2 * p + 1) * M + o) * 16;
+    const float *Gg = G + ((int64_t)p * M + o) * 16;
+    if (STAGE) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(Pg);
+        const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
+        for (int i = tid; i < n * 4; i += 256) {
+            reinterpret_cast<float4 *>(Pl)[i] = s4[i];
+            reinterpret_cast<float4 *>(Ql)[i] = q4[i];
+        }
+    }
+    const int32_t *rpg = pk.rowptr + m[13];
+    for (int i = tid; i <= n; i += 256) rp[i] = rpg[i];
+    const uint32_t *nbg = reinterpret_cast<const uint32_t *>(pk.inc_nbr + 2 * (int64_t)m[10]);
+    for (int i = tid; i < e; i += 256) reinterpret_cast<uint32_t *>(nb)[i] = nbg[i];
+    if (LAST) {
+        const uint32_t *heg = reinterpret_cast<const uint32_t *>(pk.inc_he + 2 * (int64_t)m[10]);
+        for (int i = tid; i < e; i += 256) reinterpret_cast<uint32_t *>(he)[i] = heg[i];
+    }
+    __syncthreads();
+    float extra = 0.f;     // same for every node of the graph, depends on the lane's column
+    if (LAST) extra = 0.5f * dhbarE[(int64_t)b * ld_dhbarE + p * 16 + c] / (float)e;
+    if (STAGE) {
+        for (int i = tid; i < n * 16; i += 256) {
+            const int v = i >> 4, cc = i & 15;
+            float ex = 0.f;
+            if (LAST) ex = 0.5f * dhbarE[(int64_t)b * ld_dhbarE + p * 16 + cc] / (float)e;
+            Sl[i] = Gg[i] / ((float)(rp[v + 1] - rp[v]) + 1e-6f) + ex;
+        }
+        __syncthreads();
+    }
+    const float *Ps = STAGE ? Pl : Pg;
+    const float *Qs = STAGE ? Ql : Qg;
+    const float bc = bias[p * 16 + c];
+    const int64_t he0 = LAST ? (int64_t)mb.he_off[b] : 0;
+    float sumdP = 0.f;
+    for (int v = w; v < n; v += 4) {
+        const float pv = Ps[v * 16 + c] + bc, qv = Qs[v * 16 + c] + bc;
+        const int k0 = rp[v], k1 = rp[v + 1];
+        const float sv = STAGE ? Sl[v * 16 + c] : (Gg[v * 16 + c] / ((float)(k1 - k0) + 1e-6f) + extra);
+        float accP = 0.f, accQ = 0.f;
+        for (int k = k0 + g; k < k1; k += 4) {
+            const int u = nb[k];
+            const float pu = Ps[u * 16 + c], qu = Qs[u * 16 + c];
+            const float su = STAGE ? Sl[u * 16 + c]
+                                   : (Gg[u * 16 + c] / ((float)(rp[u + 1] - rp[u]) + 1e-6f) + extra);
+            float dm = sv + su;
+            if (LAST) {
+                const int h = he[k];
+                if (h != 0xFFFF) dm += dMhe[((int64_t)p * mb.Nhe + he0 + h) * 16 + c];
+            }
+            const float t1 = fast_tanh(pv + qu), t2 = fast_tanh(pu + qv);
+            accP = fmaf(dm, 1.f - t1 * t1, accP);
+            accQ = fmaf(dm, 1.f - t2 * t2, accQ);
+        }
+        accP += __shfl_xor(accP, 16);
+        accP += __shfl_xor(accP, 32);
+        accQ += __shfl_xor(accQ, 16);
+        accQ += __shfl_xor(accQ, 32);
+        const float dP = 0.5f * accP, dQ = 0.5f * accQ;
+        if (g == 0) {
+            dPQ[((int64_t)(2 * p) * M + o + v) * 16 + c] = dP;
+            dPQ[((int64_t)(2 * p + 1) * M + o + v) * 16 + c] = dQ;
+        }
+        sumdP += dP;
+    }
+    if (g == 0) red[w * 16 + c] = sumdP;
+    __syncthreads();
+    if (tid < 16) dbias_part[(int64_t)b * (NP * 16) + p * 16 + tid] = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+}
+
+int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
+                    const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
+                    float *dbias_part, hipStream_t st, Profiler *prof) {
+    const int NP = D / 16;
+    bool stage = true;
+    int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, true);
+    if (lds > LDS_LIMIT) {
+        stage = false;
+        lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, false);
+        if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_bwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof && prof->on) {
+        hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st);
+        prof->edge_bwd.ev.push_back(e0); prof->edge_bwd.ev.push_back(e1); prof->edge_bwd.launches++;
+    }
+    dim3 grid((unsigned)(mb.B * NP)), block(256);
+#define UPAMD_EB(L_, S_)                                                                                              \
+    do {                                                                                                              \
+        if (lds > 64 * 1024)                                                                                          \
+            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_>),                   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        hipLaunchKernelGGL((edge_bwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G, dhbarE,  \
+                           ld_dhbarE, dMhe, dPQ, dbias_part);                                                         \
+    } while (0)
+    if (last && stage) UPAMD_EB(true, true);
+    else if (last) UPAMD_EB(true, false);
+    else if (stage) UPAMD_EB(false, true);
+    else UPAMD_EB(false, false);
+#undef UPAMD_EB
+    if (e1) hipEventRecord(e1, st);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-query attention over a graph's node_mask nodes (state_encoder.py:150-161 with the
+// key/value projections collapsed: score_j = r . h_j, out = Wvv (sum_j alpha_j h_j) + bvv).
+// One workgroup per graph.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_reduce_sum(float v, float *red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_reduce_max(float v, float *red) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// acc[row j] = sum_d vec[d] * H[j][d] for the graph's rows (vec in LDS)
+__device__ __forceinline__ float row_dot(const float *__restrict__ Hg, int64_t M, int NP, int j, const float *vec) {
+    float acc = 0.f;
+    for (int p = 0; p < NP; ++p) {
+        const float4 *h4 = reinterpret_cast<const float4 *>(Hg + ((int64_t)p * M + j) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 h = h4[q];
+            const float *vv = vec + p * 16 + q * 4;
+            acc = fmaf(h.x, vv[0], acc); acc = fmaf(h.y, vv[1], acc); acc = fmaf(h.z, vv[2], acc); acc = fmaf(h.w, vv[3], acc);
+        }
+    }
+    return acc;
+}
+
+// out[d] = sum_j wgt[j] * H[j][d]  (wgt in LDS, len n); 256 threads = 16 cols x 16 row groups
+__device__ __forceinline__ void weighted_colsum(const float *__restrict__ Hg, int64_t M, int NP, int n,
+                                                const float *wgt, float *part, float *__restrict__ out) {
+    const int c = threadIdx.x & 15, jg = threadIdx.x >> 4;
+    for (int p = 0; p < NP; ++p) {
+        float acc = 0.f;
+        for (int j = jg; j < n; j += 16) acc = fmaf(wgt[j], Hg[((int64_t)p * M + j) * 16 + c], acc);
+        __syncthreads();
+        part[jg * 16 + c] = acc;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += part[q * 16 + threadIdx.x];
+            out[p * 16 + threadIdx.x] = tot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(PackedView pk, MbView mb, int NP, int heads,
+                                                       const float *__restrict__ HL, const float *__restrict__ r,
+                                                       float *__restrict__ alpha, float *__restrict__ s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int D = NP * 16;
+    float *vec = reinterpret_cast<float *>(smem);          // [D]
+    float *sc = vec + D;                                   // [max_n]
+    float *part = sc + mb.max_n;                           // [256]
+    float *red = part + 256;                               // [4]
+    const int b = blockIdx.x, t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int n = m[0];
+    const int64_t o = mb.node_off[b], M = mb.M;
+    const float *Hg = HL + o * 16;
+    const uint8_t *nmask = pk.nmask + m[9];
+    for (int h = 0; h < heads; ++h) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < D; i += 256) vec[i] = r[((int64_t)b * heads + h) * D + i];
+        __syncthreads();
+        float mx = -INFINITY;
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const float v = nmask[j] ? row_dot(Hg, M, NP, j, vec) : -INFINITY;
+            sc[j] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = block_reduce_max(mx, red);
+        float sum = 0.f;
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const float ex = expf(sc[j] - mx);
+            sc[j] = ex;
+            sum += ex;
+        }
+        sum = block_reduce_sum(sum, red);
+        const float inv = 1.f / sum;
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const float a = sc[j] * inv;
+            sc[j] = a;
+            alpha[(int64_t)h * M + o + j] = a;
+        }
+        __syncthreads();
+        weighted_colsum(Hg, M, NP, n, sc, part, s + ((int64_t)b * heads + h) * D);
+    }
+}
+
+int launch_attn_fwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
+                    float *alpha, float *s, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(D + mb.max_n + 256 + 8);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(mb.B), dim3(256), lds, st, pk, mb, D / 16, heads, HL, r, alpha, s);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// backward: GL (written) = masked-mean term + attention terms;  dr[b,h,:] = sum_j dscore_j h_j
+__global__ __launch_bounds__(256) void attn_bwd_kernel(PackedView pk, MbView mb, int NP, int heads,
+                                                       const float *__restrict__ HL, const float *__restrict__ r,
+                                                       const float *__restrict__ alpha, const float *__restrict__ ds,
+                                                       const float *__restrict__ dhbarV, int ld_dhbarV,
+                                                       float *__restrict__ GL, float *__restrict__ dr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int D = NP * 16;
+    float *dsl = reinterpret_cast<float *>(smem);          // [heads][D]
+    float *rl = dsl + heads * D;                           // [heads][D]
+    float *al = rl + heads * D;                            // [heads][max_n]
+    float *dscl = al + heads * mb.max_n;                   // [heads][max_n]
+    float *part = dscl + heads * mb.max_n;                 // [256]
+    float *red = part + 256;                               // [4]
+    const int b = blockIdx.x, t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int n = m[0];
+    const int64_t o = mb.node_off[b], M = mb.M;
+    const float *Hg = HL + o * 16;
+    const uint8_t *nmask = pk.nmask + m[9];
+    for (int i = threadIdx.x; i < heads * D; i += 256) {
+        dsl[i] = ds[(int64_t)b * heads * D + i];
+        rl[i] = r[(int64_t)b * heads * D + i];
+    }
+    __syncthreads();
+    for (int h = 0; h < heads; ++h) {
+        float *a_h = al + h * mb.max_n, *d_h = dscl + h * mb.max_n;
+        float dot = 0.f;
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const float a = alpha[(int64_t)h * M + o + j];
+            const float da = nmask[j] ? row_dot(Hg, M, NP, j, dsl + h * D) : 0.f;
+            a_h[j] = a;
+            d_h[j] = da;
+            dot = fmaf(a, da, dot);
+        }
+        dot = block_reduce_sum(dot, red);
+        for (int j = threadIdx.x; j < n; j += 256) d_h[j] = a_h[j] * (d_h[j] - dot);
+        __syncthreads();
+        weighted_colsum(Hg, M, NP, n, d_h, part, dr + ((int64_t)b * heads + h) * D);
+    }
+    __syncthreads();
+    const float inv_nm = 1.f / (float)m[6];
+    for (int i = threadIdx.x; i < n * 16; i += 256) {
+        const int j = i >> 4, cc = i & 15;
+        const bool live = nmask[j] != 0;
+        for (int p = 0; p < NP; ++p) {
+            const int d = p * 16 + cc;
+            float v = live ? dhbarV[(int64_t)b * ld_dhbarV + d] * inv_nm : 0.f;
+            for (int h = 0; h < heads; ++h)
+                v += al[h * mb.max_n + j] * dsl[h * D + d] + dscl[h * mb.max_n + j] * rl[h * D + d];
+            GL[((int64_t)p * M + o + j) * 16 + cc] = v;
+        }
+    }
+}
+
+int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
+                    const float *alpha, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL, float *dr,
+                    hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(2 * heads * D + 2 * heads * mb.max_n + 256 + 8);
+    if (lds > (size_t)LDS_LIMIT) return fail(UPAMD_E_LIMIT, "attn_bwd: LDS need %zu too large", lds);
+    if (lds > 64 * 1024)
+        UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(mb.B), dim3(256), lds, st, pk, mb, D / 16, heads, HL, r, alpha, ds, dhbarV, ld_dhbarV, GL, dr);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Land-use pointer head input (state_encoder.py:207-210): for each candidate edge (i,j) of a
+// stage-0 row: m = last layer's message, features [m ; c ; m*c ; m-c] (c = current-node embedding).
+// Only land_use_mask candidates are materialised (all other logits carry probability 0).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void he_feat_fwd_kernel(PackedView pk, MbView mb, int NP,
+                                                          const float *__restrict__ PQ, const float *__restrict__ bias,
+                                                          const float *__restrict__ C, float *__restrict__ FE) {
+    const int b = blockIdx.x, t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int nh = m[2];
+    if (nh == 0) return;
+    const int64_t o = mb.node_off[b], M = mb.M, q0 = mb.he_off[b], NH = mb.Nhe;
+    const int c = threadIdx.x & 15;
+    const int D = NP * 16;
+    for (int q = threadIdx.x >> 4; q < nh; q += 16) {
+        const int i = pk.he_src[m[11] + q], j = pk.he_dst[m[11] + q];
+        const bool live = pk.he_live[m[11] + q] != 0;
+        const int64_t row = q0 + q;
+        for (int p = 0; p < NP; ++p) {
+            const float bc = bias[p * 16 + c];
+            float mm = 0.f;
+            if (live) {
+                const float Pi = PQ[((int64_t)(2 * p) * M + o + i) * 16 + c], Qj = PQ[((int64_t)(2 * p + 1) * M + o + j) * 16 + c];
+                const float Pj = PQ[((int64_t)(2 * p) * M + o + j) * 16 + c], Qi = PQ[((int64_t)(2 * p + 1) * M + o + i) * 16 + c];
+                mm = 0.5f * (fast_tanh(Pi + Qj + bc) + fast_tanh(Pj + Qi + bc));
+            }
+            const float cc = C[(int64_t)b * D + p * 16 + c];
+            FE[((int64_t)p * NH + row) * 16 + c] = mm;
+            FE[((int64_t)(NP + p) * NH + row) * 16 + c] = cc;
+            FE[((int64_t)(2 * NP + p) * NH + row) * 16 + c] = mm * cc;
+            FE[((int64_t)(3 * NP + p) * NH + row) * 16 + c] = mm - cc;
+        }
+    }
+}
+
+int launch_he_feat_fwd(const PackedView &pk, const MbView &mb, int D, const float *PQ, const float *bias,
+                       const float *C, float *FE, hipStream_t st) {
+    if (mb.Nhe == 0) return 0;
+    hipLaunchKernelGGL(he_feat_fwd_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, D / 16, PQ, bias, C, FE);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// dMhe(pm)[row][d] = live * (g1 + g3*c + g4);   dC_head[b][d] = sum_rows (g2 + g3*m - g4)
+__global__ __launch_bounds__(256) void he_feat_bwd_kernel(PackedView pk, MbView mb, int NP,
+                                                          const float *__restrict__ FE, const float *__restrict__ C,
+                                                          const float *__restrict__ dFE, float *__restrict__ dMhe,
+                                                          float *__restrict__ dC_head) {
+    __shared__ float part[256];
+    const int b = blockIdx.x, t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int nh = m[2];
+    const int D = NP * 16;
+    const int c = threadIdx.x & 15, qg = threadIdx.x >> 4;
+    const int64_t q0 = mb.he_off[b], NH = mb.Nhe;
+    for (int p = 0; p < NP; ++p) {
+        float acc = 0.f;
+        const float cc = C[(int64_t)b * D + p * 16 + c];
+        for (int q = qg; q < nh; q += 16) {
+            const int64_t row = q0 + q;
+            const float live = pk.he_live[m[11] + q] ? 1.f : 0.f;
+            const float mm = FE[((int64_t)p * NH + row) * 16 + c];
+            const float g1 = dFE[((int64_t)p * NH + row) * 16 + c], g2 = dFE[((int64_t)(NP + p) * NH + row) * 16 + c];
+            const float g3 = dFE[((int64_t)(2 * NP + p) * NH + row) * 16 + c], g4 = dFE[((int64_t)(3 * NP + p) * NH + row) * 16 + c];
+            dMhe[((int64_t)p * NH + row) * 16 + c] = live * (g1 + g3 * cc + g4);
+            acc += g2 + g3 * mm - g4;
+        }
+        __syncthreads();
+        part[qg * 16 + c] = acc;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += part[q * 16 + threadIdx.x];
+            dC_head[(int64_t)b * D + p * 16 + threadIdx.x] = tot;
+        }
+    }
+}
+
+int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
+                       const float *dFE, float *dMhe, float *dC_head, hipStream_t st) {
+    hipLaunchKernelGGL(he_feat_bwd_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, D / 16, FE, C, dFE, dMhe, dC_head);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// road head input: rows of H^L of the road_mask candidates (stage-1 rows), policy.py:58
+__global__ __launch_bounds__(256) void road_gather_kernel(PackedView pk, MbView mb, int NP, const float *__restrict__ HL,
+                                                          float *__restrict__ XR) {
+    const int b = blockIdx.x, t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int nr = m[3];
+    const int64_t o = mb.node_off[b], M = mb.M, q0 = mb.rn_off[b], NR = mb.Nrn;
+    const int c = threadIdx.x & 15;
+    for (int q = threadIdx.x >> 4; q < nr; q += 16) {
+        const int v = pk.rn_node[m[12] + q];
+        for (int p = 0; p < NP; ++p) XR[((int64_t)p * NR + q0 + q) * 16 + c] = HL[((int64_t)p * M + o + v) * 16 + c];
+    }
+}
+int launch_road_gather(const PackedView &pk, const MbView &mb, int D, const float *HL, float *XR, hipStream_t st) {
+    if (mb.Nrn == 0) return 0;
+    hipLaunchKernelGGL(road_gather_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, D / 16, HL, XR);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+__global__ __launch_bounds__(256) void road_scatter_add_kernel(PackedView pk, MbView mb, int NP,
+                                                               const float *__restrict__ dXR, float *__restrict__ GL) {
+    const int b = blockIdx.x, t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int nr = m[3];
+    const int64_t o = mb.node_off[b], M = mb.M, q0 = mb.rn_off[b], NR = mb.Nrn;
+    const int c = threadIdx.x & 15;
+    for (int q = threadIdx.x >> 4; q < nr; q += 16) {      // candidate nodes of a row are distinct: no conflicts
+        const int v = pk.rn_node[m[12] + q];
+        for (int p = 0; p < NP; ++p) GL[((int64_t)p * M + o + v) * 16 + c] += dXR[((int64_t)p * NR + q0 + q) * 16 + c];
+    }
+}
+int launch_road_scatter_add(const PackedView &pk, const MbView &mb, int D, const float *dXR, float *GL, hipStream_t st) {
+    if (mb.Nrn == 0) return 0;
+    hipLaunchKernelGGL(road_scatter_add_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, D / 16, dXR, GL);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Masked-softmax pointer head over each row's candidate list (policy.py:49-52,58-61,87-104 with
+// torch.distributions.Categorical): log_prob of the taken action, entropy.  One wave per row.
+// Rows whose stage is neither 0 nor 1 get logp = entropy = 0 (policy.py:90-91).  A row with no
+// valid candidate reproduces the reference's uniform distribution over the padded row.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void pointer_fwd_kernel(PackedView pk, MbView mb, const float *__restrict__ z_he,
+                                                          const float *__restrict__ z_rn, float *__restrict__ p_he,
+                                                          float *__restrict__ p_rn, float *__restrict__ logp,
+                                                          float *__restrict__ ent, float *__restrict__ lse_out) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= mb.B) return;
+    const int lane = threadIdx.x & 63;
+    const int32_t *m = META(mb.idx[b]);
+    const int stage = m[4];
+    if (stage > 1) {
+        if (lane == 0) { logp[b] = 0.f; ent[b] = 0.f; lse_out[b] = 0.f; }
+        return;
+    }
+    const int cnt = stage == 0 ? m[2] : m[3];
+    const int64_t off = stage == 0 ? mb.he_off[b] : mb.rn_off[b];
+    const float *z = (stage == 0 ? z_he : z_rn) + off;
+    float *pp = (stage == 0 ? p_he : p_rn) + off;
+    const float npad = (float)(stage == 0 ? m[8] : m[7]);
+    if (cnt == 0) {
+        if (lane == 0) { logp[b] = -logf(npad); ent[b] = logf(npad); lse_out[b] = 0.f; }
+        return;
+    }
+    float mx = -INFINITY;
+    for (int i = lane; i < cnt; i += 64) mx = fmaxf(mx, z[i]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < cnt; i += 64) sum += expf(z[i] - mx);
+    sum = wave_sum(sum);
+    const float lse = mx + logf(sum);
+    float pz = 0.f;
+    for (int i = lane; i < cnt; i += 64) {
+        const float lp = z[i] - lse;
+        const float p = expf(lp);
+        pp[i] = p;
+        pz += p * lp;
+    }
+    pz = wave_sum(pz);
+    if (lane == 0) {
+        const int a = m[5];
+        logp[b] = (a >= 0 ? z[a] : -4294967296.0f) - lse;
+        ent[b] = -pz;
+        lse_out[b] = lse;
+    }
+}
+
+int launch_pointer_fwd(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn, float *p_he,
+                       float *p_rn, float *logp, float *ent, float *lse, hipStream_t st) {
+    hipLaunchKernelGGL(pointer_fwd_kernel, dim3((mb.B + 3) / 4), dim3(256), 0, st, pk, mb, z_he, z_rn, p_he, p_rn, logp, ent, lse);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// dz_k = dlogp (delta_ka - p_k) - dent p_k (log p_k + H)
+__global__ __launch_bounds__(256) void pointer_bwd_kernel(PackedView pk, MbView mb, const float *__restrict__ z_he,
+                                                          const float *__restrict__ z_rn, const float *__restrict__ p_he,
+                                                          const float *__restrict__ p_rn, const float *__restrict__ ent,
+                                                          const float *__restrict__ lse, const float *__restrict__ dlogp,
+                                                          const float *__restrict__ dent, float *__restrict__ dz_he,
+                                                          float *__restrict__ dz_rn) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= mb.B) return;
+    const int lane = threadIdx.x & 63;
+    const int32_t *m = META(mb.idx[b]);
+    const int stage = m[4];
+    if (stage > 1) return;
+    const int cnt = stage == 0 ? m[2] : m[3];
+    const int64_t off = stage == 0 ? mb.he_off[b] : mb.rn_off[b];
+    const float *z = (stage == 0 ? z_he : z_rn) + off;
+    const float *pp = (stage == 0 ? p_he : p_rn) + off;
+    float *dz = (stage == 0 ? dz_he : dz_rn) + off;
+    const float gl = dlogp[b], ge = dent[b], H = ent[b], ls = lse[b];
+    const int a = m[5];
+    for (int i = lane; i < cnt; i += 64) {
+        const float p = pp[i];
+        float v = -gl * p - ge * p * ((z[i] - ls) + H);
+        if (i == a) v += gl;
+        dz[i] = v;
+    }
+}
+
+int launch_pointer_bwd(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn,
+                       const float *p_he, const float *p_rn, const float *ent, const float *lse, const float *dlogp,
+                       const float *dent, float *dz_he, float *dz_rn, hipStream_t st) {
+    hipLaunchKernelGGL(pointer_bwd_kernel, dim3((mb.B + 3) / 4), dim3(256), 0, st, pk, mb, z_he, z_rn, p_he, p_rn, ent, lse, dlogp, dent, dz_he, dz_rn);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace upamd

@@ -1,0 +1,122 @@
+// Launchers of the HIP kernels (gfx950).  Host-callable, asynchronous on `stream`.
+//
+// Data layouts
+//   row-major   [rows][ld]                        -- per-sample tensors ([B, .]), weights
+//   panel-major [cols/16][rows][16]  ("pm")       -- every per-node / per-candidate tensor.
+//     A graph's 16-column slice is one contiguous run (n*64 B), which is what the edge kernels
+//     stage into LDS and what the GEMM A-tile loads stream.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "upamd_internal.h"
+
+namespace upamd {
+
+struct PackedView {   // device pointers into the packed replay (upamd_pack_layout)
+    const int32_t *meta;
+    const float *X;
+    const uint8_t *nmask;
+    const int32_t *rowptr;
+    const uint16_t *inc_nbr, *inc_he, *he_src, *he_dst, *rn_node;
+    const uint8_t *he_live;
+    const float *numerical, *cur;
+    int Fn;
+};
+
+struct MbView {       // one minibatch (device schedule arrays)
+    int B;
+    int64_t M, Nhe, Nrn;
+    int max_n, max_inc;
+    const int32_t *idx, *node_off, *he_off, *rn_off;
+};
+
+struct KernelStat {
+    int64_t launches = 0;
+    double flops = 0, bytes = 0;
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+};
+
+struct Profiler {
+    bool on = false;
+    KernelStat gemm_nt, gemm_tn, edge_fwd, edge_bwd;
+};
+
+// ---- gemm.hip --------------------------------------------------------------------------
+// C[M,N](pm) = act( A[M,K](pm) * W[N,K]^T (row-major, ld = K) + bias[N] + R[M,N](pm) )
+int launch_gemm_nt(const float *A, int64_t M, int K, const float *W, int N, const float *bias, const float *R,
+                   float *C, int act_tanh, hipStream_t st, Profiler *prof);
+// slabs[S][I][J] = partial sums over row chunks of A[M,I](pm)^T * Bm[M,J](pm);  returns S via *S_out
+int tn_splits(int I, int J, int64_t M);
+int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, float *slabs, int *S_out,
+                   hipStream_t st, Profiler *prof);
+// dst (+)= sum_s slabs[s]:  mode 0: dst[i*ldd + j], j < jkeep;  mode 1: dst[j*ldd + i];
+// mode 2: GCN un-permute, slab row j' -> dst[((j'/32)*16 + j'%16)*ldd + ((j'/16)&1)*J + k]
+int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int jkeep, float *dst, int ldd,
+                        hipStream_t st);
+
+// ---- graph.hip -------------------------------------------------------------------------
+int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st);
+int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage);
+int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
+                    const float *Hin, float *Hout, float *hbarV, float *hbarE, hipStream_t st, Profiler *prof);
+int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
+                    const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
+                    float *dbias_part, hipStream_t st, Profiler *prof);
+int launch_attn_fwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
+                    float *alpha, float *s, hipStream_t st);
+int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
+                    const float *alpha, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL, float *dr,
+                    hipStream_t st);
+int launch_he_feat_fwd(const PackedView &pk, const MbView &mb, int D, const float *PQ, const float *bias,
+                       const float *C, float *FE, hipStream_t st);
+int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
+                       const float *dFE, float *dMhe, float *dC_head, hipStream_t st);
+int launch_road_gather(const PackedView &pk, const MbView &mb, int D, const float *HL, float *XR, hipStream_t st);
+int launch_road_scatter_add(const PackedView &pk, const MbView &mb, int D, const float *dXR, float *GL, hipStream_t st);
+// masked softmax over each row's candidate list: logp, entropy (+ probabilities kept for backward)
+int launch_pointer_fwd(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn, float *p_he,
+                       float *p_rn, float *logp, float *ent, float *lse, hipStream_t st);
+int launch_pointer_bwd(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn,
+                       const float *p_he, const float *p_rn, const float *ent, const float *lse, const float *dlogp,
+                       const float *dent, float *dz_he, float *dz_rn, hipStream_t st);
+
+// ---- dense.hip -------------------------------------------------------------------------
+// C[i*ldc + j] (=|+=) act( sum_k A[i*sa0 + k*sa1] * B[k*sb0 + j*sb1] + bias[j] ) * out_scale
+int launch_smm(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, const float *B, int64_t sb0,
+               int64_t sb1, const float *bias, float *C, int64_t ldc, int accumulate, int act_tanh, float out_scale,
+               hipStream_t st);
+// dst[j] += sum_i X[i*ld + j]   (row-major), deterministic
+int launch_colsum_rm(const float *X, int rows, int cols, int64_t ld, float *dst, hipStream_t st);
+// part[blk][col] = sum_{rows of blk} (w ? w[row] : 1) * X(pm)[row][col];  then dst[col] += sum_blk
+int colsum_pm_blocks(int64_t rows);
+int launch_colsum_pm(const float *X, int64_t rows, int cols, const float *w, float *part, float *dst, hipStream_t st);
+int launch_reduce_rows_add(const float *part, int nrows, int cols, float *dst, hipStream_t st);
+// z[row] = sum_col X(pm)[row][col] * w[col]
+int launch_rowdot_pm(const float *X, int64_t rows, int cols, const float *w, float *z, hipStream_t st);
+// dpre(pm)[row][col] = dz[row] * w[col] * (1 - X[row][col]^2)
+int launch_rowdot_bwd_pm(const float *X, int64_t rows, int cols, const float *w, const float *dz, float *dpre,
+                         hipStream_t st);
+// dz[i] *= 1 - y[i]^2 (row-major, same shape)
+int launch_tanh_bwd(float *dz, const float *y, int64_t n, hipStream_t st);
+int launch_assemble_sv(const PackedView &pk, const MbView &mb, int D, int S_last, const float *Ulast,
+                       const float *hbarV, const float *hbarE, const float *att, float *SV, hipStream_t st);
+int launch_prep_wcat(const float *W, int D, float *Wcat, float *WcatT, hipStream_t st);
+int launch_pad_cols(const float *W, int rows, int cols, int cols_pad, float *out, hipStream_t st);
+int launch_transpose(const float *W, int rows, int cols, float *out, hipStream_t st);
+int launch_axpy(float *dst, const float *src, int64_t n, float alpha, hipStream_t st);   // dst += alpha*src
+int launch_scale(float *dst, int64_t n, float alpha, hipStream_t st);                     // dst *= alpha
+int launch_ppo_loss(int B, const float *value, const float *logp, const float *ent, const float *adv,
+                    const float *ret, const float *old_logp, const float *exps, float clip_eps, float cv, float ce,
+                    float inv_rows, float inv_ind, float *dvalue, float *dlogp, float *dent, float *losses,
+                    hipStream_t st);
+int launch_gae(int64_t T, const float *rewards, const float *masks, const float *values, double gamma, double tau,
+               float *adv, float *ret, hipStream_t st);
+int launch_adam(int64_t n, float *p, const float *g, float *m, float *v, int step, double lr, double b1, double b2,
+                double eps, double wd, hipStream_t st);
+int launch_sumsq(const float *x, int64_t n, float *scratch, float *out_accum, hipStream_t st);
+int launch_clip_scale(float *g, int64_t n, const float *sumsq, float max_norm, hipStream_t st);
+
+}  // namespace upamd

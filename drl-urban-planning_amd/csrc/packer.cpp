@@ -1,0 +1,267 @@
+// Host replay packer: padded 9-field states -> ragged/CSR batch (see include/upamd.h).
+//
+// Replaces the reference's per-minibatch tensorfy/batch_data
+// (urban_planning/agents/urban_planning_agent.py:16-20, urban_planning/models/state_encoder.py:163-177).
+// Graph semantics follow the reference exactly:
+//   * live edges  = slots with edge_mask; each live edge (i,j) contributes its message to node i
+//     AND node j, so it appears once in each endpoint's incidence list (a self-loop twice in one
+//     list: state_encoder.py:145-147 counts both roles);
+//   * nodes [0,n) are kept un-compacted, n = 1 + max(last node_mask slot, any live endpoint, last
+//     road candidate) so padded-slot indices stay valid node ids; node_mask is carried per node
+//     (mean + attention use it, state_encoder.py:155-159,179-182,200);
+//   * pointer-head candidates = land_use_mask slots (stage 0) / road_mask slots (stage 1) in
+//     padded-slot order (urban_planning/models/policy.py:48-61); everything else has probability
+//     exactly 0 in the reference's masked softmax and is never materialised.
+#include "upamd_internal.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct StateView {
+    const float *numerical;
+    const float *feat;
+    const int64_t *edge_index;
+    const float *cur;
+    const uint8_t *node_mask, *edge_mask, *land_mask, *road_mask;
+    const float *stage;
+};
+
+inline StateView view(const uint64_t *ptrs, int64_t T, int64_t t) {
+    StateView s;
+    s.numerical = reinterpret_cast<const float *>(ptrs[0 * T + t]);
+    s.feat = reinterpret_cast<const float *>(ptrs[1 * T + t]);
+    s.edge_index = reinterpret_cast<const int64_t *>(ptrs[2 * T + t]);
+    s.cur = reinterpret_cast<const float *>(ptrs[3 * T + t]);
+    s.node_mask = reinterpret_cast<const uint8_t *>(ptrs[4 * T + t]);
+    s.edge_mask = reinterpret_cast<const uint8_t *>(ptrs[5 * T + t]);
+    s.land_mask = reinterpret_cast<const uint8_t *>(ptrs[6 * T + t]);
+    s.road_mask = reinterpret_cast<const uint8_t *>(ptrs[7 * T + t]);
+    s.stage = reinterpret_cast<const float *>(ptrs[8 * T + t]);
+    return s;
+}
+
+inline int argmax3(const float *s) {
+    int best = 0;
+    if (s[1] > s[best]) best = 1;
+    if (s[2] > s[best]) best = 2;
+    return best;
+}
+
+template <typename F>
+int parallel_for(int64_t T, int n_threads, F &&fn) {
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, T / 64));
+    std::atomic<int> status{0};
+    if (n_threads <= 1) {
+        for (int64_t t = 0; t < T; ++t) {
+            int rc = fn(t);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> pool;
+    for (int w = 0; w < n_threads; ++w) {
+        pool.emplace_back([&]() {
+            for (;;) {
+                int64_t t0 = next.fetch_add(64);
+                if (t0 >= T || status.load() != 0) return;
+                int64_t t1 = std::min(T, t0 + 64);
+                for (int64_t t = t0; t < t1; ++t) {
+                    int rc = fn(t);
+                    if (rc != 0) {
+                        status.store(rc);
+                        return;
+                    }
+                }
+            }
+        });
+    }
+    for (auto &th : pool) th.join();
+    return status.load();
+}
+
+inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
+
+}  // namespace
+
+extern "C" int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const int32_t *pad_e,
+                               const float *actions, int32_t node_dim, int32_t numerical_dim, int32_t n_threads,
+                               int32_t *meta, upamd_pack_layout *layout) {
+    if (T <= 0 || !ptrs || !pad_n || !pad_e || !actions || !meta || !layout)
+        return upamd::fail(UPAMD_E_INVALID, "upamd_pack_plan: null argument or T <= 0");
+    if (node_dim <= 0 || node_dim > UPAMD_NODE_PAD)
+        return upamd::fail(UPAMD_E_INVALID, "upamd_pack_plan: node_dim must be in [1, 24]");
+    int rc = parallel_for(T, n_threads, [&](int64_t t) -> int {
+        StateView s = view(ptrs, T, t);
+        const int N = pad_n[t], E = pad_e[t];
+        int32_t *m = meta + t * UPAMD_META_STRIDE;
+        std::memset(m, 0, sizeof(int32_t) * UPAMD_META_STRIDE);
+        const int stage = argmax3(s.stage);
+        int n = 1, n_mask = 0;
+        for (int v = 0; v < N; ++v)
+            if (s.node_mask[v]) {
+                n = std::max(n, v + 1);
+                ++n_mask;
+            }
+        int e = 0, nh = 0, nr = 0;
+        for (int k = 0; k < E; ++k) {
+            if (s.edge_mask[k]) {
+                const int64_t i = s.edge_index[2 * k], j = s.edge_index[2 * k + 1];
+                if (i < 0 || j < 0 || i >= N || j >= N) return -1000;
+                n = std::max(n, (int)std::max(i, j) + 1);
+                ++e;
+            }
+            if (stage == 0 && s.land_mask[k]) ++nh;
+        }
+        if (stage == 1)
+            for (int v = 0; v < N; ++v)
+                if (s.road_mask[v]) {
+                    n = std::max(n, v + 1);
+                    ++nr;
+                }
+        if (n > 65535 || nh >= 65535) return -1001;
+        int act = -1;
+        if (stage == 0) {
+            const int a = (int)actions[2 * t];
+            if (a >= 0 && a < E && s.land_mask[a]) {
+                act = 0;
+                for (int k = 0; k < a; ++k) act += s.land_mask[k] ? 1 : 0;
+            }
+        } else if (stage == 1) {
+            const int a = (int)actions[2 * t + 1];
+            if (a >= 0 && a < N && s.road_mask[a]) {
+                act = 0;
+                for (int v = 0; v < a; ++v) act += s.road_mask[v] ? 1 : 0;
+            }
+        }
+        m[0] = n; m[1] = e; m[2] = nh; m[3] = nr; m[4] = stage; m[5] = act; m[6] = n_mask; m[7] = N; m[8] = E;
+        return 0;
+    });
+    if (rc == -1000) return upamd::fail(UPAMD_E_INVALID, "upamd_pack_plan: live edge endpoint outside [0, pad_n)");
+    if (rc == -1001) return upamd::fail(UPAMD_E_LIMIT, "upamd_pack_plan: a graph exceeds the 16-bit local index range");
+    if (rc != 0) return upamd::fail(UPAMD_E_INVALID, "upamd_pack_plan: failed");
+    int64_t nodes = 0, edges = 0, he = 0, rn = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        int32_t *m = meta + t * UPAMD_META_STRIDE;
+        if (nodes + t > INT32_MAX - 70000 || 2 * edges > INT32_MAX - 200000 || he > INT32_MAX - 70000)
+            return upamd::fail(UPAMD_E_LIMIT, "upamd_pack_plan: replay too large for 32-bit offsets");
+        m[9] = (int32_t)nodes; m[10] = (int32_t)edges; m[11] = (int32_t)he; m[12] = (int32_t)rn;
+        m[13] = (int32_t)(nodes + t);
+        nodes += m[0]; edges += m[1]; he += m[2]; rn += m[3];
+    }
+    upamd_pack_layout L;
+    std::memset(&L, 0, sizeof(L));
+    L.T = T; L.total_nodes = nodes; L.total_edges = edges; L.total_he = he; L.total_rn = rn;
+    L.node_dim = node_dim; L.numerical_dim = numerical_dim;
+    int64_t off = 0;
+    auto place = [&](int64_t bytes) { int64_t o = off; off = align256(off + std::max<int64_t>(bytes, 4)); return o; };
+    L.off_meta = place(T * UPAMD_META_STRIDE * 4);
+    L.off_x = place(nodes * UPAMD_NODE_PAD * 4);
+    L.off_nmask = place(nodes);
+    L.off_rowptr = place((nodes + T) * 4);
+    L.off_inc_nbr = place(2 * edges * 2);
+    L.off_inc_he = place(2 * edges * 2);
+    L.off_he_src = place(he * 2);
+    L.off_he_dst = place(he * 2);
+    L.off_he_live = place(he);
+    L.off_he_slot = place(he * 4);
+    L.off_rn_node = place(rn * 2);
+    L.off_numerical = place(T * (int64_t)numerical_dim * 4);
+    L.off_cur = place(T * UPAMD_NODE_PAD * 4);
+    L.total_bytes = off;
+    *layout = L;
+    return UPAMD_OK;
+}
+
+extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *meta, const upamd_pack_layout *layout,
+                               int32_t n_threads, void *out) {
+    if (T <= 0 || !ptrs || !meta || !layout || !out || layout->T != T)
+        return upamd::fail(UPAMD_E_INVALID, "upamd_pack_fill: bad argument");
+    const upamd_pack_layout &L = *layout;
+    char *base = static_cast<char *>(out);
+    std::memcpy(base + L.off_meta, meta, sizeof(int32_t) * UPAMD_META_STRIDE * T);
+    float *X = reinterpret_cast<float *>(base + L.off_x);
+    uint8_t *nmask = reinterpret_cast<uint8_t *>(base + L.off_nmask);
+    int32_t *rowptr = reinterpret_cast<int32_t *>(base + L.off_rowptr);
+    uint16_t *inc_nbr = reinterpret_cast<uint16_t *>(base + L.off_inc_nbr);
+    uint16_t *inc_he = reinterpret_cast<uint16_t *>(base + L.off_inc_he);
+    uint16_t *he_src = reinterpret_cast<uint16_t *>(base + L.off_he_src);
+    uint16_t *he_dst = reinterpret_cast<uint16_t *>(base + L.off_he_dst);
+    uint8_t *he_live = reinterpret_cast<uint8_t *>(base + L.off_he_live);
+    int32_t *he_slot = reinterpret_cast<int32_t *>(base + L.off_he_slot);
+    uint16_t *rn_node = reinterpret_cast<uint16_t *>(base + L.off_rn_node);
+    float *numerical = reinterpret_cast<float *>(base + L.off_numerical);
+    float *cur = reinterpret_cast<float *>(base + L.off_cur);
+    const int F = L.node_dim, Fn = L.numerical_dim;
+
+    int rc = parallel_for(T, n_threads, [&](int64_t t) -> int {
+        StateView s = view(ptrs, T, t);
+        const int32_t *m = meta + t * UPAMD_META_STRIDE;
+        const int n = m[0], e = m[1], nh = m[2], nr = m[3], stage = m[4], N = m[7], E = m[8];
+        const int64_t o_node = m[9], o_edge = m[10], o_he = m[11], o_rn = m[12], o_rp = m[13];
+        // node features + mask
+        for (int v = 0; v < n; ++v) {
+            float *dst = X + (o_node + v) * UPAMD_NODE_PAD;
+            std::memcpy(dst, s.feat + (int64_t)v * F, sizeof(float) * F);
+            for (int c = F; c < UPAMD_NODE_PAD; ++c) dst[c] = 0.f;
+            nmask[o_node + v] = s.node_mask[v] ? 1 : 0;
+        }
+        // candidates
+        std::vector<int32_t> he_of_slot;
+        if (stage == 0) {
+            he_of_slot.assign(E, -1);
+            int q = 0;
+            for (int k = 0; k < E; ++k)
+                if (s.land_mask[k]) {
+                    const bool live = s.edge_mask[k] != 0;
+                    he_of_slot[k] = q;
+                    he_src[o_he + q] = live ? (uint16_t)s.edge_index[2 * k] : 0;
+                    he_dst[o_he + q] = live ? (uint16_t)s.edge_index[2 * k + 1] : 0;
+                    he_live[o_he + q] = live ? 1 : 0;
+                    he_slot[o_he + q] = k;
+                    ++q;
+                }
+            if (q != nh) return -1;
+        }
+        if (stage == 1) {
+            int q = 0;
+            for (int v = 0; v < N; ++v)
+                if (s.road_mask[v]) rn_node[o_rn + q++] = (uint16_t)v;
+            if (q != nr) return -1;
+        }
+        // incidence CSR (counting sort by endpoint, slot order preserved)
+        int32_t *rp = rowptr + o_rp;
+        for (int v = 0; v <= n; ++v) rp[v] = 0;
+        for (int k = 0; k < E; ++k)
+            if (s.edge_mask[k]) {
+                rp[s.edge_index[2 * k] + 1]++;
+                rp[s.edge_index[2 * k + 1] + 1]++;
+            }
+        for (int v = 0; v < n; ++v) rp[v + 1] += rp[v];
+        if (rp[n] != 2 * e) return -1;
+        std::vector<int32_t> fill(rp, rp + n);
+        uint16_t *nb = inc_nbr + 2 * o_edge;
+        uint16_t *ih = inc_he + 2 * o_edge;
+        for (int k = 0; k < E; ++k)
+            if (s.edge_mask[k]) {
+                const int i = (int)s.edge_index[2 * k], j = (int)s.edge_index[2 * k + 1];
+                const uint16_t h = (stage == 0 && he_of_slot[k] >= 0) ? (uint16_t)he_of_slot[k] : (uint16_t)0xFFFF;
+                nb[fill[i]] = (uint16_t)j; ih[fill[i]] = h; fill[i]++;
+                nb[fill[j]] = (uint16_t)i; ih[fill[j]] = h; fill[j]++;
+            }
+        // per-state dense fields
+        std::memcpy(numerical + t * Fn, s.numerical, sizeof(float) * Fn);
+        float *cdst = cur + t * UPAMD_NODE_PAD;
+        std::memcpy(cdst, s.cur, sizeof(float) * F);
+        for (int c = F; c < UPAMD_NODE_PAD; ++c) cdst[c] = 0.f;
+        return 0;
+    });
+    if (rc != 0) return upamd::fail(UPAMD_E_INVALID, "upamd_pack_fill: meta table inconsistent with the states");
+    return UPAMD_OK;
+}

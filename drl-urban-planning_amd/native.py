@@ -1,0 +1,159 @@
+"""ctypes binding of the C-ABI library ``csrc/libupamd.so`` (declared in ``include/upamd.h``).
+
+The library is the product: there is NO Python/PyTorch fallback for the hot path.  ``lib()``
+raises ``RuntimeError`` when the shared object is missing or does not export the ABI the header
+declares; ``build()`` compiles it in-tree with hipcc for gfx950.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libupamd.so')
+ABI_VERSION = 1
+MAX_MLP = 4
+META_STRIDE = 16
+NODE_PAD = 24
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [('node_dim', C.c_int32), ('numerical_dim', C.c_int32), ('D', C.c_int32), ('L', C.c_int32),
+                ('heads', C.c_int32),
+                ('n_num', C.c_int32), ('num_hidden', C.c_int32 * MAX_MLP),
+                ('n_land', C.c_int32), ('land_hidden', C.c_int32 * MAX_MLP),
+                ('n_road', C.c_int32), ('road_hidden', C.c_int32 * MAX_MLP),
+                ('n_value', C.c_int32), ('value_hidden', C.c_int32 * MAX_MLP)]
+
+
+class PackLayout(C.Structure):
+    _fields_ = [('T', C.c_int64), ('total_nodes', C.c_int64), ('total_edges', C.c_int64), ('total_he', C.c_int64),
+                ('total_rn', C.c_int64), ('node_dim', C.c_int32), ('numerical_dim', C.c_int32),
+                ('off_meta', C.c_int64), ('off_x', C.c_int64), ('off_nmask', C.c_int64), ('off_rowptr', C.c_int64),
+                ('off_inc_nbr', C.c_int64), ('off_inc_he', C.c_int64), ('off_he_src', C.c_int64),
+                ('off_he_dst', C.c_int64), ('off_he_live', C.c_int64), ('off_he_slot', C.c_int64),
+                ('off_rn_node', C.c_int64), ('off_numerical', C.c_int64), ('off_cur', C.c_int64),
+                ('total_bytes', C.c_int64)]
+
+
+class Minibatch(C.Structure):
+    _fields_ = [('B', C.c_int32), ('n_nodes', C.c_int64), ('n_he', C.c_int64), ('n_rn', C.c_int64),
+                ('max_n', C.c_int32), ('max_inc', C.c_int32), ('idx_dev', C.c_void_p), ('node_off_dev', C.c_void_p),
+                ('he_off_dev', C.c_void_p), ('rn_off_dev', C.c_void_p)]
+
+
+# every symbol include/upamd.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    'upamd_abi_version': (C.c_int, []),
+    'upamd_last_error': (C.c_char_p, []),
+    'upamd_param_count': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    'upamd_param_info': (C.c_int, [C.POINTER(ModelDesc), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'upamd_param_groups': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'upamd_pack_plan': (C.c_int, [C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(PackLayout)]),
+    'upamd_pack_fill': (C.c_int, [C.c_int64, _P, _P, C.POINTER(PackLayout), C.c_int32, _P]),
+    'upamd_engine_create': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_P)]),
+    'upamd_engine_destroy': (None, [_P]),
+    'upamd_workspace_bytes': (C.c_int, [_P, C.POINTER(Minibatch), C.c_int32, C.POINTER(C.c_int64)]),
+    'upamd_forward': (C.c_int, [_P, _P, C.POINTER(PackLayout), C.POINTER(Minibatch), _P, _P, C.c_int64, _P, _P, _P,
+                                C.c_int32, _P]),
+    'upamd_backward': (C.c_int, [_P, _P, C.POINTER(PackLayout), C.POINTER(Minibatch), _P, _P, C.c_int64, _P, _P, _P,
+                                 _P, _P]),
+    'upamd_ws_tensor': (C.c_int, [_P, C.POINTER(Minibatch), C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    'upamd_ppo_loss': (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, _P, _P, _P, _P, _P]),
+    'upamd_gae': (C.c_int, [C.c_int64, _P, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
+    'upamd_clip_first_step': (C.c_int, [C.POINTER(ModelDesc), _P, C.c_float, _P, _P]),
+    'upamd_adam_step': (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, _P]),
+    'upamd_profile_enable': (C.c_int, [_P, C.c_int32]),
+    'upamd_profile_read': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'upamd_profile_reset': (C.c_int, [_P]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC, '-j', str(os.cpu_count() or 4)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError('building libupamd.so failed:\n' + res.stdout[-4000:] + res.stderr[-8000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises loudly if it is missing or stale (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('native library %s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(or `make -C %s`). The HIP path has no Python fallback.' % (LIB_PATH, CSRC))
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise RuntimeError('%s does not export %s (stale build?)' % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if handle.upamd_abi_version() != ABI_VERSION:
+        raise RuntimeError('libupamd.so ABI version %d != binding version %d' % (handle.upamd_abi_version(), ABI_VERSION))
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().upamd_last_error()
+        raise RuntimeError('%s failed (%d): %s' % (what or 'native call', rc, msg.decode() if msg else ''))
+
+
+def make_desc(state_encoder_specs, policy_specs, value_specs, node_dim, numerical_dim):
+    """Model description from the reference's three spec dicts (hlg.yaml:21-33)."""
+    if state_encoder_specs.get('num_edge_fc_layers', 1) != 1:
+        raise NotImplementedError('num_edge_fc_layers > 1 is not supported by the HIP path '
+                                  '(every shipped config uses 1)')
+    d = ModelDesc()
+    d.node_dim, d.numerical_dim = int(node_dim), int(numerical_dim)
+    d.D = int(state_encoder_specs['gcn_node_dim'])
+    d.L = int(state_encoder_specs['num_gcn_layers'])
+    d.heads = int(state_encoder_specs['num_attention_heads'])
+
+    def fill(n_field, arr_field, values):
+        values = [int(v) for v in values]
+        if len(values) > MAX_MLP:
+            raise NotImplementedError('MLPs deeper than %d layers are not supported' % MAX_MLP)
+        setattr(d, n_field, len(values))
+        arr = getattr(d, arr_field)
+        for i, v in enumerate(values):
+            arr[i] = v
+    fill('n_num', 'num_hidden', state_encoder_specs['state_encoder_hidden_size'])
+    fill('n_land', 'land_hidden', policy_specs['policy_land_use_head_hidden_size'])
+    fill('n_road', 'road_hidden', policy_specs['policy_road_head_hidden_size'])
+    fill('n_value', 'value_hidden', value_specs['value_head_hidden_size'])
+    return d
+
+
+def param_table(desc):
+    """[(name, offset, rows, cols, group)], n_floats, group ranges."""
+    L = lib()
+    n_floats, n_tensors = C.c_int64(), C.c_int32()
+    check(L.upamd_param_count(C.byref(desc), C.byref(n_floats), C.byref(n_tensors)), 'upamd_param_count')
+    out = []
+    name = C.create_string_buffer(160)
+    off, rows, cols, grp = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+    for i in range(n_tensors.value):
+        check(L.upamd_param_info(C.byref(desc), i, name, 160, C.byref(off), C.byref(rows), C.byref(cols), C.byref(grp)),
+              'upamd_param_info')
+        out.append((name.value.decode(), off.value, rows.value, cols.value, grp.value))
+    gb, ge = (C.c_int64 * 3)(), (C.c_int64 * 3)()
+    check(L.upamd_param_groups(C.byref(desc), gb, ge), 'upamd_param_groups')
+    return out, n_floats.value, [(gb[i], ge[i]) for i in range(3)]

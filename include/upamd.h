@@ -1,0 +1,212 @@
+/*
+ * upamd.h -- C ABI of the MI355X-native SGNN policy/value + PPO-update hot path.
+ *
+ * The reference (tsinghua-fib-lab/DRL-urban-planning) is pure Python/PyTorch and has no FFI
+ * or plugin layer for this path: the drop-in boundary is its Python class
+ * surface.  This header is the boundary BEHIND that surface -- what a binding for the path
+ * (ctypes here) talks to.  Every entry point cites the reference code whose
+ * work it replaces (paths relative to the reference repo root).
+ *
+ * Conventions: plain C types, pointers and sizes only.  `*_dev` pointers are device (HBM)
+ * addresses, everything else is host memory.  `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  Every function returns 0 on success and a negative UPAMD_E_*
+ * code on failure; upamd_last_error() then returns a thread-local message.  Nothing aborts.
+ * All floating point is fp32 (the reference trains in float32: urban_planning/train.py:47-48).
+ */
+#ifndef UPAMD_H
+#define UPAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UPAMD_ABI_VERSION 1
+
+#define UPAMD_OK 0
+#define UPAMD_E_INVALID (-1)   /* bad argument / unsupported configuration            */
+#define UPAMD_E_HIP (-2)       /* a HIP runtime call failed                            */
+#define UPAMD_E_LIMIT (-3)     /* a size limit of the packed format was exceeded       */
+#define UPAMD_E_WORKSPACE (-4) /* caller's workspace is too small                      */
+
+#define UPAMD_MAX_MLP 4        /* max depth of each small MLP (hidden-size lists)      */
+#define UPAMD_META_STRIDE 16   /* int32 words per state in the meta table              */
+#define UPAMD_NODE_PAD 24      /* packed node-feature row width (node_dim <= 24)       */
+
+int upamd_abi_version(void);
+const char *upamd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Model description == the reference's YAML specs (urban_planning/cfg/exp_cfg/real/hlg.yaml:21-33)
+ * read by create_sgnn_model (urban_planning/models/model.py:8-19).
+ * Constraints of this build: D % 16 == 0, D % heads == 0, num_edge_fc_layers == 1 (all shipped
+ * configs), node_dim <= 24, policy-head hidden sizes are multiples of 16 and end in 1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct upamd_model_desc {
+    int32_t node_dim;                        /* agent.node_dim (23)                               */
+    int32_t numerical_dim;                   /* agent.numerical_feature_size (52)                 */
+    int32_t D;                               /* gcn_node_dim                                      */
+    int32_t L;                               /* num_gcn_layers                                    */
+    int32_t heads;                           /* num_attention_heads                               */
+    int32_t n_num;                           /* len(state_encoder_hidden_size)                    */
+    int32_t num_hidden[UPAMD_MAX_MLP];
+    int32_t n_land;                          /* len(policy_land_use_head_hidden_size), last == 1  */
+    int32_t land_hidden[UPAMD_MAX_MLP];
+    int32_t n_road;                          /* len(policy_road_head_hidden_size), last == 1      */
+    int32_t road_hidden[UPAMD_MAX_MLP];
+    int32_t n_value;                         /* len(value_head_hidden_size), last == 1            */
+    int32_t value_hidden[UPAMD_MAX_MLP];
+} upamd_model_desc;
+
+/* Flat fp32 parameter buffer layout.  Tensor names are the reference's de-duplicated
+ * state_dict keys ("shared_net.node_encoder.weight", "policy_land_use_head.land_use_linear_0.weight",
+ * "value_head.linear_0.weight", ...; urban_planning/models/{state_encoder,policy,value}.py).
+ * group: 0 = shared encoder + value head, 1 = land-use head, 2 = road head (the three sets
+ * torch.optim.Adam treats independently because a head that was not evaluated has grad None,
+ * urban_planning/models/policy.py:48,57).  Offsets are in floats and 4-float aligned;
+ * n_floats includes the alignment padding. */
+int upamd_param_count(const upamd_model_desc *desc, int64_t *n_floats, int32_t *n_tensors);
+int upamd_param_info(const upamd_model_desc *desc, int32_t index, char *name_out, int32_t name_cap,
+                     int64_t *offset, int32_t *rows, int32_t *cols, int32_t *group);
+/* float ranges [begin,end) of the three optimizer groups inside the flat buffer */
+int upamd_param_groups(const upamd_model_desc *desc, int64_t begin_out[3], int64_t end_out[3]);
+
+/* ------------------------------------------------------------------------------------------
+ * Replay packer (host).  Replaces the per-minibatch `tensorfy` + `batch_data` of the reference
+ * (urban_planning/agents/urban_planning_agent.py:16-20, urban_planning/models/state_encoder.py:163-177):
+ * the T padded 9-field states of one PPO iteration (wire format:
+ * urban_planning/envs/observation_extractor.py:207-228) are converted ONCE into a ragged/CSR
+ * batch that goes to HBM in a single copy.
+ *
+ * ptrs: [9][T] host addresses of the 9 fields of every state, field-major:
+ *   0 numerical f32[numerical_dim]   1 node_features f32[pad_n][node_dim]  2 edge_index i64[pad_e][2]
+ *   3 current_node f32[node_dim]     4 node_mask u8[pad_n]                 5 edge_mask u8[pad_e]
+ *   6 land_use_mask u8[pad_e]        7 road_mask u8[pad_n]                 8 stage f32[3]
+ * actions: f32[T][2] (indices into the PADDED edge / node order, urban_planning/models/policy.py:93,99).
+ * meta (out, int32[T][UPAMD_META_STRIDE]):
+ *   0 n  1 e  2 n_head_edges  3 n_road_nodes  4 stage  5 action (candidate index or -1)
+ *   6 n_node_mask  7 pad_n  8 pad_e  9 node_off  10 edge_off  11 he_off  12 rn_off  13 rowptr_off
+ * ------------------------------------------------------------------------------------------ */
+typedef struct upamd_pack_layout {
+    int64_t T;
+    int64_t total_nodes, total_edges, total_he, total_rn;
+    int32_t node_dim, numerical_dim;
+    /* byte offsets of the sections inside the packed buffer (each 256-byte aligned) */
+    int64_t off_meta;      /* int32 [T][UPAMD_META_STRIDE]                                      */
+    int64_t off_x;         /* f32   [total_nodes][UPAMD_NODE_PAD]                                */
+    int64_t off_nmask;     /* u8    [total_nodes]                                                */
+    int64_t off_rowptr;    /* int32 [total_nodes + T]   per graph n+1 local incidence offsets    */
+    int64_t off_inc_nbr;   /* u16   [2*total_edges]     neighbour (local node id) per incidence  */
+    int64_t off_inc_he;    /* u16   [2*total_edges]     local head-edge index or 0xFFFF          */
+    int64_t off_he_src;    /* u16   [total_he]                                                   */
+    int64_t off_he_dst;    /* u16   [total_he]                                                   */
+    int64_t off_he_live;   /* u8    [total_he]          0 if the candidate edge is not a live edge */
+    int64_t off_he_slot;   /* int32 [total_he]          padded edge slot of the candidate        */
+    int64_t off_rn_node;   /* u16   [total_rn]          candidate node (== padded slot)          */
+    int64_t off_numerical; /* f32   [T][numerical_dim]                                           */
+    int64_t off_cur;       /* f32   [T][UPAMD_NODE_PAD]                                          */
+    int64_t total_bytes;
+} upamd_pack_layout;
+
+int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const int32_t *pad_e,
+                    const float *actions, int32_t node_dim, int32_t numerical_dim, int32_t n_threads,
+                    int32_t *meta, upamd_pack_layout *layout);
+int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *meta, const upamd_pack_layout *layout,
+                    int32_t n_threads, void *out);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine: forward / backward of the whole policy+value network over one minibatch of graphs.
+ * Replaces SGNNStateEncoder.forward (urban_planning/models/state_encoder.py:184-214),
+ * UrbanPlanningPolicy.get_log_prob_entropy (urban_planning/models/policy.py:87-104),
+ * UrbanPlanningValue.forward (urban_planning/models/value.py:36-39) and their autograd backward.
+ * The shared encoder is evaluated ONCE per call (the reference evaluates it twice per optimizer
+ * step, urban_planning_agent.py:330-332; the gradients are identical).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct upamd_engine upamd_engine;
+
+typedef struct upamd_minibatch {
+    int32_t B;                /* rows (graphs) in this minibatch (this rank's share)               */
+    int64_t n_nodes;          /* sum of n over the rows                                            */
+    int64_t n_he;             /* sum of head-edge candidates                                       */
+    int64_t n_rn;             /* sum of road-node candidates                                       */
+    int32_t max_n;            /* max n over the rows                                               */
+    int32_t max_inc;          /* max 2*e over the rows                                             */
+    const int32_t *idx_dev;       /* [B]   state ids into the packed replay                        */
+    const int32_t *node_off_dev;  /* [B+1] prefix sums of n in minibatch order                     */
+    const int32_t *he_off_dev;    /* [B+1]                                                         */
+    const int32_t *rn_off_dev;    /* [B+1]                                                         */
+} upamd_minibatch;
+
+int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out);
+void upamd_engine_destroy(upamd_engine *eng);
+
+/* bytes of scratch HBM a minibatch of this shape needs (training=1 keeps activations) */
+int upamd_workspace_bytes(upamd_engine *eng, const upamd_minibatch *mb, int32_t training, int64_t *bytes);
+
+/* value_dev/logp_dev/ent_dev: f32[B].  keep != 0 leaves the activations in ws for upamd_backward. */
+int upamd_forward(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout,
+                  const upamd_minibatch *mb, const float *params_dev, void *ws_dev, int64_t ws_bytes,
+                  float *value_dev, float *logp_dev, float *ent_dev, int32_t keep, void *stream);
+
+/* seeds dvalue/dlogp/dent: f32[B] (dLoss/d output).  grads_dev: flat buffer (same layout as the
+ * parameters), ACCUMULATED into (zero it first).  Must follow upamd_forward(keep=1) on the same ws. */
+int upamd_backward(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout,
+                   const upamd_minibatch *mb, const float *params_dev, void *ws_dev, int64_t ws_bytes,
+                   const float *dvalue_dev, const float *dlogp_dev, const float *dent_dev,
+                   float *grads_dev, void *stream);
+
+/* byte offset / shape of a named intermediate inside ws after upamd_forward(keep=1) -- for the
+ * stage-by-stage parity tests.  kind: 0 = row-major [rows][cols], 1 = panel-major [cols/16][rows][16]. */
+int upamd_ws_tensor(upamd_engine *eng, const upamd_minibatch *mb, const char *name, int64_t *byte_offset,
+                    int64_t *rows, int64_t *cols, int32_t *kind);
+
+/* ------------------------------------------------------------------------------------------
+ * PPO minibatch math.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Clipped-surrogate + value + entropy loss and its per-row seeds.  Replaces
+ * ppo_entropy_loss (urban_planning/agents/urban_planning_agent.py:363-371), value_loss
+ * (khrylib/rl/agents/agent_pg.py:19-23) and the loss assembly (:333).
+ * inv_rows = 1/(global minibatch rows), inv_ind = 1/(global count of exps != 0): with one rank
+ * these are 1/B and 1/|ind|; with data parallelism every rank passes the GLOBAL counts and the
+ * partial losses/gradients are summed by the all-reduce.
+ * losses_dev: f32[4] = {loss, value_loss, surr_loss, entropy_loss} (this rank's partial sums). */
+int upamd_ppo_loss(int32_t B, const float *value_dev, const float *logp_dev, const float *ent_dev,
+                   const float *adv_dev, const float *ret_dev, const float *old_logp_dev,
+                   const float *exps_dev, float clip_epsilon, float value_pred_coef, float entropy_coef,
+                   float inv_rows, float inv_ind, float *dvalue_dev, float *dlogp_dev, float *dent_dev,
+                   float *losses_dev, void *stream);
+
+/* Generalised advantage estimation, bit-exact with the reference's Python loop
+ * (khrylib/rl/core/common.py:5-26): trajectories are concatenated, masks[t]==0 ends an episode. */
+int upamd_gae(int64_t T, const float *rewards_dev, const float *masks_dev, const float *values_dev,
+              double gamma, double tau, float *adv_dev, float *ret_dev, void *stream);
+
+/* The reference's gradient clipping as it actually executes (khrylib/rl/agents/agent_ppo.py:43-46 with
+ * the generator lists of urban_planning_agent.py:46): clip_grad_norm_(policy params, max_norm) then
+ * clip_grad_norm_(value params, max_norm), both effective on the first optimizer step of a process only.
+ * The caller invokes this exactly once (first step).  scratch_dev: >= 4096 floats. */
+int upamd_clip_first_step(const upamd_model_desc *desc, float *grads_dev, float max_norm,
+                          float *scratch_dev, void *stream);
+
+/* torch.optim.Adam (coupled L2 weight decay, urban_planning_agent.py:148-149) on the flat buffers,
+ * one call per optimizer group.  `step` is that group's 1-based step count. */
+int upamd_adam_step(int64_t begin, int64_t end, float *params_dev, const float *grads_dev, float *m_dev,
+                    float *v_dev, int32_t step, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing of the dominant kernels (HIP events on the launch stream), for bench.py.
+ * ------------------------------------------------------------------------------------------ */
+int upamd_profile_enable(upamd_engine *eng, int32_t on);
+/* name: "gemm_nt" | "gemm_tn" | "edge_fwd" | "edge_bwd".  Synchronises the recorded events. */
+int upamd_profile_read(upamd_engine *eng, const char *name, int64_t *launches, double *total_ms,
+                       double *total_flops, double *total_bytes);
+int upamd_profile_reset(upamd_engine *eng);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPAMD_H */

@@ -1,0 +1,84 @@
+"""Host packer (csrc/packer.cpp) against the python packer spec (tests/csr_model.pack_state). CPU only."""
+import numpy as np
+import pytest
+
+import cases
+import csr_model
+from drl_urban_planning_amd import native, packer, synth
+
+
+def _check(replay):
+    T = len(replay.states)
+    pk = packer.pack_replay(replay.states, replay.actions, synth.NODE_DIM, synth.NUMERICAL_DIM, n_threads=2, pin=False)
+    L = pk.layout
+    meta = pk.meta
+    X = pk.section('x', np.float32, L.total_nodes * native.NODE_PAD).reshape(-1, native.NODE_PAD)
+    nmask = pk.section('nmask', np.uint8, L.total_nodes)
+    rowptr = pk.section('rowptr', np.int32, L.total_nodes + T)
+    inc_nbr = pk.section('inc_nbr', np.uint16, 2 * L.total_edges)
+    inc_he = pk.section('inc_he', np.uint16, 2 * L.total_edges)
+    he_src = pk.section('he_src', np.uint16, L.total_he)
+    he_dst = pk.section('he_dst', np.uint16, L.total_he)
+    he_live = pk.section('he_live', np.uint8, L.total_he)
+    he_slot = pk.section('he_slot', np.int32, L.total_he)
+    rn_node = pk.section('rn_node', np.uint16, L.total_rn)
+    numerical = pk.section('numerical', np.float32, T * synth.NUMERICAL_DIM).reshape(T, -1)
+    cur = pk.section('cur', np.float32, T * native.NODE_PAD).reshape(T, -1)
+    meta_dev = pk.section('meta', np.int32, T * native.META_STRIDE).reshape(T, -1)
+    assert np.array_equal(meta_dev, meta)
+    for t in range(T):
+        g = csr_model.pack_state(replay.states[t], replay.actions[t])
+        m = meta[t]
+        assert (m[0], m[1], m[4], m[5], m[6]) == (g['n'], g['e'], g['stage'], g['act'], g['n_mask']), t
+        assert m[2] == g['he_src'].size and m[3] == g['rn_node'].size
+        assert m[7] == g['pad_n'] and m[8] == g['pad_e']
+        n, e = g['n'], g['e']
+        no, eo, ho, ro, rp = m[9], m[10], m[11], m[12], m[13]
+        np.testing.assert_array_equal(X[no:no + n, :synth.NODE_DIM], g['X'].astype(np.float32))
+        assert not X[no:no + n, synth.NODE_DIM:].any()
+        np.testing.assert_array_equal(nmask[no:no + n].astype(bool), g['nmask'])
+        np.testing.assert_array_equal(rowptr[rp:rp + n + 1], g['row_ptr'])
+        np.testing.assert_array_equal(inc_nbr[2 * eo:2 * eo + 2 * e], g['inc_nbr'])
+        np.testing.assert_array_equal(inc_he[2 * eo:2 * eo + 2 * e].astype(np.int64),
+                                      np.where(g['inc_he'] < 0, 0xFFFF, g['inc_he']))
+        np.testing.assert_array_equal(he_src[ho:ho + m[2]], g['he_src'])
+        np.testing.assert_array_equal(he_dst[ho:ho + m[2]], g['he_dst'])
+        np.testing.assert_array_equal(he_live[ho:ho + m[2]], g['he_live'])
+        np.testing.assert_array_equal(he_slot[ho:ho + m[2]], g['he_slot'])
+        np.testing.assert_array_equal(rn_node[ro:ro + m[3]], g['rn_node'])
+        np.testing.assert_array_equal(numerical[t], replay.states[t][0])
+        np.testing.assert_array_equal(cur[t, :synth.NODE_DIM], replay.states[t][3])
+    return pk
+
+
+def test_packer_quirky_cases():
+    _check(cases.quirky_replay(24, 40, 96, seed=3))
+    _check(cases.quirky_replay(12, 30, 64, seed=9, road_fraction=1.0))
+
+
+def test_packer_hlg_shape_and_schedule():
+    replay = synth.make_replay(16, 'hlg', seed=4, road_fraction=0.3)
+    pk = _check(replay)
+    sched = packer.Schedule(pk, [np.arange(0, 8), np.array([15, 3, 9])], 'cpu')
+    mb, it = sched.minibatch(1)
+    assert mb.B == 3 and it['n_nodes'] == int(pk.meta[[15, 3, 9], 0].sum())
+    flat = sched.dev.numpy()
+    base = it['base']
+    np.testing.assert_array_equal(flat[base:base + 3], [15, 3, 9])
+    np.testing.assert_array_equal(flat[base + 3:base + 7], np.concatenate([[0], np.cumsum(pk.meta[[15, 3, 9], 0])]))
+
+
+def test_packer_rejects_bad_input():
+    replay = cases.quirky_replay(4, 20, 40, seed=1, full_row=False)
+    replay.states[1][2][0, 0] = 25          # live edge endpoint outside [0, pad_n)
+    with pytest.raises(RuntimeError, match='endpoint'):
+        packer.pack_replay(replay.states, replay.actions, synth.NODE_DIM, synth.NUMERICAL_DIM, pin=False)
+
+
+def test_action_outside_candidates_maps_to_minus_one():
+    replay = cases.quirky_replay(6, 20, 40, seed=2, road_fraction=0.0, full_row=False)
+    s = replay.states[4]
+    bad = int(np.flatnonzero(~s[6])[0])
+    replay.actions[4, 0] = bad
+    pk = packer.pack_replay(replay.states, replay.actions, synth.NODE_DIM, synth.NUMERICAL_DIM, pin=False)
+    assert pk.meta[4, 5] == -1
