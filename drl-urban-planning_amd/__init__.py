@@ -6,3 +6,21 @@ the C-ABI library ``csrc/libupamd.so``), ``packer`` (ragged/CSR replay packer), 
 (nn.Module surface), ``agent`` (PPO update surface), ``dist`` (data-parallel helpers).
 """
 __version__ = '0.1.0'
+
+
+_LAZY = {
+    'create_sgnn_model': ('models', 'create_sgnn_model'),
+    'ActorCritic': ('models', 'ActorCritic'),
+    'PPOUpdater': ('agent', 'PPOUpdater'),
+    'HipUpdateMixin': ('agent', 'HipUpdateMixin'),
+    'install': ('agent', 'install'),
+    'DistContext': ('dist', 'DistContext'),
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        mod, attr = _LAZY[name]
+        return getattr(importlib.import_module('drl_urban_planning_amd.' + mod), attr)
+    raise AttributeError(name)

@@ -1,0 +1,249 @@
+"""PPO update surface: ``update_params(batch, iteration) -> seconds`` with the semantics of
+``UrbanPlanningAgent.update_params`` / ``update_policy``
+(urban_planning/agents/urban_planning_agent.py:248-361) running on the HIP engine.
+
+What is reproduced exactly:
+  * value + old-log-prob pre-pass (one fused sweep instead of the reference's two), GAE without
+    normalisation (khrylib/rl/core/common.py:5-26);
+  * ``num_optim_epoch`` epochs, per epoch one ``np.random.shuffle`` on the numpy GLOBAL RNG whose
+    permutations compose across epochs (:306-312), optional regrouping by stage (:314-319),
+    ``floor(T / mini_batch_size)`` minibatches with the tail dropped (:321);
+  * value loss over all rows, surrogate + entropy over rows with ``exps != 0`` (:326-333, 363-371);
+  * gradient clipping that is effective on the first optimizer step of the process only, applied
+    to the policy set and then the value set (:46 + khrylib/rl/agents/agent_ppo.py:43-46);
+  * torch.optim.Adam semantics incl. coupled weight decay, and "a head that saw no rows has no
+    gradient, so Adam skips it" (torch >= 2.0 zero_grad(set_to_none=True));
+  * ``loss_iter`` + the per-minibatch / per-epoch / per-iteration TensorBoard scalars (:338-361).
+
+What differs by design: the shared encoder is evaluated once per step (same gradients); the
+replay is packed and uploaded once per iteration; the four loss scalars stay on the GPU until the
+iteration ends (no host sync inside the minibatch loop); optimizer state lives in flat device
+buffers owned by the updater (the reference never checkpoints optimizer state either).
+"""
+import math
+import time
+
+import numpy as np
+import torch
+
+from . import packer
+from .dist import DistContext, global_counts
+from .models import backend_of
+
+
+class PPOUpdater:
+    """Owns the flat parameter / Adam buffers of one (policy_net, value_net) pair on one GPU."""
+
+    def __init__(self, policy_net, value_net, lr=4e-4, eps=1e-5, weight_decay=0.0, betas=(0.9, 0.999), gamma=1.0,
+                 tau=0.0, clip_epsilon=0.2, value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4,
+                 mini_batch_size=256, batch_stage=False, max_grad_norm=1.0, dist_ctx=None, pack_threads=0):
+        self.policy_net, self.value_net = policy_net, value_net
+        self.backend = backend_of(policy_net)
+        self.lr, self.eps, self.weight_decay, self.betas = lr, eps, weight_decay, betas
+        self.gamma, self.tau = gamma, tau
+        self.clip_epsilon = clip_epsilon
+        self.value_pred_coef, self.entropy_coef = value_pred_coef, entropy_coef
+        self.num_optim_epoch, self.mini_batch_size = num_optim_epoch, mini_batch_size
+        self.batch_stage = batch_stage
+        self.max_grad_norm = max_grad_norm
+        self.dist = dist_ctx or DistContext()
+        self.pack_threads = pack_threads
+        self.loss_iter = 0
+        self.clip_pending = True              # the generator lists are live until the first call
+        self.group_steps = [0, 0, 0]          # Adam step counts: encoder+value / land head / road head
+        self.flat = self.m = self.v = self.grads = None
+        self.last_losses = None               # np [steps, 4] of the last update_params call
+        self.last_timing = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _device(self):
+        dev = next(self.policy_net.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('update_params runs on the HIP engine and needs the networks on a GPU device '
+                               '(they are on %s); there is no CPU fallback for the update path' % dev)
+        return dev
+
+    def _ensure_buffers(self, engine):
+        if self.flat is None or self.flat.device != engine.device or self.flat.numel() != engine.n_floats:
+            self.flat = engine.new_flat()
+            self.m = engine.new_flat()
+            self.v = engine.new_flat()
+            # gradient buffer carries 4 loss scalars at its tail so one all-reduce moves both
+            self.grads = torch.zeros(engine.n_floats + 4, dtype=torch.float32, device=engine.device)
+            self.scratch = torch.zeros(4096, dtype=torch.float32, device=engine.device)
+
+    @staticmethod
+    def _to_f32(x, device):
+        return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device)
+
+    # ------------------------------------------------------------------ pre-pass + GAE
+    def prepass(self, engine, packed, T, chunk):
+        """values[T], old_logp[T] with the current parameters, no grad (:256-264, :283-292)."""
+        dev = engine.device
+        values = torch.empty(T, device=dev)
+        logp = torch.empty(T, device=dev)
+        ent = torch.empty(T, device=dev)
+        row_lists = [np.arange(i, min(i + chunk, T)) for i in range(0, T, chunk)]
+        sched = packer.Schedule(packed, row_lists, dev)
+        for k, rows in enumerate(row_lists):
+            mb, _ = sched.minibatch(k)
+            lo, hi = int(rows[0]), int(rows[-1]) + 1
+            engine.forward(packed, mb, self.flat, values[lo:hi], logp[lo:hi], ent[lo:hi], keep=False)
+        return values, logp
+
+    # ------------------------------------------------------------------ the update
+    def update_params(self, batch, iteration=0, tb_logger=None, max_steps=None):
+        t0 = time.time()
+        dev = self._device()
+        engine = self.backend.engine(dev)
+        self._ensure_buffers(engine)
+        named = self.backend.named_params()
+        engine.flatten(named, out=self.flat)
+        self.policy_net.train(True)
+        self.value_net.train(True)
+
+        states = batch.states
+        T = len(states)
+        B = self.mini_batch_size
+        world, rank = self.dist.world, self.dist.rank
+        agent = self.policy_net.agent
+        t_pack = time.time()
+        packed = packer.pack_replay(states, np.asarray(batch.actions), agent.node_dim, agent.numerical_feature_size,
+                                    n_threads=self.pack_threads).to(dev)
+        rewards = self._to_f32(batch.rewards, dev)
+        masks = self._to_f32(batch.masks, dev)
+        exps_np = np.asarray(batch.exps, dtype=np.float32)
+        exps = torch.from_numpy(exps_np).to(dev)
+        t_pre = time.time()
+        values, old_logp = self.prepass(engine, packed, T, B)
+        adv = torch.empty(T, device=dev)
+        ret = torch.empty(T, device=dev)
+        engine.gae(rewards, masks, values, self.gamma, self.tau, adv, ret)
+        t_loop = time.time()
+
+        stage_np = packed.meta[:, packer.M_STAGE]
+        order = np.arange(T)
+        nb = int(math.floor(T / B))
+        steps_total = self.num_optim_epoch * nb if max_steps is None else min(max_steps, self.num_optim_epoch * nb)
+        loss_log = torch.zeros(max(steps_total, 1), 4, device=dev)
+        value_b = torch.empty(B, device=dev)
+        logp_b = torch.empty(B, device=dev)
+        ent_b = torch.empty(B, device=dev)
+        dvalue, dlogp, dent = torch.empty(B, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
+        nflt = engine.n_floats
+        step = 0
+        epoch_ranges = []
+        for epoch in range(self.num_optim_epoch):
+            if step >= steps_total:
+                break
+            perm = np.arange(T)
+            np.random.shuffle(perm)                      # numpy global RNG, like the reference
+            order = order[perm]                          # permutations compose across epochs
+            if self.batch_stage:
+                st = stage_np[order]
+                order = np.concatenate([order[st == 0], order[st == 1]])
+            row_lists = [order[i * B:(i + 1) * B] for i in range(nb)]
+            sched = packer.Schedule(packed, row_lists, dev)
+            # per-minibatch global counts (rows, rows with exps != 0, land-use rows, road rows): known on the
+            # host, exchanged with ONE tiny all-reduce per epoch when data-parallel
+            counts = [[B] * nb, [int((exps_np[r] != 0).sum()) for r in row_lists],
+                      [int((stage_np[r] == 0).sum()) for r in row_lists],
+                      [int((stage_np[r] == 1).sum()) for r in row_lists]]
+            rows_glob, ind_glob, land_glob, road_glob = global_counts(self.dist, counts, dev)
+            order_dev = torch.from_numpy(np.ascontiguousarray(order[:nb * B])).to(dev)
+            first = step
+            for k in range(nb):
+                if step >= steps_total:
+                    break
+                mb, item = sched.minibatch(k)
+                idx = order_dev[k * B:(k + 1) * B]
+                inv_rows = 1.0 / rows_glob[k]
+                inv_ind = 1.0 / ind_glob[k] if ind_glob[k] > 0 else float('nan')
+                engine.forward(packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
+                engine.ppo_loss(B, value_b, logp_b, ent_b, adv[idx], ret[idx], old_logp[idx], exps[idx],
+                                self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
+                                dvalue, dlogp, dent, self.grads[nflt:])
+                self.grads[:nflt].zero_()
+                engine.backward(packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
+                land_rows, road_rows = land_glob[k], road_glob[k]
+                if world > 1:
+                    self.dist.all_reduce_sum(self.grads)      # one collective per optimizer step
+                loss_log[step].copy_(self.grads[nflt:])
+                if self.clip_pending:
+                    engine.clip_first_step(self.grads, self.max_grad_norm, self.scratch)
+                    self.clip_pending = False
+                active = (True, land_rows > 0, road_rows > 0)
+                for g in range(3):
+                    if active[g]:
+                        self.group_steps[g] += 1
+                        engine.adam_step(g, self.flat, self.grads, self.m, self.v, self.group_steps[g], self.lr,
+                                         self.betas[0], self.betas[1], self.eps, self.weight_decay)
+                step += 1
+            epoch_ranges.append((first, step))
+        losses = loss_log[:step].cpu().numpy() if step > 0 else np.zeros((0, 4), dtype=np.float32)
+        engine.unflatten(self.flat, named)
+        torch.cuda.synchronize(dev)
+        t_end = time.time()
+
+        # ---- logging exactly as the reference emits it (:338-361), after the fact
+        if tb_logger is not None:
+            tags = ('loss/loss', 'loss/value_loss', 'loss/surr_loss', 'loss/entropy_loss')
+            for i in range(step):
+                for j, tag in enumerate(tags):
+                    tb_logger.add_scalar(tag, float(losses[i, j]), self.loss_iter + i)
+            totals = np.zeros(4)
+            for e, (a, b) in enumerate(epoch_ranges):
+                ep = losses[a:b].astype(np.float64).sum(0) if b > a else np.zeros(4)
+                totals += ep
+                ge = iteration * self.num_optim_epoch + e
+                for j, tag in enumerate(('loss/epoch_loss', 'loss/epoch_value_loss', 'loss/epoch_surr_loss',
+                                         'loss/epoch_entropy_loss')):
+                    tb_logger.add_scalar(tag, float(ep[j]), ge)
+            for j, tag in enumerate(('loss/total_loss', 'loss/total_value_loss', 'loss/total_surr_loss',
+                                     'loss/total_entropy_loss')):
+                tb_logger.add_scalar(tag, float(totals[j] / self.num_optim_epoch), iteration)
+        self.loss_iter += step
+        self.last_losses = losses
+        self.last_timing = dict(pack=t_pre - t_pack, prepass_gae=t_loop - t_pre, loop=t_end - t_loop,
+                                total=t_end - t0, steps=step, rows_per_step=B * world)
+        return t_end - t0
+
+
+class HipUpdateMixin:
+    """Mix into the reference agent to route ``update_params`` through the HIP engine:
+
+        class Agent(HipUpdateMixin, UrbanPlanningAgent): pass
+
+    ``setup_model`` must create the networks with ``drl_urban_planning_amd.create_sgnn_model``
+    (see INTEGRATION.md).  Hyper-parameters are read from the attributes the reference's
+    ``AgentPPO.__init__`` sets and from ``self.optimizer.param_groups[0]``.
+    """
+
+    def _hip_updater(self):
+        up = getattr(self, '_upamd_updater', None)
+        if up is None:
+            pg = self.optimizer.param_groups[0]
+            up = PPOUpdater(self.policy_net, self.value_net, lr=pg['lr'], eps=pg['eps'],
+                            weight_decay=pg['weight_decay'], betas=tuple(pg['betas']), gamma=self.gamma, tau=self.tau,
+                            clip_epsilon=self.clip_epsilon, value_pred_coef=self.value_pred_coef,
+                            entropy_coef=self.entropy_coef, num_optim_epoch=self.opt_num_epochs,
+                            mini_batch_size=self.mini_batch_size,
+                            batch_stage=bool(self.cfg.agent_specs.get('batch_stage', False)))
+            up.loss_iter = self.loss_iter
+            self._upamd_updater = up
+        return up
+
+    def update_params(self, batch, iteration):
+        up = self._hip_updater()
+        up.loss_iter = self.loss_iter
+        elapsed = up.update_params(batch, iteration, tb_logger=getattr(self, 'tb_logger', None))
+        self.loss_iter = up.loss_iter
+        return elapsed
+
+
+def install(agent):
+    """Patch an existing reference agent INSTANCE (its networks must come from our create_sgnn_model)."""
+    import types
+    agent._hip_updater = types.MethodType(HipUpdateMixin._hip_updater, agent)
+    agent.update_params = types.MethodType(HipUpdateMixin.update_params, agent)
+    return agent

@@ -1,0 +1,139 @@
+"""Thin host wrapper around the native engine: owns the flat parameter / gradient / Adam buffers
+and the scratch workspace (torch tensors = device memory plumbing) and forwards every call to
+the C ABI with raw pointers.  No math happens here.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import native
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class NativeEngine:
+    """One engine per (model description, device)."""
+
+    def __init__(self, desc, device):
+        self.lib = native.lib()
+        self.desc = desc
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('the HIP engine needs a GPU device (got %s); there is no CPU fallback' % self.device)
+        h = C.c_void_p()
+        native.check(self.lib.upamd_engine_create(C.byref(desc), C.byref(h)), 'upamd_engine_create')
+        self.handle = h
+        self.table, self.n_floats, self.groups = native.param_table(desc)
+        self.index = {name: (off, rows, cols, grp) for name, off, rows, cols, grp in self.table}
+        self.ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.upamd_engine_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- flat parameter buffer <-> named tensors
+    def new_flat(self):
+        return torch.zeros(self.n_floats, dtype=torch.float32, device=self.device)
+
+    def flatten(self, named, out=None):
+        """named: dict name -> tensor (any device).  Returns the flat fp32 device buffer."""
+        flat = self.new_flat() if out is None else out
+        for name, off, rows, cols, _ in self.table:
+            flat[off:off + rows * cols].copy_(named[name].detach().reshape(-1), non_blocking=True)
+        return flat
+
+    def unflatten(self, flat, named):
+        """Copies the flat buffer back into the named tensors (in place, keeps their devices)."""
+        with torch.no_grad():
+            for name, off, rows, cols, _ in self.table:
+                dst = named[name]
+                dst.copy_(flat[off:off + rows * cols].view_as(dst))
+
+    def views(self, flat):
+        return {name: flat[off:off + rows * cols].view(rows, cols) if cols > 1 or name.endswith('weight')
+                else flat[off:off + rows] for name, off, rows, cols, _ in self.table}
+
+    # ---- workspace
+    def ensure_workspace(self, mb):
+        need = C.c_int64()
+        native.check(self.lib.upamd_workspace_bytes(self.handle, C.byref(mb), 1, C.byref(need)), 'upamd_workspace_bytes')
+        if self.ws is None or self.ws.numel() < need.value:
+            self.ws = None
+            self.ws = torch.empty(int(need.value * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+        return self.ws
+
+    def _ws_args(self):
+        base = self.ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        return C.c_void_p(aligned), C.c_int64(self.ws.numel() - (aligned - base)), aligned - base
+
+    # ---- forward / backward
+    def forward(self, packed, mb, flat_params, value, logp, ent, keep=True):
+        self.ensure_workspace(mb)
+        wsp, wsb, _ = self._ws_args()
+        native.check(self.lib.upamd_forward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
+                                            _ptr(flat_params), wsp, wsb, _ptr(value), _ptr(logp), _ptr(ent),
+                                            1 if keep else 0, _stream()), 'upamd_forward')
+
+    def backward(self, packed, mb, flat_params, dvalue, dlogp, dent, grads):
+        wsp, wsb, _ = self._ws_args()
+        native.check(self.lib.upamd_backward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
+                                             _ptr(flat_params), wsp, wsb, _ptr(dvalue), _ptr(dlogp), _ptr(dent),
+                                             _ptr(grads), _stream()), 'upamd_backward')
+
+    def ws_tensor(self, mb, name):
+        """Row-major copy of a named intermediate (parity tests)."""
+        off, rows, cols, kind = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        native.check(self.lib.upamd_ws_tensor(self.handle, C.byref(mb), name.encode(), C.byref(off), C.byref(rows),
+                                              C.byref(cols), C.byref(kind)), 'upamd_ws_tensor')
+        _, _, shift = self._ws_args()
+        n = rows.value * cols.value
+        raw = self.ws[shift + off.value: shift + off.value + 4 * n].view(torch.float32)
+        if kind.value == 1:
+            return raw.view(cols.value // 16, rows.value, 16).permute(1, 0, 2).reshape(rows.value, cols.value).clone()
+        return raw.view(rows.value, cols.value).clone()
+
+    # ---- PPO math
+    def ppo_loss(self, B, value, logp, ent, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind, dvalue,
+                 dlogp, dent, losses):
+        native.check(self.lib.upamd_ppo_loss(B, _ptr(value), _ptr(logp), _ptr(ent), _ptr(adv), _ptr(ret), _ptr(old_logp),
+                                             _ptr(exps), clip_eps, cv, ce, inv_rows, inv_ind, _ptr(dvalue), _ptr(dlogp),
+                                             _ptr(dent), _ptr(losses), _stream()), 'upamd_ppo_loss')
+
+    def gae(self, rewards, masks, values, gamma, tau, adv, ret):
+        native.check(self.lib.upamd_gae(rewards.numel(), _ptr(rewards), _ptr(masks), _ptr(values), float(gamma),
+                                        float(tau), _ptr(adv), _ptr(ret), _stream()), 'upamd_gae')
+
+    def clip_first_step(self, grads, max_norm, scratch):
+        native.check(self.lib.upamd_clip_first_step(C.byref(self.desc), _ptr(grads), float(max_norm), _ptr(scratch),
+                                                    _stream()), 'upamd_clip_first_step')
+
+    def adam_step(self, group, params, grads, m, v, step, lr, beta1, beta2, eps, weight_decay):
+        b, e = self.groups[group]
+        native.check(self.lib.upamd_adam_step(b, e, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), int(step), float(lr),
+                                              float(beta1), float(beta2), float(eps), float(weight_decay), _stream()),
+                     'upamd_adam_step')
+
+    # ---- profiling
+    def profile(self, on):
+        native.check(self.lib.upamd_profile_enable(self.handle, 1 if on else 0), 'upamd_profile_enable')
+
+    def profile_reset(self):
+        native.check(self.lib.upamd_profile_reset(self.handle), 'upamd_profile_reset')
+
+    def profile_read(self, name):
+        n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        native.check(self.lib.upamd_profile_read(self.handle, name.encode(), C.byref(n), C.byref(ms), C.byref(fl),
+                                                 C.byref(by)), 'upamd_profile_read')
+        return dict(launches=n.value, total_ms=ms.value, flops=fl.value, bytes=by.value)

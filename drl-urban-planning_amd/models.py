@@ -1,0 +1,364 @@
+"""Drop-in ``nn.Module`` surface of the reference's SGNN policy / value networks.
+
+``create_sgnn_model(cfg, agent) -> (policy_net, value_net)`` mirrors
+urban_planning/models/model.py:8-19; attribute names, construction order (hence seeded
+initialisation) and ``state_dict`` keys are those of urban_planning/models/state_encoder.py:13-33,
+policy.py:9-43 and value.py:8-34, so reference checkpoints load both ways
+(``ActorCritic(policy_net, value_net).load_state_dict``).
+
+Two execution paths, selected by where the parameters live:
+
+* **cuda** -- the hot path: states are packed to the ragged/CSR form and the whole network
+  (forward and hand-written backward) runs in the HIP library through ``NativeEngine``; autograd
+  sees one ``torch.autograd.Function``.  If the native library is missing this raises -- there is
+  no fallback.
+* **cpu** -- rollout workers (``Agent.sample`` moves the modules to the CPU and forks,
+  khrylib/rl/agents/agent.py:75-100) evaluate single states with plain torch ops on the padded
+  tensors.  This path never sees an optimizer step; ``update_params`` refuses to run on it.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import native, packer
+from .engine import NativeEngine
+
+_PAD_LOGIT = -2. ** 32 + 1       # policy.py:50,59
+
+
+def _mlp(sizes_in, hidden, prefix='linear_', act_prefix='tanh_', first_flatten=False, bias_after_first=True,
+         last_act=True, flatten_last_if_one=False, last_flatten_prefix='flatten_'):
+    seq = nn.Sequential()
+    prev = sizes_in
+    for i, h in enumerate(hidden):
+        if i == 0 and first_flatten:
+            seq.add_module('flatten_0', nn.Flatten())
+        seq.add_module(prefix + str(i), nn.Linear(prev, h, bias=(i == 0 or bias_after_first)))
+        if i < len(hidden) - 1 or last_act:
+            seq.add_module(act_prefix + str(i), nn.Tanh())
+        elif flatten_last_if_one and h == 1:
+            seq.add_module(last_flatten_prefix + str(i), nn.Flatten())
+        prev = h
+    return seq
+
+
+class SGNNStateEncoder(nn.Module):
+    """Parameter container + CPU forward of the shared GNN state encoder (state_encoder.py:7-214)."""
+    EPSILON = 1e-6
+
+    def __init__(self, cfg, agent):
+        super().__init__()
+        self.cfg = cfg
+        self.agent = agent
+        D = cfg['gcn_node_dim']
+        self.numerical_feature_encoder = _mlp(agent.numerical_feature_size, cfg['state_encoder_hidden_size'],
+                                              first_flatten=True)
+        self.node_encoder = nn.Linear(agent.node_dim, D)
+        self.num_gcn_layers = cfg['num_gcn_layers']
+        self.num_edge_fc_layers = cfg['num_edge_fc_layers']
+        self.edge_fc_layers = nn.ModuleList()
+        for _ in range(self.num_gcn_layers):
+            fc = nn.Sequential()
+            for k in range(self.num_edge_fc_layers):
+                fc.add_module('linear_%d' % k, nn.Linear(2 * D if k == 0 else D, D))
+                fc.add_module('tanh_%d' % k, nn.Tanh())
+            self.edge_fc_layers.append(fc)
+        self.max_num_nodes = cfg['max_num_nodes']
+        self.max_num_edges = cfg['max_num_edges']
+        self.attention_layer = nn.MultiheadAttention(D, cfg['num_attention_heads'])
+        self.attention_query_layer = nn.Linear(D, D)
+        self.attention_key_layer = nn.Linear(D, D)
+        self.attention_value_layer = nn.Linear(D, D)
+        self.output_policy_land_use_size = 4 * D
+        self.output_policy_road_size = D
+        self.output_value_size = 3 * D + cfg['state_encoder_hidden_size'][-1] + 3
+
+    # ---- CPU rollout path (padded dense tensors, B is 1 in practice)
+    @staticmethod
+    def batch_data(x):
+        return [torch.stack(f) for f in zip(*x)]
+
+    def _messages(self, h, edge_index, edge_mask, fc):
+        D = h.size(-1)
+        src = edge_index[..., 0].unsqueeze(-1).expand(-1, -1, D)
+        dst = edge_index[..., 1].unsqueeze(-1).expand(-1, -1, D)
+        hs, hd = torch.gather(h, 1, src), torch.gather(h, 1, dst)
+        m = 0.5 * (fc(torch.cat([hs, hd], -1)) + fc(torch.cat([hd, hs], -1)))
+        return m * edge_mask.unsqueeze(-1).to(m.dtype), src, dst
+
+    def _aggregate(self, m, src, dst, edge_mask, num_nodes):
+        agg = torch.zeros(m.size(0), num_nodes, m.size(-1), dtype=m.dtype, device=m.device)
+        cnt = torch.zeros_like(agg)
+        ones = edge_mask.unsqueeze(-1).expand_as(m).to(m.dtype)
+        for idx in (src, dst):
+            agg = agg.scatter_add(1, idx, m)
+            cnt = cnt.scatter_add(1, idx, ones)
+        return agg / (cnt + self.EPSILON)
+
+    def forward(self, x):
+        numerical, nodes, edge_index, cur, node_mask, edge_mask, land_mask, road_mask, stage = self.batch_data(x)
+        h_num = self.numerical_feature_encoder(numerical)
+        h = self.node_encoder(nodes)
+        c = self.node_encoder(cur.unsqueeze(1))
+        m = None
+        for fc in self.edge_fc_layers:
+            m, src, dst = self._messages(h, edge_index, edge_mask, fc)
+            h = h + self._aggregate(m, src, dst, edge_mask, nodes.size(1))
+        fe, fn = edge_mask.unsqueeze(-1).to(h.dtype), node_mask.unsqueeze(-1).to(h.dtype)
+        mean_e = (m * fe).sum(1) / fe.sum(1)
+        mean_n = (h * fn).sum(1) / fn.sum(1)
+        q = self.attention_query_layer(c).transpose(0, 1)
+        k = self.attention_key_layer(h).transpose(0, 1)
+        v = self.attention_value_layer(h).transpose(0, 1)
+        att, _ = self.attention_layer(q, k, v, key_padding_mask=~node_mask)
+        att = att.transpose(0, 1).squeeze(1)
+        state_value = torch.cat([h_num, mean_n, mean_e, att, stage], dim=1)
+        cc = c.expand(-1, m.size(1), -1)
+        state_land = torch.cat([m, cc, m * cc, m - cc], dim=-1)
+        return state_land, h, state_value, land_mask, road_mask, stage
+
+
+class _HipNetwork(torch.autograd.Function):
+    """value / log-prob / entropy of a packed minibatch through the native engine."""
+
+    @staticmethod
+    def forward(ctx, flat_params, runner):
+        value, logp, ent = runner.run_forward(flat_params)
+        ctx.runner = runner
+        ctx.save_for_backward(flat_params)
+        return value, logp, ent
+
+    @staticmethod
+    def backward(ctx, dvalue, dlogp, dent):
+        (flat_params,) = ctx.saved_tensors
+        grads = ctx.runner.run_backward(flat_params, dvalue, dlogp, dent)
+        return grads, None
+
+
+class _Runner:
+    """One packed batch bound to an engine (forward keeps the activations for backward)."""
+
+    def __init__(self, engine, packed, sched):
+        self.engine, self.packed, self.sched = engine, packed, sched
+        self.mb, self.item = sched.minibatch(0)
+
+    def run_forward(self, flat_params):
+        B, dev = self.mb.B, self.engine.device
+        value = torch.empty(B, device=dev)
+        logp = torch.empty(B, device=dev)
+        ent = torch.empty(B, device=dev)
+        self.engine.forward(self.packed, self.mb, flat_params.contiguous(), value, logp, ent, keep=True)
+        return value, logp, ent
+
+    def run_backward(self, flat_params, dvalue, dlogp, dent):
+        B, dev = self.mb.B, self.engine.device
+        z = torch.zeros(B, device=dev)
+        grads = torch.zeros_like(flat_params)
+        self.engine.backward(self.packed, self.mb, flat_params.contiguous(),
+                             z if dvalue is None else dvalue.contiguous(), z if dlogp is None else dlogp.contiguous(),
+                             z if dent is None else dent.contiguous(), grads)
+        return grads
+
+
+class _HipBackend:
+    """Shared by policy_net and value_net (they share the encoder object): engine + name mapping."""
+
+    def __init__(self, shared_net, policy_cfg, value_cfg):
+        self.shared_net = shared_net
+        self.policy_cfg, self.value_cfg = policy_cfg, value_cfg
+        self.policy_net = None
+        self.value_net = None
+        self._engine = None
+
+    def desc(self):
+        return native.make_desc(self.shared_net.cfg, self.policy_cfg, self.value_cfg, self.shared_net.agent.node_dim,
+                                self.shared_net.agent.numerical_feature_size)
+
+    def engine(self, device):
+        if self._engine is None or self._engine.device != torch.device(device):
+            self._engine = NativeEngine(self.desc(), device)
+        return self._engine
+
+    def named_params(self):
+        """flat-layout name -> nn.Parameter (de-duplicated: the encoder appears once)."""
+        out = {}
+        for k, v in self.shared_net.named_parameters():
+            out['shared_net.' + k] = v
+        for k, v in self.policy_net.policy_land_use_head.named_parameters():
+            out['policy_land_use_head.' + k] = v
+        for k, v in self.policy_net.policy_road_head.named_parameters():
+            out['policy_road_head.' + k] = v
+        for k, v in self.value_net.value_head.named_parameters():
+            out['value_head.' + k] = v
+        return out
+
+    def flat_params_autograd(self, engine):
+        """Flat parameter vector that autograd can differentiate back to the module parameters."""
+        named = self.named_params()
+        pieces, cursor = [], 0
+        for name, off, rows, cols, _ in engine.table:
+            if off > cursor:
+                pieces.append(torch.zeros(off - cursor, device=engine.device))
+            pieces.append(named[name].reshape(-1))
+            cursor = off + rows * cols
+        if engine.n_floats > cursor:
+            pieces.append(torch.zeros(engine.n_floats - cursor, device=engine.device))
+        return torch.cat(pieces)
+
+    def run(self, x, action):
+        """x: list[B] of list[9] tensors on any device.  Returns (value, logp, ent) f32[B] on the GPU."""
+        device = next(self.shared_net.parameters()).device
+        engine = self.engine(device)
+        states = [[f.detach().cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in s] for s in x]
+        B = len(states)
+        if action is None:
+            act = np.zeros((B, 2), dtype=np.float32)
+        else:
+            act = action.detach().cpu().numpy().astype(np.float32).reshape(B, 2)
+        pk = packer.pack_replay(states, act, self.shared_net.agent.node_dim,
+                                self.shared_net.agent.numerical_feature_size).to(device)
+        sched = packer.Schedule(pk, [np.arange(B)], device)
+        runner = _Runner(engine, pk, sched)
+        flat = self.flat_params_autograd(engine)
+        value, logp, ent = _HipNetwork.apply(flat, runner)
+        return value, logp, ent, runner
+
+
+def _on_gpu(module):
+    return next(module.parameters()).device.type == 'cuda'
+
+
+class UrbanPlanningPolicy(nn.Module):
+    """Two masked-softmax pointer heads over edges / nodes (policy.py:5-104)."""
+
+    def __init__(self, cfg, agent, shared_net, backend=None):
+        super().__init__()
+        self.cfg = cfg
+        self.agent = agent
+        self.shared_net = shared_net
+        self.policy_land_use_head = self._head(shared_net.output_policy_land_use_size,
+                                               cfg['policy_land_use_head_hidden_size'], 'land_use')
+        self.policy_road_head = self._head(shared_net.output_policy_road_size,
+                                           cfg['policy_road_head_hidden_size'], 'road')
+        self._backend = [backend]          # list: keep the backend out of nn.Module attribute registration
+
+    @staticmethod
+    def _head(input_size, hidden, name):
+        return _mlp(input_size, hidden, prefix=name + '_linear_', act_prefix=name + '_tanh_', bias_after_first=False,
+                    last_act=False, flatten_last_if_one=True, last_flatten_prefix=name + '_flatten_')
+
+    # ---- CPU (rollout) path
+    def forward(self, x):
+        if _on_gpu(self):
+            raise RuntimeError('UrbanPlanningPolicy.forward() returns Categorical objects over padded rows and is '
+                               'only available on the CPU rollout path; on the GPU call select_action / '
+                               'get_log_prob_entropy (HIP path).')
+        s_land, s_road, _, land_mask, road_mask, stage = self.shared_net(x)
+        land_dist = road_dist = None
+        is_land, is_road = stage[:, 0].bool(), stage[:, 1].bool()
+        if is_land.any():
+            z = self.policy_land_use_head(s_land[is_land])
+            z = torch.where(land_mask[is_land], z, torch.full_like(z, _PAD_LOGIT))
+            land_dist = torch.distributions.Categorical(logits=z)
+        if is_road.any():
+            z = self.policy_road_head(s_road[is_road])
+            z = torch.where(road_mask[is_road], z, torch.full_like(z, _PAD_LOGIT))
+            road_dist = torch.distributions.Categorical(logits=z)
+        return land_dist, road_dist, stage
+
+    def select_action(self, x, mean_action=False):
+        if _on_gpu(self):
+            return self._select_action_gpu(x, mean_action)
+        land_dist, road_dist, stage = self.forward(x)
+        action = torch.zeros(stage.shape[0], 2, dtype=self.agent.dtype, device=stage.device)
+        for col, dist in ((0, land_dist), (1, road_dist)):
+            if dist is not None:
+                a = dist.probs.argmax(dim=1) if mean_action else dist.sample()
+                action[stage[:, col].bool(), col] = a.to(self.agent.dtype)
+        return action
+
+    def _select_action_gpu(self, x, mean_action):
+        backend = self._backend[0]
+        with torch.no_grad():
+            _, _, _, runner = backend.run(x, None)
+            eng, mb, meta = runner.engine, runner.mb, runner.packed.meta
+            p_he = eng.ws_tensor(mb, 'p_he').reshape(-1).cpu()
+            p_rn = eng.ws_tensor(mb, 'p_rn').reshape(-1).cpu()
+            he_slot = runner.packed.section('he_slot', np.int32, max(int(runner.packed.layout.total_he), 1))
+            rn_node = runner.packed.section('rn_node', np.uint16, max(int(runner.packed.layout.total_rn), 1))
+        B = mb.B
+        action = torch.zeros(B, 2, dtype=self.agent.dtype)
+        for b in range(B):
+            st, cnt_h, cnt_r = int(meta[b, 4]), int(meta[b, 2]), int(meta[b, 3])
+            if st == 0 and cnt_h > 0:
+                p = p_he[int(meta[b, 11]):int(meta[b, 11]) + cnt_h]
+                k = int(p.argmax()) if mean_action else int(torch.multinomial(p, 1))
+                action[b, 0] = float(he_slot[int(meta[b, 11]) + k])
+            elif st == 1 and cnt_r > 0:
+                p = p_rn[int(meta[b, 12]):int(meta[b, 12]) + cnt_r]
+                k = int(p.argmax()) if mean_action else int(torch.multinomial(p, 1))
+                action[b, 1] = float(rn_node[int(meta[b, 12]) + k])
+        return action.to(next(self.parameters()).device)
+
+    def get_log_prob_entropy(self, x, action):
+        if _on_gpu(self):
+            _, logp, ent, _ = self._backend[0].run(x, action)
+            return logp.unsqueeze(1), ent.unsqueeze(1)
+        land_dist, road_dist, stage = self.forward(x)
+        B = stage.shape[0]
+        log_prob = torch.zeros(B, dtype=self.agent.dtype, device=stage.device)
+        entropy = torch.zeros(B, dtype=self.agent.dtype, device=stage.device)
+        for col, dist in ((0, land_dist), (1, road_dist)):
+            if dist is not None:
+                sel = stage[:, col].bool()
+                log_prob[sel] = dist.log_prob(action[sel, col])
+                entropy[sel] = dist.entropy()
+        return log_prob.unsqueeze(1), entropy.unsqueeze(1)
+
+
+class UrbanPlanningValue(nn.Module):
+    """MLP value head on the pooled graph features (value.py:4-39)."""
+
+    def __init__(self, cfg, agent, shared_net, backend=None):
+        super().__init__()
+        self.cfg = cfg
+        self.agent = agent
+        self.shared_net = shared_net
+        self.value_head = _mlp(shared_net.output_value_size, cfg['value_head_hidden_size'], last_act=False)
+        self._backend = [backend]
+
+    def forward(self, x):
+        if _on_gpu(self):
+            value, _, _, _ = self._backend[0].run(x, None)
+            return value.unsqueeze(1)
+        _, _, state_value, _, _, _ = self.shared_net(x)
+        return self.value_head(state_value)
+
+
+def create_sgnn_model(cfg, agent):
+    """Drop-in for urban_planning/models/model.py:8-19.  ``cfg`` carries the three spec dicts
+    (``state_encoder_specs``, ``policy_specs``, ``value_specs``); ``agent`` carries ``node_dim``,
+    ``numerical_feature_size`` and ``dtype``."""
+    shared_net = SGNNStateEncoder(cfg.state_encoder_specs, agent)
+    backend = _HipBackend(shared_net, cfg.policy_specs, cfg.value_specs)
+    policy_net = UrbanPlanningPolicy(cfg.policy_specs, agent, shared_net, backend)
+    value_net = UrbanPlanningValue(cfg.value_specs, agent, shared_net, backend)
+    backend.policy_net, backend.value_net = policy_net, value_net
+    return policy_net, value_net
+
+
+class ActorCritic(nn.Module):
+    """Same container as urban_planning/models/model.py:36-47 (one optimizer / checkpoint dict)."""
+
+    def __init__(self, actor_net, value_net):
+        super().__init__()
+        self.actor_net = actor_net
+        self.value_net = value_net
+
+
+def backend_of(net):
+    """The shared HIP backend of a policy_net / value_net created by ``create_sgnn_model``."""
+    return net._backend[0]

@@ -1,0 +1,345 @@
+"""Parity of the HIP path against the oracle / golden vectors (needs a real MI355X: -m gpu).
+
+Everything goes through the C ABI (ctypes -> libupamd.so); nothing here touches /root/reference.
+Tolerances (fp32): per-row value / log-prob / entropy abs <= 1e-5 or rel <= 1e-4;
+loss scalars rel <= 1e-5 (abs 1e-6); parameter gradients rel-L2 <= 1e-4 and max-abs <= 1e-5 * scale;
+parameters after the update rel-L2 <= 1e-4; GAE bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import csr_model
+import helpers
+from oracle import sgnn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def _engine_setup(cfg, sd_actor_critic, states, actions):
+    from drl_urban_planning_amd import packer
+    from drl_urban_planning_amd.models import backend_of
+    policy_net, value_net, ac = helpers.build_product(cfg)
+    ac.load_state_dict(sd_actor_critic)
+    ac.to(DEV)
+    backend = backend_of(policy_net)
+    eng = backend.engine(torch.device(DEV))
+    flat = eng.flatten(backend.named_params())
+    pk = packer.pack_replay(states, actions, 23, 52).to(DEV)
+    sched = packer.Schedule(pk, [np.arange(len(states))], DEV)
+    mb, item = sched.minibatch(0)
+    return policy_net, value_net, ac, eng, flat, pk, sched, mb
+
+
+def _forward(eng, pk, mb, flat):
+    B = mb.B
+    value, logp, ent = (torch.empty(B, device=DEV) for _ in range(3))
+    eng.forward(pk, mb, flat, value, logp, ent, keep=True)
+    torch.cuda.synchronize()
+    return value, logp, ent
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
+    g = grads_flat.detach().cpu().numpy()
+    refs = {name: ref_of(name) for name, *_ in eng.table}
+    scale = max(max(float(np.abs(r).max()) for r in refs.values()), 1e-12)
+    report = []
+    bad = []
+    for name, off, rows, cols, _ in eng.table:
+        mine = g[off:off + rows * cols].reshape(refs[name].shape)
+        err = float(np.abs(mine - refs[name]).max())
+        rl2 = _rel_l2(mine, refs[name])
+        report.append('%-60s max|d|=%.3e relL2=%.3e |ref|max=%.3e' % (name, err, rl2, float(np.abs(refs[name]).max())))
+        # tensors whose reference gradient is pure rounding noise (key-side attention biases) only get the abs test
+        if err > atol_scale * scale and (rl2 > rtol_l2):
+            bad.append(name)
+        elif err > 50 * atol_scale * scale:
+            bad.append(name)
+    assert not bad, 'gradient mismatch in %s\n%s' % (bad, '\n'.join(report))
+
+
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c'])
+def test_forward_stages_match_oracle(name):
+    z, sd, states = helpers.load_case(name)
+    cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
+    B = z['fwd/value'].shape[0]
+    heads = helpers.CASE_MODEL[name]['heads']
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, states[:B], z['actions'][:B])
+    value, logp, ent = _forward(eng, pk, mb, flat)
+    P = helpers.oracle_params(sd, requires_grad=False)
+    keep = {}
+    with torch.no_grad():
+        orc.value_forward(P, orc.tensorfy(states[:B]), heads, keep)
+    L = helpers.CASE_MODEL[name]['L']
+    ns = pk.meta[:B, 0]
+    offs = np.concatenate([[0], np.cumsum(ns)])
+    msgs = []
+    for l in range(L + 1):
+        mine = eng.ws_tensor(mb, 'H%d' % l).cpu().numpy()
+        ref = keep['h_nodes_%d' % l].numpy()
+        err = max(float(np.abs(mine[offs[b]:offs[b + 1]] - ref[b, :ns[b]]).max()) for b in range(B))
+        msgs.append('H%d err %.3e' % (l, err))
+        assert err < 2e-5, msgs
+    for nm, key in (('hbarV', 'h_nodes_mean'), ('hbarE', 'h_edges_mean'), ('C', 'h_cur'), ('att', 'h_att'),
+                    ('SV', 'state_value')):
+        mine = eng.ws_tensor(mb, nm).cpu().numpy()
+        err = float(np.abs(mine - keep[key].numpy()).max())
+        msgs.append('%s err %.3e' % (nm, err))
+        assert err < 2e-5, msgs
+    np.testing.assert_allclose(value.cpu().numpy(), z['fwd/value'][:, 0], rtol=1e-4, atol=1e-5, err_msg=str(msgs))
+    np.testing.assert_allclose(logp.cpu().numpy(), z['fwd/logp'][:, 0], rtol=1e-4, atol=1e-5, err_msg=str(msgs))
+    np.testing.assert_allclose(ent.cpu().numpy(), z['fwd/entropy'][:, 0], rtol=1e-4, atol=1e-5, err_msg=str(msgs))
+
+
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c'])
+def test_loss_and_gradients_match_reference(name):
+    from test_oracle_golden import CASE_HYPER
+    z, sd, states = helpers.load_case(name)
+    cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
+    hy = CASE_HYPER[name]
+    B = z['fwd/value'].shape[0]
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, states[:B], z['actions'][:B])
+    value, logp, ent = _forward(eng, pk, mb, flat)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    adv, ret, old = t(z['mb/adv'][:, 0]), t(z['mb/ret'][:, 0]), t(z['mb/old_logp'][:, 0])
+    exps = t(z['exps'][:B])
+    dvalue, dlogp, dent = (torch.empty(B, device=DEV) for _ in range(3))
+    losses = torch.zeros(4, device=DEV)
+    nind = int((z['exps'][:B] != 0).sum())
+    eng.ppo_loss(B, value, logp, ent, adv, ret, old, exps, hy['clip_epsilon'], hy['value_pred_coef'],
+                 hy['entropy_coef'], 1.0 / B, 1.0 / nind, dvalue, dlogp, dent, losses)
+    np.testing.assert_allclose(losses.cpu().numpy(), z['mb/losses'], rtol=2e-5, atol=2e-6)
+    # seeds agree with the spec
+    _, dv, dl, de = csr_model.ppo_seeds(value.cpu().numpy().astype(np.float64), logp.cpu().numpy().astype(np.float64),
+                                        ent.cpu().numpy().astype(np.float64), z['mb/adv'][:, 0], z['mb/ret'][:, 0],
+                                        z['mb/old_logp'][:, 0], z['exps'][:B], hy['clip_epsilon'],
+                                        hy['value_pred_coef'], hy['entropy_coef'])
+    np.testing.assert_allclose(dvalue.cpu().numpy(), dv, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dlogp.cpu().numpy(), dl, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(dent.cpu().numpy(), de, rtol=1e-5, atol=1e-9)
+    grads = torch.zeros(eng.n_floats, device=DEV)
+    eng.backward(pk, mb, flat, dvalue, dlogp, dent, grads)
+    torch.cuda.synchronize()
+    _check_grads(eng, grads, lambda nm: z[helpers.golden_key('grad/', nm)])
+
+
+@pytest.mark.parametrize('name', ['case_a', 'case_c'])
+def test_module_surface_autograd(name):
+    """The reference's own call pattern: value_net(x), policy_net.get_log_prob_entropy(x, a), loss.backward()."""
+    from test_oracle_golden import CASE_HYPER
+    z, sd, states = helpers.load_case(name)
+    cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
+    hy = CASE_HYPER[name]
+    B = z['fwd/value'].shape[0]
+    policy_net, value_net, ac = helpers.build_product(cfg)
+    ac.load_state_dict(sd)
+    ac.to(DEV)
+    xs = [[torch.tensor(f).to(DEV) for f in s] for s in states[:B]]
+    actions = torch.from_numpy(z['actions'][:B]).float().to(DEV)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    adv, ret, old, exps = t(z['mb/adv']), t(z['mb/ret']), t(z['mb/old_logp']), t(z['exps'][:B])
+    ind = exps.nonzero(as_tuple=False).squeeze(1)
+    values_pred = value_net(xs)
+    value_loss = (values_pred - ret).pow(2).mean()
+    log_probs, entropy = policy_net.get_log_prob_entropy(xs, actions)
+    ratio = torch.exp(log_probs[ind] - old[ind])
+    surr1 = ratio * adv[ind]
+    surr2 = torch.clamp(ratio, 1.0 - hy['clip_epsilon'], 1.0 + hy['clip_epsilon']) * adv[ind]
+    surr_loss = -torch.min(surr1, surr2).mean()
+    entropy_loss = -entropy[ind].mean()
+    loss = surr_loss + hy['value_pred_coef'] * value_loss + hy['entropy_coef'] * entropy_loss
+    np.testing.assert_allclose([loss.item(), value_loss.item(), surr_loss.item(), entropy_loss.item()], z['mb/losses'],
+                               rtol=2e-5, atol=2e-6)
+    loss.backward()
+    scale = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith('grad/'))
+    for k, p in ac.named_parameters():
+        g = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)
+        ref = z['grad/' + k]
+        assert np.abs(g - ref).max() <= 1e-5 * scale or _rel_l2(g, ref) <= 1e-4, k
+    with torch.no_grad():
+        act = policy_net.select_action(xs, mean_action=True).cpu().numpy()
+    for b in range(B):
+        st = int(np.argmax(states[b][8]))
+        if st == 0:
+            assert states[b][6][int(act[b, 0])]
+        elif st == 1:
+            assert states[b][7][int(act[b, 1])]
+
+
+@pytest.mark.parametrize('name', ['case_a', 'case_b'])
+def test_gae_bit_exact(name):
+    from test_oracle_golden import CASE_HYPER
+    z, sd, states = helpers.load_case(name)
+    cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
+    hy = CASE_HYPER[name]
+    _, _, _, eng, *_ = _engine_setup(cfg, sd, states[:4], z['actions'][:4])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    rewards, masks, values = t(z['rewards']), t(z['masks']), t(z['gae/values'][:, 0])
+    for tag, (ga, ta) in dict(cfg=(hy['gamma'], hy['tau']), g95=(0.99, 0.95)).items():
+        adv, ret = torch.empty_like(values), torch.empty_like(values)
+        eng.gae(rewards, masks, values, ga, ta, adv, ret)
+        assert np.array_equal(adv.cpu().numpy(), z['gae/%s_adv' % tag][:, 0]), tag
+        assert np.array_equal(ret.cpu().numpy(), z['gae/%s_ret' % tag][:, 0]), tag
+
+
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c'])
+def test_update_params_matches_reference(name):
+    """The whole update_params (two calls): loss curve within 1e-4 rel per step, parameters rel-L2 <= 1e-4,
+    loss_iter bookkeeping, TB scalar tags; clipping active on the very first step only."""
+    from drl_urban_planning_amd import PPOUpdater, synth
+    from oracle.ref_import import ScalarLog
+    from test_oracle_golden import CASE_HYPER, CASE_EPOCHS, CASE_SEED, CASE_B
+    z, sd, states = helpers.load_case(name)
+    cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
+    hy = CASE_HYPER[name]
+    policy_net, value_net, ac = helpers.build_product(cfg)
+    ac.load_state_dict(sd)
+    ac.to(DEV)
+    up = PPOUpdater(policy_net, value_net, lr=hy['lr'], eps=hy['eps'], weight_decay=hy['weight_decay'],
+                    gamma=hy['gamma'], tau=hy['tau'], clip_epsilon=hy['clip_epsilon'],
+                    value_pred_coef=hy['value_pred_coef'], entropy_coef=hy['entropy_coef'],
+                    num_optim_epoch=CASE_EPOCHS[name], mini_batch_size=CASE_B[name])
+    replay = synth.Replay(states, z['actions'], z['masks'], z['rewards'], z['exps'])
+    log = ScalarLog()
+    np.random.seed(CASE_SEED[name] + 11)
+    elapsed = up.update_params(replay, 0, tb_logger=log)
+    assert elapsed > 0
+    np.testing.assert_allclose(up.last_losses, z['upd/scalars'], rtol=1e-4, atol=2e-6)
+    assert up.loss_iter == int(z['upd/loss_iter'])
+    per_step = [v for (tag, v, s) in log.scalars if tag == 'loss/loss']
+    assert len(per_step) == up.loss_iter
+    assert [s for (tag, v, s) in log.scalars if tag == 'loss/loss'] == list(range(up.loss_iter))
+    assert sum(1 for (tag, v, s) in log.scalars if tag == 'loss/epoch_loss') == CASE_EPOCHS[name]
+    mine = {k: v.detach().cpu().numpy() for k, v in ac.state_dict().items()}
+    for k in mine:
+        assert _rel_l2(mine[k], z['upd_sd/' + k]) <= 1e-4, (k, _rel_l2(mine[k], z['upd_sd/' + k]))
+    np.random.seed(CASE_SEED[name] + 12)
+    up.update_params(replay, 1, tb_logger=log)
+    mine = {k: v.detach().cpu().numpy() for k, v in ac.state_dict().items()}
+    for k in mine:
+        assert _rel_l2(mine[k], z['upd2_sd/' + k]) <= 2e-4, (k, _rel_l2(mine[k], z['upd2_sd/' + k]))
+    n1 = z['upd/scalars'].shape[0]
+    np.testing.assert_allclose(up.last_losses, z['upd2/scalars'][n1:], rtol=2e-4, atol=5e-6)
+
+
+def _random_case(D, L, heads, S, land, road, value, T, max_nodes, max_edges, seed, road_fraction, n_range):
+    from drl_urban_planning_amd import synth
+    cfg = helpers.make_cfg(D=D, L=L, S=S, heads=heads, land_head=land, road_head=road, value_head=value,
+                           max_nodes=max_nodes, max_edges=max_edges)
+    _, _, ac = helpers.build_product(cfg, seed=seed)
+    sd = helpers.perturbed_state_dict(ac, seed + 1, scale=0.05)
+    replay = synth.make_replay(T, 'hlg', max_nodes=max_nodes, max_edges=max_edges, seed=seed,
+                               road_fraction=road_fraction, n_range=n_range)
+    return cfg, sd, replay
+
+
+@pytest.mark.parametrize('D,L,heads,n_range,T', [(256, 3, 1, (200, 345), 5), (128, 2, 4, (40, 90), 6),
+                                                    (64, 2, 2, (30, 60), 6)])
+def test_wide_model_matches_oracle(D, L, heads, n_range, T):
+    """BASELINE cfg-2 dims (3 layers x 256) on HLG-shaped graphs: exercises the MFMA GEMM tiles."""
+    cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
+                                   int(5.55 * n_range[1]) + 10, seed=21, road_fraction=0.3, n_range=n_range)
+    states, actions = replay.states, replay.actions
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, states, actions)
+    value, logp, ent = _forward(eng, pk, mb, flat)
+    P = helpers.oracle_params(sd)
+    xs = orc.tensorfy(states)
+    act_t = torch.from_numpy(actions).float()
+    g = torch.Generator().manual_seed(5)
+    adv, ret = torch.randn(T, 1, generator=g), torch.randn(T, 1, generator=g)
+    with torch.no_grad():
+        v0 = orc.value_forward(P, xs, heads)
+        lp0, en0 = orc.get_log_prob_entropy(P, xs, act_t, heads)
+    np.testing.assert_allclose(value.cpu().numpy(), v0[:, 0].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp0[:, 0].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ent.cpu().numpy(), en0[:, 0].numpy(), rtol=1e-4, atol=1e-5)
+    old = lp0 + 0.3 * torch.randn(T, 1, generator=g)
+    exps = torch.ones(T)
+    loss, vl, sl, el = orc.ppo_losses(P, xs, act_t, adv, ret, old, exps, 0.2, 0.5, 0.01, heads)
+    loss.backward()
+    dvalue, dlogp, dent = (torch.empty(T, device=DEV) for _ in range(3))
+    losses = torch.zeros(4, device=DEV)
+    eng.ppo_loss(T, value, logp, ent, adv[:, 0].to(DEV), ret[:, 0].to(DEV), old[:, 0].to(DEV), exps.to(DEV), 0.2, 0.5,
+                 0.01, 1.0 / T, 1.0 / T, dvalue, dlogp, dent, losses)
+    np.testing.assert_allclose(losses.cpu().numpy(), [loss.item(), vl.item(), sl.item(), el.item()], rtol=1e-4, atol=1e-5)
+    grads = torch.zeros(eng.n_floats, device=DEV)
+    eng.backward(pk, mb, flat, dvalue, dlogp, dent, grads)
+    torch.cuda.synchronize()
+    _check_grads(eng, grads, lambda nm: (P[nm].grad if P[nm].grad is not None else torch.zeros_like(P[nm])).numpy())
+
+
+def test_full_size_properties():
+    """BASELINE-size minibatch (2048 HLG-shaped graphs, D=256, L=3) through size-independent properties:
+    padding invariance, row-order invariance (bit-exact), run-to-run determinism of the gradients."""
+    from drl_urban_planning_amd import packer, synth
+    B = 2048
+    cfg = helpers.make_cfg(D=256, L=3)
+    _, _, ac = helpers.build_product(cfg, seed=3)
+    sd = ac.state_dict()
+    replay = synth.make_replay(B, 'hlg', seed=9, unique=256)
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, replay.states, replay.actions)
+    value, logp, ent = _forward(eng, pk, mb, flat)
+    assert torch.isfinite(value).all() and torch.isfinite(logp).all() and torch.isfinite(ent).all()
+    assert (ent > 0).all() and (logp < 0).all()
+    # states are tiled from 256 unique ones: identical graphs must give identical rows (bit-exact)
+    v = value.cpu().numpy().reshape(8, 256)
+    assert np.array_equal(v, np.broadcast_to(v[0], v.shape))
+    lp = logp.cpu().numpy().reshape(8, 256)
+    assert np.array_equal(lp, np.broadcast_to(lp[0], lp.shape))
+    # row order invariance
+    perm = np.random.default_rng(0).permutation(B)
+    sched2 = packer.Schedule(pk, [perm], DEV)
+    mb2, _ = sched2.minibatch(0)
+    value2, logp2, ent2 = _forward(eng, pk, mb2, flat)
+    assert np.array_equal(value2.cpu().numpy(), value.cpu().numpy()[perm])
+    assert np.array_equal(ent2.cpu().numpy(), ent.cpu().numpy()[perm])
+    # padding invariance: same graphs re-padded tightly
+    sub = 64
+    tight = []
+    for s in replay.states[:sub]:
+        n, e = int(s[4].sum()), int(s[5].sum())
+        ei = np.full((e + 3, 2), n + 1, dtype=np.int64)
+        ei[:e] = s[2][:e]
+        tight.append([s[0], np.concatenate([s[1][:n], np.zeros((2, 23), np.float32)]), ei, s[3],
+                      np.concatenate([s[4][:n], [False, False]]), np.concatenate([s[5][:e], [False] * 3]),
+                      np.concatenate([s[6][:e], [False] * 3]), np.concatenate([s[7][:n], [False, False]]), s[8]])
+    pk3 = packer.pack_replay(tight, replay.actions[:sub], 23, 52).to(DEV)
+    sched3 = packer.Schedule(pk3, [np.arange(sub)], DEV)
+    mb3, _ = sched3.minibatch(0)
+    value3, logp3, ent3 = _forward(eng, pk3, mb3, flat)
+    assert np.array_equal(value3.cpu().numpy(), value.cpu().numpy()[:sub])
+    assert np.array_equal(logp3.cpu().numpy(), logp.cpu().numpy()[:sub])
+    # determinism of the backward
+    g = torch.Generator().manual_seed(1)
+    dv, dl, de = (torch.randn(B, generator=g).to(DEV) / B for _ in range(3))
+    value, logp, ent = _forward(eng, pk, mb, flat)
+    g1 = torch.zeros(eng.n_floats, device=DEV)
+    eng.backward(pk, mb, flat, dv, dl, de, g1)
+    value, logp, ent = _forward(eng, pk, mb, flat)
+    g2 = torch.zeros(eng.n_floats, device=DEV)
+    eng.backward(pk, mb, flat, dv, dl, de, g2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g1).all()
+    assert torch.equal(g1, g2)
+    assert float(g1.abs().max()) > 0
+
+
+def test_native_failure_modes():
+    from drl_urban_planning_amd import native
+    cfg = helpers.make_cfg(**helpers.CASE_MODEL['case_a'])
+    z, sd, states = helpers.load_case('case_a')
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, states[:4], z['actions'][:4])
+    eng.ensure_workspace(mb)
+    import ctypes as C
+    v = torch.empty(4, device=DEV)
+    rc = eng.lib.upamd_forward(eng.handle, C.c_void_p(pk.dev_buf.data_ptr()), C.byref(pk.layout), C.byref(mb),
+                               C.c_void_p(flat.data_ptr()), C.c_void_p((eng.ws.data_ptr() + 255) // 256 * 256),
+                               C.c_int64(1024), C.c_void_p(v.data_ptr()), C.c_void_p(v.data_ptr()),
+                               C.c_void_p(v.data_ptr()), 0, None)
+    assert rc == -4 and b'workspace too small' in eng.lib.upamd_last_error()
