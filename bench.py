@@ -1,0 +1,224 @@
+"""Benchmark of the hot path: PPO-update samples/s on HLG-shaped graphs (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one PPO optimizer step on one minibatch: SGNN forward (encoder once) + clipped-surrogate /
+value / entropy loss + full backward + (gradient all-reduce) + Adam, exactly what
+``UrbanPlanningAgent.update_policy`` does per minibatch (urban_planning_agent.py:321-346).  The replay is
+packed and resident in HBM before the timed region (value/old-log-prob pre-pass and GAE are done, as they
+are once per iteration in the reference).  Workload at N=1 = BASELINE.json configs[1]: HLG-shaped graphs,
+SGNN 3 layers x 256, PPO minibatch 2048; with N GPUs every rank processes 2048 rows of its own replay shard
+(weak scaling, global minibatch 2048*N) and the flat gradient buffer is all-reduced once per step (RCCL).
+Data is synthetic (seeded generator); weights are random-init of that architecture.
+
+Prints ONE JSON line on rank 0.  Extra objects: ``roofline`` (dominant kernel = the fp32-MFMA node GEMM,
+timed with HIP events on the launch stream inside the timed region) and ``cpu_baseline`` (the oracle =
+PyTorch-CPU port of the reference path, timed on this host's cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: "HLG community, PPO batch 2048, SGNN 3 layers x256, 1xMI355X"
+    'hlg_d256': dict(community='hlg', D=256, L=3, B=2048, T=16384, unique=1024, max_nodes=1000, max_edges=3000),
+    # the reference's shipped YAML dims (hlg.yaml:21-44) -- the tiny-model regime, for orientation
+    'hlg_ref': dict(community='hlg', D=16, L=2, B=256, T=8192, unique=1024, max_nodes=1000, max_edges=3000),
+    # BASELINE.json configs[2]
+    'dhm_d256': dict(community='dhm', D=256, L=3, B=4096, T=32768, unique=1024, max_nodes=1000, max_edges=3000),
+}
+
+
+def model_cfg(w):
+    """The reference's three spec dicts (hlg.yaml:21-33) with the workload's GCN width / depth."""
+    import types
+    cfg = types.SimpleNamespace()
+    cfg.state_encoder_specs = dict(state_encoder_hidden_size=[64, 16], gcn_node_dim=w['D'], num_gcn_layers=w['L'],
+                                   num_edge_fc_layers=1, max_num_nodes=w['max_nodes'], max_num_edges=w['max_edges'],
+                                   num_attention_heads=1)
+    cfg.policy_specs = dict(policy_land_use_head_hidden_size=[32, 1], policy_road_head_hidden_size=[32, 1])
+    cfg.value_specs = dict(value_head_hidden_size=[32, 32, 1])
+    cfg.agent_specs = {}
+    return cfg
+
+
+def build_networks(cfg, seed=0):
+    import types
+    from drl_urban_planning_amd import create_sgnn_model, ActorCritic
+    torch.manual_seed(seed)
+    agent = types.SimpleNamespace(node_dim=23, numerical_feature_size=52, dtype=torch.float32)
+    policy_net, value_net = create_sgnn_model(cfg, agent)
+    return policy_net, value_net, ActorCritic(policy_net, value_net)
+
+
+def algorithmic_flops_per_sample(n, e, D, L, F=23, Fn=52, S=(64, 16), H=32):
+    """forward GEMM FLOPs (factorised forms), x3 for forward + backward."""
+    num_enc = 2 * (Fn * S[0] + S[0] * S[1])
+    node_enc = 2 * (n + 1) * F * D
+    gcn = L * 2 * n * D * 2 * D
+    attn = 4 * n * D + 8 * D * D
+    head = e * (2 * D * H + 2 * H) + 6 * D * H
+    value = 2 * ((3 * D + 19) * 32 + 32 * 32 + 32)
+    return 3.0 * (num_enc + node_enc + gcn + attn + head + value)
+
+
+def cpu_baseline(w, seconds_budget=25.0):
+    """Oracle (PyTorch-CPU port of the reference's update step, padded dense batches as the reference
+    executes them) on this host's cores, bounded sample."""
+    from drl_urban_planning_amd import synth
+    from oracle import sgnn_oracle as orc
+    cfg = model_cfg(w)
+    _, _, ac = build_networks(cfg, seed=0)
+    P = orc.leaf_params(orc.split_actor_critic_state_dict(ac.state_dict()))
+    Bc = 16 if w['D'] >= 128 else 128
+    replay = synth.make_replay(Bc, w['community'], max_nodes=w['max_nodes'], max_edges=w['max_edges'], seed=77)
+    up = orc.OracleUpdater(P, mini_batch_size=Bc, num_optim_epoch=1)
+    actions = torch.from_numpy(replay.actions).float()
+    g = torch.Generator().manual_seed(1)
+    adv, ret = torch.randn(Bc, 1, generator=g), torch.randn(Bc, 1, generator=g)
+    with torch.no_grad():
+        old, _ = orc.get_log_prob_entropy(P, orc.tensorfy(replay.states), actions)
+    exps = torch.ones(Bc)
+    up.step(replay.states, actions, adv, ret, old, exps)        # warm-up (and the one clipped step)
+    t0 = time.time()
+    steps = 0
+    while True:
+        up.step(replay.states, actions, adv, ret, old, exps)
+        steps += 1
+        if time.time() - t0 > seconds_budget * 0.6 or steps >= 8:
+            break
+    dt = time.time() - t0
+    return dict(value=Bc * steps / dt, unit='samples/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d optimizer steps of %d rows (pads %d/%d, D=%d, L=%d), oracle/sgnn_oracle.py, %d torch threads'
+                       % (steps, Bc, w['max_nodes'], w['max_edges'], w['D'], w['L'], torch.get_num_threads()),
+                ms_per_step=1e3 * dt / steps, host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--workload', default='hlg_d256', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    args = ap.parse_args()
+
+    from drl_urban_planning_amd import PPOUpdater, synth, DistContext
+
+    w = WORKLOADS[args.workload]
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    ctx = DistContext.from_env(device=dev)
+    if ctx.world != args.gpus:
+        raise RuntimeError('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, ctx.world))
+    rank = ctx.rank
+
+    cfg = model_cfg(w)
+    policy_net, value_net, ac = build_networks(cfg, seed=0)              # identical weights on every rank
+    ac.to(dev)
+    up = PPOUpdater(policy_net, value_net, lr=4e-4, eps=1e-5, weight_decay=0.0, gamma=1.0, tau=0.0, clip_epsilon=0.2,
+                    value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4, mini_batch_size=w['B'], dist_ctx=ctx)
+    need = args.steps + args.warmup
+    T = max(w['T'], w['B'] * ((need + 3) // 4))
+    t_gen = time.time()
+    replay = synth.make_replay(T, w['community'], max_nodes=w['max_nodes'], max_edges=w['max_edges'],
+                               seed=100 + rank, unique=w['unique'])
+    t_gen = time.time() - t_gen
+    np.random.seed(7 + rank)
+    engine = up.attach()
+    t_prep = time.time()
+    it = up.prepare(replay)
+    torch.cuda.synchronize(dev)
+    t_prep = time.time() - t_prep
+
+    meta = it.packed.meta
+    nodes_per_sample = float(meta[:, 0].mean())
+    edges_per_sample = float(meta[:, 1].mean())
+
+    def run(nsteps, timed):
+        done = 0
+        while done < nsteps:
+            ep = up.make_epoch(it)
+            for k in range(ep.nb):
+                if done >= nsteps:
+                    break
+                up.step(it, ep, k)
+                done += 1
+
+    run(args.warmup, False)
+    torch.cuda.synchronize(dev)
+    if not args.no_kernel_events:
+        engine.profile_reset()
+        engine.profile(True)
+    ctx.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    torch.cuda.synchronize(dev)
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    engine.profile(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    ctx.all_reduce_max(tmax)
+    dt = float(tmax.item())
+
+    kern = {}
+    if not args.no_kernel_events:
+        for name in ('gemm_nt_128', 'gemm_nt_64', 'gemm_nt_32', 'gemm_tn_128', 'gemm_tn_32', 'edge_fwd', 'edge_bwd'):
+            st = engine.profile_read(name)
+            if st['launches']:
+                kern[name] = st
+    up.detach()
+
+    if rank != 0:
+        return
+    samples = w['B'] * ctx.world * args.steps
+    value = samples / dt
+    out = {
+        'metric': 'PPO-update samples/sec', 'value': value, 'unit': 'samples/s', 'n_gpus': ctx.world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s: %s-shaped graphs (n~%.0f nodes, e~%.0f edges live; pads %d/%d), SGNN %d layers x %d, '
+                               'PPO minibatch %d per GPU, replay %d states resident in HBM'
+                               % (args.workload, w['community'].upper(), nodes_per_sample, edges_per_sample, w['max_nodes'],
+                                  w['max_edges'], w['L'], w['D'], w['B'], T),
+                   'global_batch': w['B'] * ctx.world, 'parallelism': 'dp%d' % ctx.world,
+                   'node_steps_per_s': value * nodes_per_sample},
+        'setup_s': {'generate': t_gen, 'pack_upload_prepass_gae': t_prep},
+    }
+    flops_sample = algorithmic_flops_per_sample(nodes_per_sample, edges_per_sample, w['D'], w['L'])
+    out['algorithmic'] = {'flops_per_sample_step': flops_sample, 'tflops': value / ctx.world * flops_sample / 1e12,
+                          'frac_of_fp32_mfma_peak': value / ctx.world * flops_sample / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+    dom = 'gemm_nt_128' if 'gemm_nt_128' in kern else (sorted(kern, key=lambda k: -kern[k]['total_ms'])[0] if kern else None)
+    if dom is not None:
+        st = kern[dom]
+        ach = st['flops'] / (st['total_ms'] * 1e-3) / 1e12
+        out['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'launches': st['launches'],
+                           'avg_launch_ms': st['total_ms'] / st['launches'],
+                           'algorithmic_flops_per_launch': st['flops'] / st['launches']}
+        out['kernel_ms_per_step'] = {k: v['total_ms'] / args.steps for k, v in kern.items()}
+    if ctx.world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(w)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

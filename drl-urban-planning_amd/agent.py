@@ -31,6 +31,24 @@ from .dist import DistContext, global_counts
 from .models import backend_of
 
 
+class IterationState:
+    """Everything one PPO iteration keeps resident in HBM: packed replay + per-row RL tensors."""
+
+    def __init__(self, packed, T, exps_np, exps, values, old_logp, adv, ret):
+        self.packed, self.T = packed, T
+        self.exps_np, self.exps = exps_np, exps
+        self.values, self.old_logp, self.adv, self.ret = values, old_logp, adv, ret
+        self.order = np.arange(T)
+
+
+class Epoch:
+    """One epoch's minibatch schedule (device index arrays uploaded once) + global row counts."""
+
+    def __init__(self, sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob):
+        self.sched, self.order_dev, self.nb = sched, order_dev, nb
+        self.rows_glob, self.ind_glob, self.land_glob, self.road_glob = rows_glob, ind_glob, land_glob, road_glob
+
+
 class PPOUpdater:
     """Owns the flat parameter / Adam buffers of one (policy_net, value_net) pair on one GPU."""
 
@@ -52,10 +70,11 @@ class PPOUpdater:
         self.clip_pending = True              # the generator lists are live until the first call
         self.group_steps = [0, 0, 0]          # Adam step counts: encoder+value / land head / road head
         self.flat = self.m = self.v = self.grads = None
+        self.engine = None
         self.last_losses = None               # np [steps, 4] of the last update_params call
         self.last_timing = {}
 
-    # ------------------------------------------------------------------ helpers
+    # ------------------------------------------------------------------ buffers
     def _device(self):
         dev = next(self.policy_net.parameters()).device
         if dev.type != 'cuda':
@@ -63,125 +82,140 @@ class PPOUpdater:
                                '(they are on %s); there is no CPU fallback for the update path' % dev)
         return dev
 
-    def _ensure_buffers(self, engine):
+    def attach(self):
+        """Bind to the engine of the networks' device and (re)load the flat parameter buffer from them."""
+        dev = self._device()
+        engine = self.backend.engine(dev)
         if self.flat is None or self.flat.device != engine.device or self.flat.numel() != engine.n_floats:
             self.flat = engine.new_flat()
             self.m = engine.new_flat()
             self.v = engine.new_flat()
-            # gradient buffer carries 4 loss scalars at its tail so one all-reduce moves both
+            # the gradient buffer carries the 4 loss scalars at its tail: one all-reduce moves both
             self.grads = torch.zeros(engine.n_floats + 4, dtype=torch.float32, device=engine.device)
             self.scratch = torch.zeros(4096, dtype=torch.float32, device=engine.device)
+        self.engine = engine
+        self._named = self.backend.named_params()
+        engine.flatten(self._named, out=self.flat)
+        B = self.mini_batch_size
+        if getattr(self, '_rowbuf_B', None) != B:
+            self._rows = [torch.empty(B, device=dev) for _ in range(6)]   # value, logp, ent, dvalue, dlogp, dent
+            self._rowbuf_B = B
+        return engine
+
+    def detach(self):
+        """Write the flat parameters back into the nn.Module parameters."""
+        self.engine.unflatten(self.flat, self._named)
 
     @staticmethod
     def _to_f32(x, device):
         return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device)
 
-    # ------------------------------------------------------------------ pre-pass + GAE
-    def prepass(self, engine, packed, T, chunk):
-        """values[T], old_logp[T] with the current parameters, no grad (:256-264, :283-292)."""
-        dev = engine.device
+    # ------------------------------------------------------------------ iteration set-up
+    def prepare(self, batch):
+        """Pack + upload the replay, value / old-log-prob pre-pass (:256-264, :283-292), GAE (:267)."""
+        engine, dev = self.engine, self.engine.device
+        agent = self.policy_net.agent
+        T = len(batch.states)
+        packed = packer.pack_replay(batch.states, np.asarray(batch.actions), agent.node_dim,
+                                    agent.numerical_feature_size, n_threads=self.pack_threads).to(dev)
+        rewards = self._to_f32(batch.rewards, dev)
+        masks = self._to_f32(batch.masks, dev)
+        exps_np = np.asarray(batch.exps, dtype=np.float32)
+        exps = torch.from_numpy(exps_np).to(dev)
         values = torch.empty(T, device=dev)
         logp = torch.empty(T, device=dev)
         ent = torch.empty(T, device=dev)
+        chunk = self.mini_batch_size
         row_lists = [np.arange(i, min(i + chunk, T)) for i in range(0, T, chunk)]
         sched = packer.Schedule(packed, row_lists, dev)
         for k, rows in enumerate(row_lists):
             mb, _ = sched.minibatch(k)
             lo, hi = int(rows[0]), int(rows[-1]) + 1
             engine.forward(packed, mb, self.flat, values[lo:hi], logp[lo:hi], ent[lo:hi], keep=False)
-        return values, logp
-
-    # ------------------------------------------------------------------ the update
-    def update_params(self, batch, iteration=0, tb_logger=None, max_steps=None):
-        t0 = time.time()
-        dev = self._device()
-        engine = self.backend.engine(dev)
-        self._ensure_buffers(engine)
-        named = self.backend.named_params()
-        engine.flatten(named, out=self.flat)
-        self.policy_net.train(True)
-        self.value_net.train(True)
-
-        states = batch.states
-        T = len(states)
-        B = self.mini_batch_size
-        world, rank = self.dist.world, self.dist.rank
-        agent = self.policy_net.agent
-        t_pack = time.time()
-        packed = packer.pack_replay(states, np.asarray(batch.actions), agent.node_dim, agent.numerical_feature_size,
-                                    n_threads=self.pack_threads).to(dev)
-        rewards = self._to_f32(batch.rewards, dev)
-        masks = self._to_f32(batch.masks, dev)
-        exps_np = np.asarray(batch.exps, dtype=np.float32)
-        exps = torch.from_numpy(exps_np).to(dev)
-        t_pre = time.time()
-        values, old_logp = self.prepass(engine, packed, T, B)
         adv = torch.empty(T, device=dev)
         ret = torch.empty(T, device=dev)
         engine.gae(rewards, masks, values, self.gamma, self.tau, adv, ret)
-        t_loop = time.time()
+        return IterationState(packed, T, exps_np, exps, values, logp, adv, ret)
 
-        stage_np = packed.meta[:, packer.M_STAGE]
-        order = np.arange(T)
+    def make_epoch(self, it):
+        """Next epoch's schedule: numpy-global-RNG shuffle composed onto the running order (:306-319)."""
+        T, B, dev = it.T, self.mini_batch_size, self.engine.device
+        perm = np.arange(T)
+        np.random.shuffle(perm)
+        it.order = it.order[perm]
+        stage_np = it.packed.meta[:, packer.M_STAGE]
+        if self.batch_stage:
+            st = stage_np[it.order]
+            it.order = np.concatenate([it.order[st == 0], it.order[st == 1]])
         nb = int(math.floor(T / B))
+        row_lists = [it.order[i * B:(i + 1) * B] for i in range(nb)]
+        sched = packer.Schedule(it.packed, row_lists, dev)
+        # per-minibatch global counts (rows, rows with exps != 0, land-use rows, road rows): known on the
+        # host, exchanged with ONE tiny all-reduce per epoch when data-parallel
+        counts = [[B] * nb, [int((it.exps_np[r] != 0).sum()) for r in row_lists],
+                  [int((stage_np[r] == 0).sum()) for r in row_lists], [int((stage_np[r] == 1).sum()) for r in row_lists]]
+        rows_glob, ind_glob, land_glob, road_glob = global_counts(self.dist, counts, dev)
+        order_dev = torch.from_numpy(np.ascontiguousarray(it.order[:nb * B])).to(dev)
+        return Epoch(sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob)
+
+    # ------------------------------------------------------------------ one optimizer step
+    def step(self, it, ep, k, loss_out=None):
+        """forward + loss + backward (+ all-reduce) + first-step clip + Adam on minibatch k of the epoch.
+        Everything is enqueued on the current stream; nothing synchronises with the host."""
+        engine, B = self.engine, self.mini_batch_size
+        value_b, logp_b, ent_b, dvalue, dlogp, dent = self._rows
+        nflt = engine.n_floats
+        mb, _ = ep.sched.minibatch(k)
+        idx = ep.order_dev[k * B:(k + 1) * B]
+        inv_rows = 1.0 / ep.rows_glob[k]
+        inv_ind = 1.0 / ep.ind_glob[k] if ep.ind_glob[k] > 0 else float('nan')
+        engine.forward(it.packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
+        engine.ppo_loss(B, value_b, logp_b, ent_b, it.adv[idx], it.ret[idx], it.old_logp[idx], it.exps[idx],
+                        self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
+                        dvalue, dlogp, dent, self.grads[nflt:])
+        self.grads[:nflt].zero_()
+        engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
+        if self.dist.world > 1:
+            self.dist.all_reduce_sum(self.grads)          # ONE collective per optimizer step
+        if loss_out is not None:
+            loss_out.copy_(self.grads[nflt:])
+        if self.clip_pending:
+            engine.clip_first_step(self.grads, self.max_grad_norm, self.scratch)
+            self.clip_pending = False
+        active = (True, ep.land_glob[k] > 0, ep.road_glob[k] > 0)
+        for g in range(3):
+            if active[g]:
+                self.group_steps[g] += 1
+                engine.adam_step(g, self.flat, self.grads, self.m, self.v, self.group_steps[g], self.lr,
+                                 self.betas[0], self.betas[1], self.eps, self.weight_decay)
+
+    # ------------------------------------------------------------------ the reference's entry point
+    def update_params(self, batch, iteration=0, tb_logger=None, max_steps=None):
+        t0 = time.time()
+        engine = self.attach()
+        dev = engine.device
+        self.policy_net.train(True)
+        self.value_net.train(True)
+        it = self.prepare(batch)
+        t_loop = time.time()
+        nb = int(math.floor(it.T / self.mini_batch_size))
         steps_total = self.num_optim_epoch * nb if max_steps is None else min(max_steps, self.num_optim_epoch * nb)
         loss_log = torch.zeros(max(steps_total, 1), 4, device=dev)
-        value_b = torch.empty(B, device=dev)
-        logp_b = torch.empty(B, device=dev)
-        ent_b = torch.empty(B, device=dev)
-        dvalue, dlogp, dent = torch.empty(B, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
-        nflt = engine.n_floats
         step = 0
         epoch_ranges = []
-        for epoch in range(self.num_optim_epoch):
+        for _ in range(self.num_optim_epoch):
             if step >= steps_total:
                 break
-            perm = np.arange(T)
-            np.random.shuffle(perm)                      # numpy global RNG, like the reference
-            order = order[perm]                          # permutations compose across epochs
-            if self.batch_stage:
-                st = stage_np[order]
-                order = np.concatenate([order[st == 0], order[st == 1]])
-            row_lists = [order[i * B:(i + 1) * B] for i in range(nb)]
-            sched = packer.Schedule(packed, row_lists, dev)
-            # per-minibatch global counts (rows, rows with exps != 0, land-use rows, road rows): known on the
-            # host, exchanged with ONE tiny all-reduce per epoch when data-parallel
-            counts = [[B] * nb, [int((exps_np[r] != 0).sum()) for r in row_lists],
-                      [int((stage_np[r] == 0).sum()) for r in row_lists],
-                      [int((stage_np[r] == 1).sum()) for r in row_lists]]
-            rows_glob, ind_glob, land_glob, road_glob = global_counts(self.dist, counts, dev)
-            order_dev = torch.from_numpy(np.ascontiguousarray(order[:nb * B])).to(dev)
+            ep = self.make_epoch(it)
             first = step
-            for k in range(nb):
+            for k in range(ep.nb):
                 if step >= steps_total:
                     break
-                mb, item = sched.minibatch(k)
-                idx = order_dev[k * B:(k + 1) * B]
-                inv_rows = 1.0 / rows_glob[k]
-                inv_ind = 1.0 / ind_glob[k] if ind_glob[k] > 0 else float('nan')
-                engine.forward(packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
-                engine.ppo_loss(B, value_b, logp_b, ent_b, adv[idx], ret[idx], old_logp[idx], exps[idx],
-                                self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
-                                dvalue, dlogp, dent, self.grads[nflt:])
-                self.grads[:nflt].zero_()
-                engine.backward(packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
-                land_rows, road_rows = land_glob[k], road_glob[k]
-                if world > 1:
-                    self.dist.all_reduce_sum(self.grads)      # one collective per optimizer step
-                loss_log[step].copy_(self.grads[nflt:])
-                if self.clip_pending:
-                    engine.clip_first_step(self.grads, self.max_grad_norm, self.scratch)
-                    self.clip_pending = False
-                active = (True, land_rows > 0, road_rows > 0)
-                for g in range(3):
-                    if active[g]:
-                        self.group_steps[g] += 1
-                        engine.adam_step(g, self.flat, self.grads, self.m, self.v, self.group_steps[g], self.lr,
-                                         self.betas[0], self.betas[1], self.eps, self.weight_decay)
+                self.step(it, ep, k, loss_out=loss_log[step])
                 step += 1
             epoch_ranges.append((first, step))
         losses = loss_log[:step].cpu().numpy() if step > 0 else np.zeros((0, 4), dtype=np.float32)
-        engine.unflatten(self.flat, named)
+        self.detach()
         torch.cuda.synchronize(dev)
         t_end = time.time()
 
@@ -193,19 +227,19 @@ class PPOUpdater:
                     tb_logger.add_scalar(tag, float(losses[i, j]), self.loss_iter + i)
             totals = np.zeros(4)
             for e, (a, b) in enumerate(epoch_ranges):
-                ep = losses[a:b].astype(np.float64).sum(0) if b > a else np.zeros(4)
-                totals += ep
+                ep_sum = losses[a:b].astype(np.float64).sum(0) if b > a else np.zeros(4)
+                totals += ep_sum
                 ge = iteration * self.num_optim_epoch + e
                 for j, tag in enumerate(('loss/epoch_loss', 'loss/epoch_value_loss', 'loss/epoch_surr_loss',
                                          'loss/epoch_entropy_loss')):
-                    tb_logger.add_scalar(tag, float(ep[j]), ge)
+                    tb_logger.add_scalar(tag, float(ep_sum[j]), ge)
             for j, tag in enumerate(('loss/total_loss', 'loss/total_value_loss', 'loss/total_surr_loss',
                                      'loss/total_entropy_loss')):
                 tb_logger.add_scalar(tag, float(totals[j] / self.num_optim_epoch), iteration)
         self.loss_iter += step
         self.last_losses = losses
-        self.last_timing = dict(pack=t_pre - t_pack, prepass_gae=t_loop - t_pre, loop=t_end - t_loop,
-                                total=t_end - t0, steps=step, rows_per_step=B * world)
+        self.last_timing = dict(prepare=t_loop - t0, loop=t_end - t_loop, total=t_end - t0, steps=step,
+                                rows_per_step=self.mini_batch_size * self.dist.world)
         return t_end - t0
 
 

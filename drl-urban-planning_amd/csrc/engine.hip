@@ -179,10 +179,9 @@ extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **
 
 extern "C" int upamd_profile_reset(upamd_engine *eng) {
     if (!eng) return fail(UPAMD_E_INVALID, "null engine");
-    for (KernelStat *k : {&eng->prof.gemm_nt, &eng->prof.gemm_tn, &eng->prof.edge_fwd, &eng->prof.edge_bwd}) {
-        for (hipEvent_t e : k->ev) hipEventDestroy(e);
-        *k = KernelStat();
-    }
+    for (auto &kv : eng->prof.stats)
+        for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
+    eng->prof.stats.clear();
     return UPAMD_OK;
 }
 
@@ -201,12 +200,15 @@ extern "C" int upamd_profile_enable(upamd_engine *eng, int32_t on) {
 extern "C" int upamd_profile_read(upamd_engine *eng, const char *name, int64_t *launches, double *total_ms,
                                   double *total_flops, double *total_bytes) {
     if (!eng || !name) return fail(UPAMD_E_INVALID, "null argument");
-    KernelStat *k = nullptr;
-    if (!std::strcmp(name, "gemm_nt")) k = &eng->prof.gemm_nt;
-    else if (!std::strcmp(name, "gemm_tn")) k = &eng->prof.gemm_tn;
-    else if (!std::strcmp(name, "edge_fwd")) k = &eng->prof.edge_fwd;
-    else if (!std::strcmp(name, "edge_bwd")) k = &eng->prof.edge_bwd;
-    else return fail(UPAMD_E_INVALID, "unknown kernel name '%s'", name);
+    auto itk = eng->prof.stats.find(name);
+    if (itk == eng->prof.stats.end()) {
+        if (launches) *launches = 0;
+        if (total_ms) *total_ms = 0;
+        if (total_flops) *total_flops = 0;
+        if (total_bytes) *total_bytes = 0;
+        return UPAMD_OK;
+    }
+    KernelStat *k = &itk->second;
     double ms = 0;
     for (size_t i = 0; i + 1 < k->ev.size(); i += 2) {
         UPAMD_HIP(hipEventSynchronize(k->ev[i + 1]));

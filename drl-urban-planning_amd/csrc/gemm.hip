@@ -163,12 +163,12 @@ __global__ void gemm_nt_generic_kernel(const float *__restrict__ A, int64_t M, i
     C[o] = acc;
 }
 
-static int prof_begin(Profiler *prof, KernelStat Profiler::*which, hipStream_t st, double flops, double bytes) {
+int prof_begin(Profiler *prof, const char *name, hipStream_t st, double flops, double bytes) {
     if (!prof || !prof->on) return 0;
-    KernelStat &k = prof->*which;
+    KernelStat &k = prof->stats[name];
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
-    hipEventRecord(e0, st);
+    (void)hipEventRecord(e0, st);
     k.ev.push_back(e0);
     k.ev.push_back(e1);
     k.launches++;
@@ -176,8 +176,8 @@ static int prof_begin(Profiler *prof, KernelStat Profiler::*which, hipStream_t s
     k.bytes += bytes;
     return 1;
 }
-static void prof_end(Profiler *prof, KernelStat Profiler::*which, hipStream_t st, int began) {
-    if (began == 1) hipEventRecord((prof->*which).ev.back(), st);
+void prof_end(Profiler *prof, const char *name, hipStream_t st, int began) {
+    if (began == 1) (void)hipEventRecord(prof->stats[name].ev.back(), st);
 }
 
 int launch_gemm_nt(const float *A, int64_t M, int K, const float *W, int N, const float *bias, const float *R,
@@ -186,7 +186,8 @@ int launch_gemm_nt(const float *A, int64_t M, int K, const float *W, int N, cons
     if (K % 16 != 0 || N % 16 != 0) return fail(UPAMD_E_INVALID, "gemm_nt: K and N must be multiples of 16 (K=%d N=%d)", K, N);
     const double flops = 2.0 * (double)M * K * N;
     const double bytes = 4.0 * ((double)M * K + (double)M * N * (R ? 2 : 1) + (double)N * K);
-    int began = prof_begin(prof, &Profiler::gemm_nt, st, flops, bytes);
+    const char *pname = (N % 32 != 0) ? "gemm_nt_generic" : (N % 128 == 0 ? "gemm_nt_128" : (N % 64 == 0 ? "gemm_nt_64" : "gemm_nt_32"));
+    int began = prof_begin(prof, pname, st, flops, bytes);
     if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
     if (N % 32 == 0) {
         const int MT = (int)((M + 127) / 128);
@@ -205,7 +206,7 @@ int launch_gemm_nt(const float *A, int64_t M, int K, const float *W, int N, cons
         const int64_t total = M * N;
         hipLaunchKernelGGL(gemm_nt_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A, M, K, W, N, bias, R, C, act_tanh);
     }
-    prof_end(prof, &Profiler::gemm_nt, st, began);
+    prof_end(prof, pname, st, began);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }
@@ -374,7 +375,8 @@ int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, flo
     chunk = (chunk + 15) / 16 * 16;
     const double flops = 2.0 * (double)M * I * J;
     const double bytes = 4.0 * ((double)M * (I + J) + (double)S * I * J);
-    int began = prof_begin(prof, &Profiler::gemm_tn, st, flops, bytes);
+    const char *pname = !tn_use_mfma(I, J) ? "gemm_tn_generic" : (J % 128 == 0 ? "gemm_tn_128" : (J % 64 == 0 ? "gemm_tn_64" : "gemm_tn_32"));
+    int began = prof_begin(prof, pname, st, flops, bytes);
     if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
     if (tn_use_mfma(I, J)) {
         const int IT = I / 128;
@@ -391,7 +393,7 @@ int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, flo
     } else {
         hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((I * J + 255) / 256, S), dim3(256), 0, st, A, I, Bm, J, M, chunk, slabs);
     }
-    prof_end(prof, &Profiler::gemm_tn, st, began);
+    prof_end(prof, pname, st, began);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

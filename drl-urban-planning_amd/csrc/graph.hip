@@ -158,11 +158,7 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
         lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, false);
         if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_fwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof && prof->on) {
-        hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st);
-        prof->edge_fwd.ev.push_back(e0); prof->edge_fwd.ev.push_back(e1); prof->edge_fwd.launches++;
-    }
+    const int began = prof_begin(prof, "edge_fwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(256);
 #define UPAMD_EF(L_, S_)                                                                                              \
     do {                                                                                                              \
@@ -177,7 +173,7 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     else if (stage) UPAMD_EF(false, true);
     else UPAMD_EF(false, false);
 #undef UPAMD_EF
-    if (e1) hipEventRecord(e1, st);
+    prof_end(prof, "edge_fwd", st, began);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }
@@ -298,11 +294,7 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
         lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, false);
         if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_bwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof && prof->on) {
-        hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st);
-        prof->edge_bwd.ev.push_back(e0); prof->edge_bwd.ev.push_back(e1); prof->edge_bwd.launches++;
-    }
+    const int began = prof_begin(prof, "edge_bwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(256);
 #define UPAMD_EB(L_, S_)                                                                                              \
     do {                                                                                                              \
@@ -317,7 +309,7 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     else if (stage) UPAMD_EB(false, true);
     else UPAMD_EB(false, false);
 #undef UPAMD_EB
-    if (e1) hipEventRecord(e1, st);
+    prof_end(prof, "edge_bwd", st, began);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

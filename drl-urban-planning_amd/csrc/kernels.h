@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
+#include <string>
 
 #include "upamd_internal.h"
 
@@ -41,8 +43,11 @@ struct KernelStat {
 
 struct Profiler {
     bool on = false;
-    KernelStat gemm_nt, gemm_tn, edge_fwd, edge_bwd;
+    std::map<std::string, KernelStat> stats;   // keyed by kernel instance name ("gemm_nt_128", "edge_fwd", ...)
 };
+// HIP-event bracket around one launch on `st` (no-ops unless prof->on); returns 1 if recording
+int prof_begin(Profiler *prof, const char *name, hipStream_t st, double flops, double bytes);
+void prof_end(Profiler *prof, const char *name, hipStream_t st, int began);
 
 // ---- gemm.hip --------------------------------------------------------------------------
 // C[M,N](pm) = act( A[M,K](pm) * W[N,K]^T (row-major, ld = K) + bias[N] + R[M,N](pm) )

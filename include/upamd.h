@@ -201,7 +201,8 @@ int upamd_adam_step(int64_t begin, int64_t end, float *params_dev, const float *
  * Per-kernel timing of the dominant kernels (HIP events on the launch stream), for bench.py.
  * ------------------------------------------------------------------------------------------ */
 int upamd_profile_enable(upamd_engine *eng, int32_t on);
-/* name: "gemm_nt" | "gemm_tn" | "edge_fwd" | "edge_bwd".  Synchronises the recorded events. */
+/* name: kernel instance, e.g. "gemm_nt_128" | "gemm_nt_32" | "gemm_tn_128" | "gemm_tn_32" | "edge_fwd" | "edge_bwd"
+ * (zero launches if that instance never ran).  Synchronises the recorded events. */
 int upamd_profile_read(upamd_engine *eng, const char *name, int64_t *launches, double *total_ms,
                        double *total_flops, double *total_bytes);
 int upamd_profile_reset(upamd_engine *eng);
