@@ -110,6 +110,7 @@ PackedView make_view(const void *packed_dev, const upamd_pack_layout &L) {
     v.he_dst = reinterpret_cast<const uint16_t *>(b + L.off_he_dst);
     v.he_live = reinterpret_cast<const uint8_t *>(b + L.off_he_live);
     v.rn_node = reinterpret_cast<const uint16_t *>(b + L.off_rn_node);
+    v.order = reinterpret_cast<const uint16_t *>(b + L.off_order);
     v.numerical = reinterpret_cast<const float *>(b + L.off_numerical);
     v.cur = reinterpret_cast<const float *>(b + L.off_cur);
     v.Fn = L.numerical_dim;

@@ -1,15 +1,5 @@
-// Ragged-graph kernels (gfx950, wave64): message passing, single-query attention, pointer heads.
-//
-// One workgroup handles one (graph, 16-column panel): the graph's P/Q projections for those 16
-// columns are a contiguous n*64 B run in the panel-major layout and are staged into LDS once
-// (coalesced 16 B loads); every neighbour gather then hits LDS.  A wave processes one node at a
-// time: lanes = 16 columns x 4 neighbour slots, the 4 partial sums are combined with two
-// __shfl_xor steps -- CSR-by-destination segment sums in a fixed order, no atomics, so results
-// are run-to-run deterministic.
-//
-// Reference math (urban_planning/models/state_encoder.py:110-148,194-197): for a live edge (i,j)
-//   m_ij = 1/2 [ tanh(W [h_i;h_j] + b) + tanh(W [h_j;h_i] + b) ],  h_v += sum_{e touches v} m_e / (deg_v + 1e-6)
-// with W [h_i;h_j] = P_i + Q_j where P = H Wa^T, Q = H Wb^T (W = [Wa | Wb]) come from the node GEMM.
+// Ragged-graph kernels (gfx950, wave64): minibatch input gather, single-query attention, pointer
+// heads (candidate features, masked softmax).  The message-passing kernels live in edge.hip.
 #include "kernels.h"
 
 namespace upamd {
@@ -20,6 +10,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 #define META(t) (pk.meta + (int64_t)(t) * UPAMD_META_STRIDE)
+
+constexpr int64_t LDS_LIMIT = 160 * 1024;
 
 // ------------------------------------------------------------------------------------------
 // inputs of a minibatch: node features -> panel-major (K padded to 32), numerical + current node
@@ -45,271 +37,6 @@ __global__ __launch_bounds__(256) void gather_inputs_kernel(PackedView pk, MbVie
 
 int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st) {
     hipLaunchKernelGGL(gather_inputs_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, Xp, U0, curg);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// GCN layer forward: H_out = H_in + S / (deg + 1e-6);  last layer also emits the masked node mean
-// and the edge mean (= 1/2 sum_v S_v / e, each message is counted at both endpoints).
-// ------------------------------------------------------------------------------------------
-constexpr int64_t LDS_LIMIT = 160 * 1024;
-
-int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage) {
-    int64_t b = 0;
-    if (stage) b += (int64_t)max_n * 64 * (bwd ? 3 : 2);      // P, Q (, dS) slices
-    b += ((int64_t)max_n + 1) * 4;                            // row_ptr
-    b += (int64_t)max_inc * 2 * ((bwd && last) ? 2 : 1);      // neighbour ids (, head-edge ids)
-    b = (b + 15) / 16 * 16;
-    b += 4 * 2 * 16 * 4;                                      // cross-wave reduction scratch
-    return b;
-}
-
-template <bool LAST, bool STAGE>
-__global__ __launch_bounds__(256) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
-                                                       const float *__restrict__ PQ, const float *__restrict__ bias,
-                                                       const float *__restrict__ Hin, float *__restrict__ Hout,
-                                                       float *__restrict__ hbarV, float *__restrict__ hbarE) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x / NP, p = blockIdx.x % NP;
-    const int t = mb.idx[b];
-    const int32_t *m = META(t);
-    const int n = m[0], e = m[1];
-    const int64_t o = mb.node_off[b], M = mb.M;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int c = lane & 15, g = lane >> 4;
-
-    unsigned char *sp = smem;
-    float *Pl = nullptr, *Ql = nullptr;
-    if (STAGE) {
-        Pl = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
-        Ql = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
-    }
-    int *rp = reinterpret_cast<int *>(sp); sp += ((int64_t)n + 1) * 4;
-    uint16_t *nb = reinterpret_cast<uint16_t *>(sp); sp += (int64_t)e * 4;
-    float *red = reinterpret_cast<float *>(smem + (((sp - smem) + 15) / 16 * 16));
-
-    const float *Pg = PQ + ((int64_t)(2 * p) * M + o) * 16;
-    const float *Qg = PQ + ((int64_t)(2 * p + 1) * M + o) * 16;
-    if (STAGE) {
-        const float4 *s4 = reinterpret_cast<const float4 *>(Pg);
-        const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
-        for (int i = tid; i < n * 4; i += 256) {
-            reinterpret_cast<float4 *>(Pl)[i] = s4[i];
-            reinterpret_cast<float4 *>(Ql)[i] = q4[i];
-        }
-    }
-    const int32_t *rpg = pk.rowptr + m[13];
-    for (int i = tid; i <= n; i += 256) rp[i] = rpg[i];
-    const uint32_t *nbg = reinterpret_cast<const uint32_t *>(pk.inc_nbr + 2 * (int64_t)m[10]);
-    for (int i = tid; i < e; i += 256) reinterpret_cast<uint32_t *>(nb)[i] = nbg[i];
-    __syncthreads();
-
-    const float *Ps = STAGE ? Pl : Pg;
-    const float *Qs = STAGE ? Ql : Qg;
-    const float bc = bias[p * 16 + c];
-    const uint8_t *nmask = pk.nmask + m[9];
-    float sumS = 0.f, sumH = 0.f;
-    for (int v = w; v < n; v += 4) {
-        const float pv = Ps[v * 16 + c] + bc, qv = Qs[v * 16 + c] + bc;
-        const int k0 = rp[v], k1 = rp[v + 1];
-        float acc = 0.f;
-        for (int k = k0 + g; k < k1; k += 4) {
-            const int u = nb[k];
-            const float pu = Ps[u * 16 + c], qu = Qs[u * 16 + c];
-            acc += fast_tanh(pv + qu) + fast_tanh(pu + qv);
-        }
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        const float S = 0.5f * acc;
-        const float a = S / ((float)(k1 - k0) + 1e-6f);
-        const int64_t go = ((int64_t)p * M + o + v) * 16 + c;
-        const float h = Hin[go] + a;
-        if (g == 0) Hout[go] = h;
-        if (LAST) {
-            sumS += S;
-            if (nmask[v]) sumH += h;
-        }
-    }
-    if (LAST) {
-        if (g == 0) {
-            red[(w * 2 + 0) * 16 + c] = sumS;
-            red[(w * 2 + 1) * 16 + c] = sumH;
-        }
-        __syncthreads();
-        if (tid < 32) {
-            const int which = tid >> 4, cc = tid & 15;
-            const float tot = red[(0 * 2 + which) * 16 + cc] + red[(1 * 2 + which) * 16 + cc] +
-                              red[(2 * 2 + which) * 16 + cc] + red[(3 * 2 + which) * 16 + cc];
-            const int D = NP * 16;
-            if (which == 0) hbarE[(int64_t)b * D + p * 16 + cc] = 0.5f * tot / (float)e;
-            else hbarV[(int64_t)b * D + p * 16 + cc] = tot / (float)m[6];
-        }
-    }
-}
-
-int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
-                    const float *Hin, float *Hout, float *hbarV, float *hbarE, hipStream_t st, Profiler *prof) {
-    const int NP = D / 16;
-    bool stage = true;
-    int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, true);
-    if (lds > LDS_LIMIT) {
-        stage = false;
-        lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, false);
-        if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_fwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
-    }
-    const int began = prof_begin(prof, "edge_fwd", st, 0.0, 0.0);
-    dim3 grid((unsigned)(mb.B * NP)), block(256);
-#define UPAMD_EF(L_, S_)                                                                                              \
-    do {                                                                                                              \
-        if (lds > 64 * 1024)                                                                                          \
-            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_>),                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-        hipLaunchKernelGGL((edge_fwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, Hout,  \
-                           hbarV, hbarE);                                                                             \
-    } while (0)
-    if (last && stage) UPAMD_EF(true, true);
-    else if (last) UPAMD_EF(true, false);
-    else if (stage) UPAMD_EF(false, true);
-    else UPAMD_EF(false, false);
-#undef UPAMD_EF
-    prof_end(prof, "edge_fwd", st, began);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// GCN layer backward w.r.t. P and Q (node-centric, recomputes the tanh's):
-//   dS_v = G_v / (deg_v + 1e-6) (+ 1/2 dhbarE / e on the last layer)
-//   dm_(v,u) = dS_v + dS_u (+ pointer-head gradient of that edge on the last layer)
-//   dP_v = sum_u 1/2 dm (1 - tanh^2(P_v + Q_u + b)),  dQ_v = sum_u 1/2 dm (1 - tanh^2(P_u + Q_v + b))
-// ------------------------------------------------------------------------------------------
-template <bool LAST, bool STAGE>
-__global__ __launch_bounds__(256) void edge_bwd_kernel(PackedView pk, MbView mb, int NP,
-                                                       const float *__restrict__ PQ, const float *__restrict__ bias,
-                                                       const float *__restrict__ G, const float *__restrict__ dhbarE,
-                                                       int ld_dhbarE, const float *__restrict__ dMhe,
-                                                       float *__restrict__ dPQ, float *__restrict__ dbias_part) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x / NP, p = blockIdx.x % NP;
-    const int t = mb.idx[b];
-    const int32_t *m = META(t);
-    const int n = m[0], e = m[1];
-    const int64_t o = mb.node_off[b], M = mb.M;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int c = lane & 15, g = lane >> 4;
-
-    unsigned char *sp = smem;
-    float *Pl = nullptr, *Ql = nullptr, *Sl = nullptr;
-    if (STAGE) {
-        Pl = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
-        Ql = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
-        Sl = reinterpret_cast<float *>(sp); sp += (int64_t)n * 64;
-    }
-    int *rp = reinterpret_cast<int *>(sp); sp += ((int64_t)n + 1) * 4;
-    uint16_t *nb = reinterpret_cast<uint16_t *>(sp); sp += (int64_t)e * 4;
-    uint16_t *he = nullptr;
-    if (LAST) { he = reinterpret_cast<uint16_t *>(sp); sp += (int64_t)e * 4; }
-    float *red = reinterpret_cast<float *>(smem + (((sp - smem) + 15) / 16 * 16));
-
-    const float *Pg = PQ + ((int64_t)(2 * p) * M + o) * 16;
-    const float *Qg = PQ + ((int64_t)(2 * p + 1) * M + o) * 16;
-    const float *Gg = G + ((int64_t)p * M + o) * 16;
-    if (STAGE) {
-        const float4 *s4 = reinterpret_cast<const float4 *>(Pg);
-        const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
-        for (int i = tid; i < n * 4; i += 256) {
-            reinterpret_cast<float4 *>(Pl)[i] = s4[i];
-            reinterpret_cast<float4 *>(Ql)[i] = q4[i];
-        }
-    }
-    const int32_t *rpg = pk.rowptr + m[13];
-    for (int i = tid; i <= n; i += 256) rp[i] = rpg[i];
-    const uint32_t *nbg = reinterpret_cast<const uint32_t *>(pk.inc_nbr + 2 * (int64_t)m[10]);
-    for (int i = tid; i < e; i += 256) reinterpret_cast<uint32_t *>(nb)[i] = nbg[i];
-    if (LAST) {
-        const uint32_t *heg = reinterpret_cast<const uint32_t *>(pk.inc_he + 2 * (int64_t)m[10]);
-        for (int i = tid; i < e; i += 256) reinterpret_cast<uint32_t *>(he)[i] = heg[i];
-    }
-    __syncthreads();
-    float extra = 0.f;     // same for every node of the graph, depends on the lane's column
-    if (LAST) extra = 0.5f * dhbarE[(int64_t)b * ld_dhbarE + p * 16 + c] / (float)e;
-    if (STAGE) {
-        for (int i = tid; i < n * 16; i += 256) {
-            const int v = i >> 4, cc = i & 15;
-            float ex = 0.f;
-            if (LAST) ex = 0.5f * dhbarE[(int64_t)b * ld_dhbarE + p * 16 + cc] / (float)e;
-            Sl[i] = Gg[i] / ((float)(rp[v + 1] - rp[v]) + 1e-6f) + ex;
-        }
-        __syncthreads();
-    }
-    const float *Ps = STAGE ? Pl : Pg;
-    const float *Qs = STAGE ? Ql : Qg;
-    const float bc = bias[p * 16 + c];
-    const int64_t he0 = LAST ? (int64_t)mb.he_off[b] : 0;
-    float sumdP = 0.f;
-    for (int v = w; v < n; v += 4) {
-        const float pv = Ps[v * 16 + c] + bc, qv = Qs[v * 16 + c] + bc;
-        const int k0 = rp[v], k1 = rp[v + 1];
-        const float sv = STAGE ? Sl[v * 16 + c] : (Gg[v * 16 + c] / ((float)(k1 - k0) + 1e-6f) + extra);
-        float accP = 0.f, accQ = 0.f;
-        for (int k = k0 + g; k < k1; k += 4) {
-            const int u = nb[k];
-            const float pu = Ps[u * 16 + c], qu = Qs[u * 16 + c];
-            const float su = STAGE ? Sl[u * 16 + c]
-                                   : (Gg[u * 16 + c] / ((float)(rp[u + 1] - rp[u]) + 1e-6f) + extra);
-            float dm = sv + su;
-            if (LAST) {
-                const int h = he[k];
-                if (h != 0xFFFF) dm += dMhe[((int64_t)p * mb.Nhe + he0 + h) * 16 + c];
-            }
-            const float t1 = fast_tanh(pv + qu), t2 = fast_tanh(pu + qv);
-            accP = fmaf(dm, 1.f - t1 * t1, accP);
-            accQ = fmaf(dm, 1.f - t2 * t2, accQ);
-        }
-        accP += __shfl_xor(accP, 16);
-        accP += __shfl_xor(accP, 32);
-        accQ += __shfl_xor(accQ, 16);
-        accQ += __shfl_xor(accQ, 32);
-        const float dP = 0.5f * accP, dQ = 0.5f * accQ;
-        if (g == 0) {
-            dPQ[((int64_t)(2 * p) * M + o + v) * 16 + c] = dP;
-            dPQ[((int64_t)(2 * p + 1) * M + o + v) * 16 + c] = dQ;
-        }
-        sumdP += dP;
-    }
-    if (g == 0) red[w * 16 + c] = sumdP;
-    __syncthreads();
-    if (tid < 16) dbias_part[(int64_t)b * (NP * 16) + p * 16 + tid] = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
-}
-
-int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
-                    const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
-                    float *dbias_part, hipStream_t st, Profiler *prof) {
-    const int NP = D / 16;
-    bool stage = true;
-    int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, true);
-    if (lds > LDS_LIMIT) {
-        stage = false;
-        lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, false);
-        if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_bwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
-    }
-    const int began = prof_begin(prof, "edge_bwd", st, 0.0, 0.0);
-    dim3 grid((unsigned)(mb.B * NP)), block(256);
-#define UPAMD_EB(L_, S_)                                                                                              \
-    do {                                                                                                              \
-        if (lds > 64 * 1024)                                                                                          \
-            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_>),                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-        hipLaunchKernelGGL((edge_bwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G, dhbarE,  \
-                           ld_dhbarE, dMhe, dPQ, dbias_part);                                                         \
-    } while (0)
-    if (last && stage) UPAMD_EB(true, true);
-    else if (last) UPAMD_EB(true, false);
-    else if (stage) UPAMD_EB(false, true);
-    else UPAMD_EB(false, false);
-#undef UPAMD_EB
-    prof_end(prof, "edge_bwd", st, began);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

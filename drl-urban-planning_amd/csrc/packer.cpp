@@ -174,6 +174,7 @@ extern "C" int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *p
     L.off_rn_node = place(rn * 2);
     L.off_numerical = place(T * (int64_t)numerical_dim * 4);
     L.off_cur = place(T * UPAMD_NODE_PAD * 4);
+    L.off_order = place(nodes * 2);
     L.total_bytes = off;
     *layout = L;
     return UPAMD_OK;
@@ -198,6 +199,7 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
     uint16_t *rn_node = reinterpret_cast<uint16_t *>(base + L.off_rn_node);
     float *numerical = reinterpret_cast<float *>(base + L.off_numerical);
     float *cur = reinterpret_cast<float *>(base + L.off_cur);
+    uint16_t *order = reinterpret_cast<uint16_t *>(base + L.off_order);
     const int F = L.node_dim, Fn = L.numerical_dim;
 
     int rc = parallel_for(T, n_threads, [&](int64_t t) -> int {
@@ -255,6 +257,16 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
                 nb[fill[i]] = (uint16_t)j; ih[fill[i]] = h; fill[i]++;
                 nb[fill[j]] = (uint16_t)i; ih[fill[j]] = h; fill[j]++;
             }
+        // processing order of the edge kernels: nodes by degree, descending (stable), so that the four
+        // nodes a wave handles together have similar neighbour counts
+        {
+            std::vector<uint16_t> ord(n);
+            for (int v = 0; v < n; ++v) ord[v] = (uint16_t)v;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint16_t a, uint16_t b) {
+                return (rp[a + 1] - rp[a]) > (rp[b + 1] - rp[b]);
+            });
+            std::memcpy(order + o_node, ord.data(), sizeof(uint16_t) * n);
+        }
         // per-state dense fields
         std::memcpy(numerical + t * Fn, s.numerical, sizeof(float) * Fn);
         float *cdst = cur + t * UPAMD_NODE_PAD;

@@ -107,6 +107,8 @@ typedef struct upamd_pack_layout {
     int64_t off_rn_node;   /* u16   [total_rn]          candidate node (== padded slot)          */
     int64_t off_numerical; /* f32   [T][numerical_dim]                                           */
     int64_t off_cur;       /* f32   [T][UPAMD_NODE_PAD]                                          */
+    int64_t off_order;     /* u16   [total_nodes]       per graph: node ids sorted by degree (descending,
+                                                         stable) -- the processing order of the edge kernels */
     int64_t total_bytes;
 } upamd_pack_layout;
 

@@ -67,6 +67,7 @@ def pack_state(state, action):
         inc_he[fill[j]] = h
         fill[j] += 1
     rn_node = np.flatnonzero(road_mask) if stage_id == 1 else np.zeros(0, dtype=np.int64)
+    order = np.argsort(-cnt, kind='stable')          # edge-kernel processing order: degree descending, stable
     act = -1
     if stage_id == 0:
         a = int(action[0])
@@ -78,7 +79,7 @@ def pack_state(state, action):
         act = int(pos[0]) if pos.size else -1
     return dict(n=n, e=e, stage=stage_id, X=feat[:n].astype(np.float64), nmask=node_mask[:n].copy(),
                 row_ptr=row_ptr, inc_nbr=inc_nbr, inc_he=inc_he, he_src=he_src, he_dst=he_dst, he_live=he_live,
-                he_slot=he_slot, rn_node=rn_node, act=act, numerical=numerical.astype(np.float64).ravel(),
+                he_slot=he_slot, rn_node=rn_node, act=act, order=order, numerical=numerical.astype(np.float64).ravel(),
                 cur=cur.astype(np.float64), stage_vec=stage.astype(np.float64), pad_n=feat.shape[0],
                 pad_e=edge_index.shape[0], n_mask=int(node_mask.sum()))
 

@@ -22,6 +22,7 @@ def _check(replay):
     he_live = pk.section('he_live', np.uint8, L.total_he)
     he_slot = pk.section('he_slot', np.int32, L.total_he)
     rn_node = pk.section('rn_node', np.uint16, L.total_rn)
+    order = pk.section('order', np.uint16, L.total_nodes)
     numerical = pk.section('numerical', np.float32, T * synth.NUMERICAL_DIM).reshape(T, -1)
     cur = pk.section('cur', np.float32, T * native.NODE_PAD).reshape(T, -1)
     meta_dev = pk.section('meta', np.int32, T * native.META_STRIDE).reshape(T, -1)
@@ -46,6 +47,7 @@ def _check(replay):
         np.testing.assert_array_equal(he_live[ho:ho + m[2]], g['he_live'])
         np.testing.assert_array_equal(he_slot[ho:ho + m[2]], g['he_slot'])
         np.testing.assert_array_equal(rn_node[ro:ro + m[3]], g['rn_node'])
+        np.testing.assert_array_equal(order[no:no + n], g['order'])
         np.testing.assert_array_equal(numerical[t], replay.states[t][0])
         np.testing.assert_array_equal(cur[t, :synth.NODE_DIM], replay.states[t][3])
     return pk
