@@ -60,3 +60,27 @@ extern "C" int upamd_adam_step(int64_t begin, int64_t end, float *params_dev, co
     return launch_adam(end - begin, params_dev + begin, grads_dev + begin, m_dev + begin, v_dev + begin, step, lr, beta1,
                        beta2, eps, weight_decay, static_cast<hipStream_t>(stream));
 }
+
+extern "C" int upamd_gemm_nt(const float *A_dev, int64_t M, int32_t K, int64_t lda, int32_t a_row_major, const float *W_dev,
+                             int32_t N, int64_t ldw, const float *bias_dev, const float *R_dev, float *C_dev, int64_t ldc,
+                             int32_t c_row_major, int32_t act_tanh, float alpha, void *stream) {
+    if (!A_dev || !W_dev || !C_dev || M <= 0 || K <= 0 || N <= 0) return fail(UPAMD_E_INVALID, "upamd_gemm_nt: bad argument");
+    GemmNT g{A_dev, M, K, lda, a_row_major != 0, W_dev, N, ldw, bias_dev, R_dev, C_dev, ldc, c_row_major != 0, act_tanh, alpha};
+    return launch_gemm_nt_ex(g, static_cast<hipStream_t>(stream), nullptr);
+}
+
+extern "C" int64_t upamd_gemm_tn_scratch_floats(int32_t I, int32_t J, int64_t M) {
+    return (int64_t)tn_splits(I, J, M) * I * J;
+}
+
+extern "C" int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev, int32_t J, int64_t ldb, int64_t M,
+                             int32_t row_major, float *scratch_dev, float *out_dev, void *stream) {
+    if (!A_dev || !B_dev || !scratch_dev || !out_dev || I <= 0 || J <= 0) return fail(UPAMD_E_INVALID, "upamd_gemm_tn: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GemmTN g{A_dev, I, lda, B_dev, J, ldb, M, row_major != 0, scratch_dev};
+    int S = 1;
+    int rc = launch_gemm_tn_ex(g, &S, st, nullptr);
+    if (rc) return rc;
+    UPAMD_HIP(hipMemsetAsync(out_dev, 0, sizeof(float) * (size_t)I * J, st));
+    return launch_reduce_slabs(scratch_dev, S, I, J, 0, J, out_dev, J, st);
+}

@@ -78,22 +78,28 @@ int launch_smm(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, co
     return 0;
 }
 
-// dst[j] += sum_i X[i*ld + j]; one thread per column block-strided over rows, fixed order
-__global__ __launch_bounds__(256) void colsum_rm_kernel(const float *__restrict__ X, int rows, int cols, int64_t ld,
-                                                        float *__restrict__ dst) {
-    __shared__ float part[4][64];
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rg = threadIdx.x >> 6;
+// dst[j] += sum_i X[i*ld + j].  One 1024-thread workgroup per 16 columns: 64 row groups x 16 columns,
+// every thread sums a strided subset of the rows, then the 64 partials are added in a fixed order.
+__global__ __launch_bounds__(1024) void colsum_rm_kernel(const float *__restrict__ X, int rows, int cols, int64_t ld,
+                                                         float *__restrict__ dst) {
+    __shared__ float part[64][17];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + c;
     float acc = 0.f;
     if (j < cols)
-        for (int i = rg; i < rows; i += 4) acc += X[i * ld + j];
-    part[rg][threadIdx.x & 63] = acc;
+        for (int i = rg; i < rows; i += 64) acc += X[i * ld + j];
+    part[rg][c] = acc;
     __syncthreads();
-    if (threadIdx.x < 64 && j < cols) dst[j] += part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (threadIdx.x < 16 && j < cols) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) tot += part[q][threadIdx.x];
+        dst[j] += tot;
+    }
 }
 int launch_colsum_rm(const float *X, int rows, int cols, int64_t ld, float *dst, hipStream_t st) {
     if (rows <= 0 || cols <= 0) return 0;
-    hipLaunchKernelGGL(colsum_rm_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, X, rows, cols, ld, dst);
+    hipLaunchKernelGGL(colsum_rm_kernel, dim3((cols + 15) / 16), dim3(1024), 0, st, X, rows, cols, ld, dst);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }
@@ -123,18 +129,8 @@ __global__ __launch_bounds__(256) void colsum_pm_kernel(const float *__restrict_
         part[(int64_t)blk * cols + p * 16 + threadIdx.x] = tot;
     }
 }
-__global__ void reduce_rows_add_kernel(const float *__restrict__ part, int nrows, int cols, float *__restrict__ dst) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
-    float acc = 0.f;
-    for (int i = 0; i < nrows; ++i) acc += part[(int64_t)i * cols + j];
-    dst[j] += acc;
-}
 int launch_reduce_rows_add(const float *part, int nrows, int cols, float *dst, hipStream_t st) {
-    if (nrows <= 0 || cols <= 0) return 0;
-    hipLaunchKernelGGL(reduce_rows_add_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, part, nrows, cols, dst);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
+    return launch_colsum_rm(part, nrows, cols, cols, dst, st);
 }
 int launch_colsum_pm(const float *X, int64_t rows, int cols, const float *w, float *part, float *dst, hipStream_t st) {
     if (rows <= 0 || cols <= 0) return 0;

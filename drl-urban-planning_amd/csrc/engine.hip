@@ -41,12 +41,13 @@ Dims dims_of(const upamd_model_desc &d) {
     return x;
 }
 
-int64_t slab_floats(const Dims &x, int64_t M, int64_t Nhe, int64_t Nrn) {
+int64_t slab_floats(const Dims &x, int64_t B, int64_t M, int64_t Nhe, int64_t Nrn) {
     int64_t s = 0;
     s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, x.D, M) * 2 * x.D * x.D);          // GCN weight grads
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, 32, M) * x.D * 32);                    // node encoder
     s = std::max<int64_t>(s, (int64_t)tn_splits(4 * x.D, x.h0l, Nhe) * 4 * x.D * x.h0l);    // land head
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.h0r, Nrn) * x.D * x.h0r);            // road head
+    s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.D, B) * x.D * x.D);                  // per-sample D x D layers
     return s;
 }
 
@@ -68,6 +69,7 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     }
     add("Wkk", (int64_t)D * D); add("Wvv", (int64_t)D * D); add("bvv", D);
     add("W1T", 4LL * D * x.h0l); add("R1T", (int64_t)D * x.h0r);
+    add("wt", (int64_t)x.maxdim * x.maxdim);          // transposed-weight scratch of the per-sample layers
     add("Xp", 2 * M * 16);
     add("U0", B * x.Fn);
     for (int i = 0; i < d.n_num; ++i) add("U" + std::to_string(i + 1), B * d.num_hidden[i]);
@@ -85,13 +87,14 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     add("lse", B); add("entk", B);
     // backward temporaries
     add("dzA", B * x.maxdim); add("dzB", B * x.maxdim); add("dnA", B * x.maxdim); add("dnB", B * x.maxdim);
+    add("datt", B * D);
     add("do", B * D); add("ds", B * x.heads * D); add("dr", B * x.heads * D);
     add("dq1", B * D); add("dq0", B * D); add("dC", B * D); add("dC_head", B * D);
     add("dWkk", (int64_t)D * D); add("dWvv", (int64_t)D * D); add("dbvv", D);
     add("dz_he", NH); add("dz_rn", NR); add("dprel", NH * x.h0l); add("dFE", NH * 4 * D); add("dMhe", NH * D);
     add("dprer", NR * x.h0r); add("dXR", NR * D);
     add("G0", M * D); add("G1", M * D); add("dPQ", M * 2 * D); add("dbias_part", B * D);
-    add("slabs", slab_floats(x, M, NH, NR));
+    add("slabs", slab_floats(x, B, M, NH, NR));
     const int64_t maxrows = std::max(M, std::max(NH, NR));
     add("cs_part", (int64_t)colsum_pm_blocks(maxrows) * std::max(4 * D, 64));
     pl->total = off;
@@ -144,23 +147,45 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
         if (_rc) return _rc; \
     } while (0)
 
-// Y[R,N] = act(X[R,K] W[N,K]^T + b)
-int lin_fwd(const float *X, int64_t ldx, int R, int K, const float *W, const float *b, int N, float *Y, int64_t ldy,
-            int act, float scale, hipStream_t st) {
-    return launch_smm(R, N, K, X, ldx, 1, W, 1, K, b, Y, ldy, 0, act, scale, st);
-}
-// dX[R,K] = dY[R,N] W[N,K]
-int lin_dx(const float *dY, int64_t ldy, int R, int N, const float *W, int K, float *dX, int64_t ldx, int accumulate,
-           hipStream_t st) {
-    return launch_smm(R, K, N, dY, ldy, 1, W, K, 1, nullptr, dX, ldx, accumulate, 0, 1.f, st);
-}
-// dW[N,K] += dY[R,N]^T X[R,K];  db[N] += colsum(dY)
-int lin_dw(const float *dY, int64_t ldy, int R, int N, const float *X, int64_t ldx, int K, float *dW, float *db,
-           hipStream_t st) {
-    CK(launch_smm(N, K, R, dY, 1, ldy, X, ldx, 1, nullptr, dW, K, 1, 0, 1.f, st));
-    if (db) CK(launch_colsum_rm(dY, R, N, ldy, db, st));
-    return 0;
-}
+// Row-major [rows, .] linear algebra of the per-sample layers.  Large, well-shaped products go to the MFMA
+// kernels (row-major operand variants); everything else to the generic strided kernel.
+struct Lin {
+    hipStream_t st;
+    Profiler *prof;
+    float *slabs;      // split-K scratch
+    float *wt;         // transposed-weight scratch
+    static constexpr int MIN_ROWS = 256;
+
+    // Y[R,N] = scale * act(X[R,K] W[N,K]^T + b)
+    int nt(const float *X, int64_t ldx, int R, int K, const float *W, int64_t ldw, const float *b, int N, float *Y,
+           int64_t ldy, int act, float scale) const {
+        GemmNT g{X, R, K, ldx, true, W, N, ldw, b, nullptr, Y, ldy, true, act, scale};
+        if (R >= MIN_ROWS && gemm_nt_mfma_ok(g)) return launch_gemm_nt_ex(g, st, prof);
+        return launch_smm(R, N, K, X, ldx, 1, W, 1, ldw, b, Y, ldy, 0, act, scale, st);
+    }
+    // Y[R,N] = X[R,K] Wm[K,N]   (Wm row-major dense, ld = N)
+    int nn(const float *X, int64_t ldx, int R, int K, const float *Wm, int N, float *Y, int64_t ldy) const {
+        GemmNT g{X, R, K, ldx, true, wt, N, K, nullptr, nullptr, Y, ldy, true, 0, 1.f};
+        if (R >= MIN_ROWS && gemm_nt_mfma_ok(g)) {
+            CK(launch_transpose(Wm, K, N, wt, st));
+            return launch_gemm_nt_ex(g, st, prof);
+        }
+        return launch_smm(R, N, K, X, ldx, 1, Wm, N, 1, nullptr, Y, ldy, 0, 0, 1.f, st);
+    }
+    // dW[N,K] += dY[R,N]^T X[R,K];  db[N] += colsum(dY)
+    int tn_acc(const float *dY, int64_t ldy, int R, int N, const float *X, int64_t ldx, int K, float *dW, float *db) const {
+        GemmTN g{dY, N, ldy, X, K, ldx, R, true, slabs};
+        if (R >= MIN_ROWS && gemm_tn_mfma_ok(g)) {
+            int S = 1;
+            CK(launch_gemm_tn_ex(g, &S, st, prof));
+            CK(launch_reduce_slabs(slabs, S, N, K, 0, K, dW, K, st));
+        } else {
+            CK(launch_smm(N, K, R, dY, 1, ldy, X, ldx, 1, nullptr, dW, K, 1, 0, 1.f, st));
+        }
+        if (db) CK(launch_colsum_rm(dY, R, N, ldy, db, st));
+        return 0;
+    }
+};
 
 }  // namespace
 
@@ -201,14 +226,12 @@ extern "C" int upamd_profile_enable(upamd_engine *eng, int32_t on) {
 extern "C" int upamd_profile_read(upamd_engine *eng, const char *name, int64_t *launches, double *total_ms,
                                   double *total_flops, double *total_bytes) {
     if (!eng || !name) return fail(UPAMD_E_INVALID, "null argument");
+    if (launches) *launches = 0;
+    if (total_ms) *total_ms = 0;
+    if (total_flops) *total_flops = 0;
+    if (total_bytes) *total_bytes = 0;
     auto itk = eng->prof.stats.find(name);
-    if (itk == eng->prof.stats.end()) {
-        if (launches) *launches = 0;
-        if (total_ms) *total_ms = 0;
-        if (total_flops) *total_flops = 0;
-        if (total_bytes) *total_bytes = 0;
-        return UPAMD_OK;
-    }
+    if (itk == eng->prof.stats.end()) return UPAMD_OK;
     KernelStat *k = &itk->second;
     double ms = 0;
     for (size_t i = 0; i + 1 < k->ev.size(); i += 2) {
@@ -259,7 +282,7 @@ extern "C" int upamd_ws_tensor(upamd_engine *eng, const upamd_minibatch *mb, con
     else if (n == "alpha") { r = x.heads; c = M; }
     else if (n == "SV") { r = B; c = x.W; }
     else if (n == "r" || n == "s" || n == "ds" || n == "dr") { r = B; c = (int64_t)x.heads * x.D; }
-    else if (n == "lse") { r = B; c = 1; }
+    else if (n == "lse" || n == "entk") { r = B; c = 1; }
     else if (n == "U0") { r = B; c = x.Fn; }
     else if (n == "curg") { r = B; c = UPAMD_NODE_PAD; }
     else if (n == "Wkk" || n == "Wvv" || n == "dWkk" || n == "dWvv") { r = x.D; c = x.D; }
@@ -293,6 +316,7 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     auto W = [&](const std::string &n) { return ws + pl.off.at(n); };
     auto PR = [&](int idx) { return prm + P.off(idx); };
     Profiler *prof = &eng->prof;
+    const Lin lin{st, prof, W("slabs"), W("wt")};
 
     // -- per-step weight preparation (tiny)
     CK(launch_pad_cols(PR(P.node_w), D, x.F, 32, W("We_pad"), st));
@@ -302,8 +326,8 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
     const float *biq = bin, *biv = bin + 2 * D;
     // Wkk = Wik Wk, Wvv = Wiv Wv, bvv = Wiv bv + biv
-    CK(launch_smm(D, D, D, Wik, D, 1, PR(P.k_w), D, 1, nullptr, W("Wkk"), D, 0, 0, 1.f, st));
-    CK(launch_smm(D, D, D, Wiv, D, 1, PR(P.v_w), D, 1, nullptr, W("Wvv"), D, 0, 0, 1.f, st));
+    CK(lin.nn(Wik, D, D, D, PR(P.k_w), D, W("Wkk"), D));
+    CK(lin.nn(Wiv, D, D, D, PR(P.v_w), D, W("Wvv"), D));
     CK(launch_smm(1, D, D, PR(P.v_b), D, 1, Wiv, 1, D, biv, W("bvv"), D, 0, 0, 1.f, st));
 
     // -- inputs
@@ -312,8 +336,8 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     {
         int prev = x.Fn;
         for (int i = 0; i < d.n_num; ++i) {
-            CK(lin_fwd(W("U" + std::to_string(i)), prev, B, prev, PR(P.num_w[i]), PR(P.num_b[i]), d.num_hidden[i],
-                       W("U" + std::to_string(i + 1)), d.num_hidden[i], 1, 1.f, st));
+            CK(lin.nt(W("U" + std::to_string(i)), prev, B, prev, PR(P.num_w[i]), prev, PR(P.num_b[i]), d.num_hidden[i],
+                      W("U" + std::to_string(i + 1)), d.num_hidden[i], 1, 1.f));
             prev = d.num_hidden[i];
         }
     }
@@ -331,16 +355,16 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     const float *HL = W("H" + std::to_string(x.L));
     // attention (state_encoder.py:150-161)
     const float scale = 1.0f / std::sqrt((float)x.dh);
-    CK(lin_fwd(W("C"), D, B, D, PR(P.q_w), PR(P.q_b), D, W("q0"), D, 0, 1.f, st));
-    CK(lin_fwd(W("q0"), D, B, D, Wiq, biq, D, W("q1"), D, 0, scale, st));
+    CK(lin.nt(W("C"), D, B, D, PR(P.q_w), D, PR(P.q_b), D, W("q0"), D, 0, 1.f));
+    CK(lin.nt(W("q0"), D, B, D, Wiq, D, biq, D, W("q1"), D, 0, scale));
     for (int h = 0; h < x.heads; ++h)   // r[b,h,:] = q1[b, h-slice] @ Wkk[h-slice, :]
-        CK(launch_smm(B, D, x.dh, W("q1") + h * x.dh, D, 1, W("Wkk") + (int64_t)h * x.dh * D, D, 1, nullptr,
-                      W("r") + (int64_t)h * D, (int64_t)x.heads * D, 0, 0, 1.f, st));
+        CK(lin.nn(W("q1") + h * x.dh, D, B, x.dh, W("Wkk") + (int64_t)h * x.dh * D, D, W("r") + (int64_t)h * D,
+                  (int64_t)x.heads * D));
     CK(launch_attn_fwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("s"), st));
     for (int h = 0; h < x.heads; ++h)   // o[b, h-slice] = s[b,h,:] @ Wvv[h-slice,:]^T + bvv[h-slice]
-        CK(launch_smm(B, x.dh, D, W("s") + (int64_t)h * D, (int64_t)x.heads * D, 1, W("Wvv") + (int64_t)h * x.dh * D, 1, D,
-                      W("bvv") + h * x.dh, W("o") + h * x.dh, D, 0, 0, 1.f, st));
-    CK(lin_fwd(W("o"), D, B, D, PR(P.outproj_w), PR(P.outproj_b), D, W("att"), D, 0, 1.f, st));
+        CK(lin.nt(W("s") + (int64_t)h * D, (int64_t)x.heads * D, B, D, W("Wvv") + (int64_t)h * x.dh * D, D, W("bvv") + h * x.dh,
+                  x.dh, W("o") + h * x.dh, D, 0, 1.f));
+    CK(lin.nt(W("o"), D, B, D, PR(P.outproj_w), D, PR(P.outproj_b), D, W("att"), D, 0, 1.f));
     // value head (value.py:15-39)
     CK(launch_assemble_sv(pk, mb, D, x.S_last, W("U" + std::to_string(d.n_num)), W("hbarV"), W("hbarE"), W("att"), W("SV"), st));
     {
@@ -348,8 +372,8 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         int prev = x.W;
         for (int i = 0; i < d.n_value; ++i) {
             float *out = (i == d.n_value - 1) ? value_dev : W("V" + std::to_string(i + 1));
-            CK(lin_fwd(prevp, prev, B, prev, PR(P.value_w[i]), PR(P.value_b[i]), d.value_hidden[i], out, d.value_hidden[i],
-                       i < d.n_value - 1, 1.f, st));
+            CK(lin.nt(prevp, prev, B, prev, PR(P.value_w[i]), prev, PR(P.value_b[i]), d.value_hidden[i], out, d.value_hidden[i],
+                      i < d.n_value - 1, 1.f));
             prevp = out;
             prev = d.value_hidden[i];
         }
@@ -393,6 +417,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     auto PR = [&](int idx) { return prm + P.off(idx); };
     auto GR = [&](int idx) { return grads + P.off(idx); };
     Profiler *prof = &eng->prof;
+    const Lin lin{st, prof, W("slabs"), W("wt")};
     const float *Win = PR(P.inproj_w);
     const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
     float *gWin = GR(P.inproj_w), *gbin = GR(P.inproj_b);
@@ -401,83 +426,80 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // ---- value head
     float *dzA = W("dzA"), *dzB = W("dzB");
     {
-        // dz for the last layer is the seed itself ([B,1])
-        const float *dz = dvalue_dev;
+        const float *dz = dvalue_dev;     // dz of the last layer is the seed itself ([B,1])
         int64_t ldz = 1;
         for (int i = d.n_value - 1; i >= 0; --i) {
             const int N = d.value_hidden[i];
             const int K = (i == 0) ? x.W : d.value_hidden[i - 1];
             const float *Xin = (i == 0) ? W("SV") : W("V" + std::to_string(i));
-            float *dzw = const_cast<float *>(dz);
-            if (i < d.n_value - 1) CK(launch_tanh_bwd(dzw, W("V" + std::to_string(i + 1)), (int64_t)B * N, st));
-            CK(lin_dw(dz, ldz, B, N, Xin, K, K, GR(P.value_w[i]), GR(P.value_b[i]), st));
+            if (i < d.n_value - 1) CK(launch_tanh_bwd(const_cast<float *>(dz), W("V" + std::to_string(i + 1)), (int64_t)B * N, st));
+            CK(lin.tn_acc(dz, ldz, B, N, Xin, K, K, GR(P.value_w[i]), GR(P.value_b[i])));
             float *dnext = (dz == dzA) ? dzB : dzA;
-            CK(lin_dx(dz, ldz, B, N, PR(P.value_w[i]), K, dnext, K, 0, st));
+            CK(lin.nn(dz, ldz, B, N, PR(P.value_w[i]), K, dnext, K));
             dz = dnext;
             ldz = K;
         }
-        // dz now holds dSV [B, W]; keep it in dzA
         if (dz != dzA) UPAMD_HIP(hipMemcpyAsync(dzA, dz, sizeof(float) * (size_t)B * x.W, hipMemcpyDeviceToDevice, st));
     }
-    const float *dSV = dzA;
-    const float *dUlast = dSV;                       // cols [0, S_last)
-    const float *dhbarV = dSV + x.S_last;            // ld = W
+    const float *dSV = dzA;                          // [B, W]
+    const float *dhbarV = dSV + x.S_last;            // column slices, ld = W
     const float *dhbarE = dSV + x.S_last + D;
-    const float *datt = dSV + x.S_last + 2 * D;
 
     // ---- numerical encoder backward
     {
         float *bufA = W("dnA"), *bufB = W("dnB");
         // compact the dUlast column slice of dSV into a dense [B, S_last] buffer
-        UPAMD_HIP(hipMemcpy2DAsync(bufA, sizeof(float) * x.S_last, dUlast, sizeof(float) * x.W, sizeof(float) * x.S_last, B,
+        UPAMD_HIP(hipMemcpy2DAsync(bufA, sizeof(float) * x.S_last, dSV, sizeof(float) * x.W, sizeof(float) * x.S_last, B,
                                    hipMemcpyDeviceToDevice, st));
         float *dz = bufA;
         for (int i = d.n_num - 1; i >= 0; --i) {
             const int N = d.num_hidden[i];
             const int K = (i == 0) ? x.Fn : d.num_hidden[i - 1];
             CK(launch_tanh_bwd(dz, W("U" + std::to_string(i + 1)), (int64_t)B * N, st));
-            CK(lin_dw(dz, N, B, N, W("U" + std::to_string(i)), K, K, GR(P.num_w[i]), GR(P.num_b[i]), st));
+            CK(lin.tn_acc(dz, N, B, N, W("U" + std::to_string(i)), K, K, GR(P.num_w[i]), GR(P.num_b[i])));
             if (i > 0) {
                 float *dnext = (dz == bufA) ? bufB : bufA;
-                CK(lin_dx(dz, N, B, N, PR(P.num_w[i]), K, dnext, K, 0, st));
+                CK(lin.nn(dz, N, B, N, PR(P.num_w[i]), K, dnext, K));
                 dz = dnext;
             }
         }
     }
 
-    // ---- attention, dense part
-    CK(lin_dw(datt, x.W, B, D, W("o"), D, D, GR(P.outproj_w), GR(P.outproj_b), st));
-    CK(lin_dx(datt, x.W, B, D, PR(P.outproj_w), D, W("do"), D, 0, st));
+    // ---- attention, dense part (datt compacted so the MFMA path sees aligned rows)
+    UPAMD_HIP(hipMemcpy2DAsync(W("datt"), sizeof(float) * D, dSV + x.S_last + 2 * D, sizeof(float) * x.W, sizeof(float) * D, B,
+                               hipMemcpyDeviceToDevice, st));
+    const float *datt = W("datt");
+    CK(lin.tn_acc(datt, D, B, D, W("o"), D, D, GR(P.outproj_w), GR(P.outproj_b)));
+    CK(lin.nn(datt, D, B, D, PR(P.outproj_w), D, W("do"), D));
     UPAMD_HIP(hipMemsetAsync(W("dWvv"), 0, sizeof(float) * (size_t)D * D, st));
     UPAMD_HIP(hipMemsetAsync(W("dWkk"), 0, sizeof(float) * (size_t)D * D, st));
     UPAMD_HIP(hipMemsetAsync(W("dbvv"), 0, sizeof(float) * (size_t)D, st));
     CK(launch_colsum_rm(W("do"), B, D, D, W("dbvv"), st));
     for (int h = 0; h < x.heads; ++h) {
         // dWvv[h-slice,:] += do[:,h-slice]^T s[:,h,:]
-        CK(launch_smm(x.dh, D, B, W("do") + h * x.dh, 1, D, W("s") + (int64_t)h * D, (int64_t)x.heads * D, 1, nullptr,
-                      W("dWvv") + (int64_t)h * x.dh * D, D, 1, 0, 1.f, st));
+        CK(lin.tn_acc(W("do") + h * x.dh, D, B, x.dh, W("s") + (int64_t)h * D, (int64_t)x.heads * D, D,
+                      W("dWvv") + (int64_t)h * x.dh * D, nullptr));
         // ds[:,h,:] = do[:,h-slice] Wvv[h-slice,:]
-        CK(launch_smm(B, D, x.dh, W("do") + h * x.dh, D, 1, W("Wvv") + (int64_t)h * x.dh * D, D, 1, nullptr,
-                      W("ds") + (int64_t)h * D, (int64_t)x.heads * D, 0, 0, 1.f, st));
+        CK(lin.nn(W("do") + h * x.dh, D, B, x.dh, W("Wvv") + (int64_t)h * x.dh * D, D, W("ds") + (int64_t)h * D,
+                  (int64_t)x.heads * D));
     }
     // ---- attention core: writes G^L (mean + attention terms) and dr
     float *G = W("G0"), *Gn = W("G1");
     CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("ds"), dhbarV, x.W, G, W("dr"), st));
     for (int h = 0; h < x.heads; ++h) {
         // dq1[:,h-slice] = dr[:,h,:] Wkk[h-slice,:]^T
-        CK(launch_smm(B, x.dh, D, W("dr") + (int64_t)h * D, (int64_t)x.heads * D, 1, W("Wkk") + (int64_t)h * x.dh * D, 1, D,
-                      nullptr, W("dq1") + h * x.dh, D, 0, 0, 1.f, st));
+        CK(lin.nt(W("dr") + (int64_t)h * D, (int64_t)x.heads * D, B, D, W("Wkk") + (int64_t)h * x.dh * D, D, nullptr, x.dh,
+                  W("dq1") + h * x.dh, D, 0, 1.f));
         // dWkk[h-slice,:] += q1[:,h-slice]^T dr[:,h,:]
-        CK(launch_smm(x.dh, D, B, W("q1") + h * x.dh, 1, D, W("dr") + (int64_t)h * D, (int64_t)x.heads * D, 1, nullptr,
-                      W("dWkk") + (int64_t)h * x.dh * D, D, 1, 0, 1.f, st));
+        CK(lin.tn_acc(W("q1") + h * x.dh, D, B, x.dh, W("dr") + (int64_t)h * D, (int64_t)x.heads * D, D,
+                      W("dWkk") + (int64_t)h * x.dh * D, nullptr));
     }
     const float scale = 1.0f / std::sqrt((float)x.dh);
-    // dpre = dq1 * scale (in place)
-    CK(launch_scale(W("dq1"), (int64_t)B * D, scale, st));
-    CK(lin_dw(W("dq1"), D, B, D, W("q0"), D, D, gWin, gbin, st));                      // in_proj q rows
-    CK(lin_dx(W("dq1"), D, B, D, Wiq, D, W("dq0"), D, 0, st));
-    CK(lin_dw(W("dq0"), D, B, D, W("C"), D, D, GR(P.q_w), GR(P.q_b), st));
-    CK(lin_dx(W("dq0"), D, B, D, PR(P.q_w), D, W("dC"), D, 0, st));
+    CK(launch_scale(W("dq1"), (int64_t)B * D, scale, st));                                  // dpre = dq1 * scale
+    CK(lin.tn_acc(W("dq1"), D, B, D, W("q0"), D, D, gWin, gbin));                            // in_proj, q rows
+    CK(lin.nn(W("dq1"), D, B, D, Wiq, D, W("dq0"), D));
+    CK(lin.tn_acc(W("dq0"), D, B, D, W("C"), D, D, GR(P.q_w), GR(P.q_b)));
+    CK(lin.nn(W("dq0"), D, B, D, PR(P.q_w), D, W("dC"), D));
     // collapsed products: Wkk = Wik Wk ; Wvv = Wiv Wv ; bvv = Wiv bv + biv
     CK(launch_smm(D, D, D, W("dWkk"), D, 1, PR(P.k_w), 1, D, nullptr, gWin + (int64_t)D * D, D, 1, 0, 1.f, st));      // dWik += dWkk Wk^T
     CK(launch_smm(D, D, D, Wik, 1, D, W("dWkk"), D, 1, nullptr, GR(P.k_w), D, 1, 0, 1.f, st));                         // dWk  += Wik^T dWkk
@@ -529,6 +551,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     CK(launch_gemm_tn(G, D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
     CK(launch_reduce_slabs(W("slabs"), S, D, 32, 0, x.F, GR(P.node_w), x.F, st));
     CK(launch_colsum_pm(G, mb.M, D, nullptr, W("cs_part"), GR(P.node_b), st));
-    CK(lin_dw(W("dC"), D, B, D, W("curg"), UPAMD_NODE_PAD, x.F, GR(P.node_w), GR(P.node_b), st));
+    CK(launch_smm(D, x.F, B, W("dC"), 1, D, W("curg"), UPAMD_NODE_PAD, 1, nullptr, GR(P.node_w), x.F, 1, 0, 1.f, st));
+    CK(launch_colsum_rm(W("dC"), B, D, D, GR(P.node_b), st));
     return UPAMD_OK;
 }

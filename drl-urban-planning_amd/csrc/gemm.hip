@@ -1,14 +1,16 @@
-// fp32 MFMA GEMMs for the dense per-node / per-candidate MLP layers (gfx950, wave64).
+// fp32 MFMA GEMMs for the dense per-node / per-candidate / per-sample MLP layers (gfx950, wave64).
 //
 // Both kernels use v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak):
 // operand A: lane l holds A[i = l & 31][k = l >> 5]; operand B: lane l holds B[k = l >> 5][j = l & 31];
 // accumulator reg r of lane l is D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31].
 //
-//   gemm_nt : C[M,N](pm) = act(A[M,K](pm) * W[N,K]^T + bias + R)       M = nodes (~10^5..10^6), K,N <= ~1024
-//             forward P/Q projection, node encoder, pointer-head hidden layers, all "dgrad"s.
-//   gemm_tn : slabs[s][I][J] = A[rows_s, I](pm)^T * B[rows_s, J](pm)     reduction over nodes, split-K
-//             all weight gradients; slabs are summed by reduce_slabs in a fixed order (deterministic,
+//   gemm_nt : C[M,N] = alpha * act(A[M,K] * W[N,K]^T + bias + R)        M = nodes (~10^5..10^6) or rows of a
+//             minibatch, K,N <= ~1024.  Forward P/Q projection, node encoder, pointer-head hidden layers, every
+//             "dgrad", and the per-sample [B, D] linear layers (row-major operands).
+//   gemm_tn : slabs[s][I][J] = A[rows_s, I]^T * B[rows_s, J]             reduction over rows, split-K.
+//             Every weight gradient; the slabs are summed by reduce_slabs in a fixed order (deterministic,
 //             no float atomics).
+// A / C (and R) are panel-major [cols/16][rows][16] for per-node tensors, or row-major for per-sample tensors.
 //
 // Replaces the reference's nn.Linear calls on padded [B,E,2D] / [B,N,D] tensors
 // (urban_planning/models/state_encoder.py:19,59-82,110-130; policy.py:19-43) and their autograd.
@@ -25,12 +27,12 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 // ------------------------------------------------------------------------------------------ NT
-template <int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K,
-                                                           const float *__restrict__ W, int N,
+template <int BN, int WM, int WN, bool A_RM, bool C_RM>
+__global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K, int64_t lda,
+                                                           const float *__restrict__ W, int N, int64_t ldw,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ R, float *__restrict__ C,
-                                                           int act_tanh, int MT, int NT) {
+                                                           int64_t ldc, int act_tanh, float alpha, int MT, int NT) {
     constexpr int BM = 128, LD = 17;
     constexpr int WAVES_N = BN / WN;
     constexpr int TI = WM / 32, TJ = WN / 32;
@@ -66,13 +68,13 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
         for (int q = 0; q < 2; ++q) {
             const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
             const int64_t gm = m0 + row;
-            ra[q] = gm < M ? *reinterpret_cast<const float4 *>(A + ((int64_t)kp * M + gm) * 16 + c4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *src = A_RM ? A + gm * lda + kp * 16 + c4 : A + ((int64_t)kp * M + gm) * 16 + c4;
+            ra[q] = gm < M ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
-            if (e < BN * 4) rb[q] = *reinterpret_cast<const float4 *>(W + (int64_t)(n0 + row) * K + kp * 16 + c4);
+            if (e < BN * 4) rb[q] = *reinterpret_cast<const float4 *>(W + (int64_t)(n0 + row) * ldw + kp * 16 + c4);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -128,26 +130,26 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const int64_t gm = m0 + wr * WM + i * 32 + row;
                 if (gm < M) {
-                    const int64_t o = ((int64_t)(gn >> 4) * M + gm) * 16 + (gn & 15);
+                    const int64_t o = C_RM ? gm * ldc + gn : ((int64_t)(gn >> 4) * M + gm) * 16 + (gn & 15);
                     float v = acc[i][j][r] + bv;
                     if (R) v += R[o];
                     if (act_tanh) v = fast_tanh(v);
-                    C[o] = v;
+                    C[o] = v * alpha;
                 }
             }
         }
 }
 
-// generic fallback (any N % 16 == 0): one thread per output element
+// generic fallback (panel-major, any N % 16 == 0): one thread per output element
 __global__ void gemm_nt_generic_kernel(const float *__restrict__ A, int64_t M, int K, const float *__restrict__ W,
-                                       int N, const float *__restrict__ bias, const float *__restrict__ R,
-                                       float *__restrict__ C, int act_tanh) {
+                                       int N, int64_t ldw, const float *__restrict__ bias, const float *__restrict__ R,
+                                       float *__restrict__ C, int act_tanh, float alpha) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= M * N) return;
     const int64_t m = g / N;
     const int n = (int)(g % N);
     float acc = bias ? bias[n] : 0.f;
-    const float *w = W + (int64_t)n * K;
+    const float *w = W + (int64_t)n * ldw;
     for (int kp = 0; kp < (K >> 4); ++kp) {
         const float4 *a4 = reinterpret_cast<const float4 *>(A + ((int64_t)kp * M + m) * 16);
         const float4 *w4 = reinterpret_cast<const float4 *>(w + kp * 16);
@@ -160,7 +162,7 @@ __global__ void gemm_nt_generic_kernel(const float *__restrict__ A, int64_t M, i
     const int64_t o = ((int64_t)(n >> 4) * M + m) * 16 + (n & 15);
     if (R) acc += R[o];
     if (act_tanh) acc = fast_tanh(acc);
-    C[o] = acc;
+    C[o] = acc * alpha;
 }
 
 int prof_begin(Profiler *prof, const char *name, hipStream_t st, double flops, double bytes) {
@@ -180,41 +182,69 @@ void prof_end(Profiler *prof, const char *name, hipStream_t st, int began) {
     if (began == 1) (void)hipEventRecord(prof->stats[name].ev.back(), st);
 }
 
-int launch_gemm_nt(const float *A, int64_t M, int K, const float *W, int N, const float *bias, const float *R,
-                   float *C, int act_tanh, hipStream_t st, Profiler *prof) {
-    if (M <= 0) return 0;
-    if (K % 16 != 0 || N % 16 != 0) return fail(UPAMD_E_INVALID, "gemm_nt: K and N must be multiples of 16 (K=%d N=%d)", K, N);
-    const double flops = 2.0 * (double)M * K * N;
-    const double bytes = 4.0 * ((double)M * K + (double)M * N * (R ? 2 : 1) + (double)N * K);
-    const char *pname = (N % 32 != 0) ? "gemm_nt_generic" : (N % 128 == 0 ? "gemm_nt_128" : (N % 64 == 0 ? "gemm_nt_64" : "gemm_nt_32"));
+bool gemm_nt_mfma_ok(const GemmNT &g) {
+    if (g.K % 16 != 0 || g.N % 32 != 0 || g.ldw % 4 != 0) return false;
+    if (reinterpret_cast<uintptr_t>(g.A) % 16 || reinterpret_cast<uintptr_t>(g.W) % 16) return false;
+    if (g.a_rm && g.lda % 4 != 0) return false;
+    return true;
+}
+
+template <bool A_RM, bool C_RM>
+static void launch_nt_layout(const GemmNT &g, hipStream_t st) {
+    const int MT = (int)((g.M + 127) / 128);
+    const int MT8 = (MT + 7) / 8 * 8;
+    if (g.N % 128 == 0) {
+        const int NT = g.N / 128;
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
+                           g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
+    } else if (g.N % 64 == 0) {
+        const int NT = g.N / 64;
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64, 32, A_RM, C_RM>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
+                           g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
+    } else {
+        const int NT = g.N / 32;
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<32, 32, 32, A_RM, C_RM>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
+                           g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
+    }
+}
+
+int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
+    if (g.M <= 0) return 0;
+    const bool mfma = gemm_nt_mfma_ok(g);
+    if (!mfma && (g.a_rm || g.c_rm)) return fail(UPAMD_E_INVALID, "gemm_nt: row-major operands need the MFMA path (K=%d N=%d)", g.K, g.N);
+    if (g.K % 16 != 0 || g.N % 16 != 0) return fail(UPAMD_E_INVALID, "gemm_nt: K and N must be multiples of 16 (K=%d N=%d)", g.K, g.N);
+    const double flops = 2.0 * (double)g.M * g.K * g.N;
+    const double bytes = 4.0 * ((double)g.M * g.K + (double)g.M * g.N * (g.R ? 2 : 1) + (double)g.N * g.K);
+    const char *pname = !mfma ? "gemm_nt_generic" : (g.N % 128 == 0 ? "gemm_nt_128" : (g.N % 64 == 0 ? "gemm_nt_64" : "gemm_nt_32"));
     int began = prof_begin(prof, pname, st, flops, bytes);
     if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
-    if (N % 32 == 0) {
-        const int MT = (int)((M + 127) / 128);
-        const int MT8 = (MT + 7) / 8 * 8;
-        if (N % 128 == 0) {
-            const int NT = N / 128;
-            hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64>), dim3(MT8 * NT), dim3(256), 0, st, A, M, K, W, N, bias, R, C, act_tanh, MT, NT);
-        } else if (N % 64 == 0) {
-            const int NT = N / 64;
-            hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64, 32>), dim3(MT8 * NT), dim3(256), 0, st, A, M, K, W, N, bias, R, C, act_tanh, MT, NT);
-        } else {
-            const int NT = N / 32;
-            hipLaunchKernelGGL((gemm_nt_mfma_kernel<32, 32, 32>), dim3(MT8 * NT), dim3(256), 0, st, A, M, K, W, N, bias, R, C, act_tanh, MT, NT);
-        }
+    if (mfma) {
+        if (g.a_rm && g.c_rm) launch_nt_layout<true, true>(g, st);
+        else if (g.a_rm) launch_nt_layout<true, false>(g, st);
+        else if (g.c_rm) launch_nt_layout<false, true>(g, st);
+        else launch_nt_layout<false, false>(g, st);
     } else {
-        const int64_t total = M * N;
-        hipLaunchKernelGGL(gemm_nt_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A, M, K, W, N, bias, R, C, act_tanh);
+        const int64_t total = g.M * g.N;
+        hipLaunchKernelGGL(gemm_nt_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g.A, g.M, g.K, g.W, g.N,
+                           g.ldw, g.bias, g.R, g.C, g.act_tanh, g.alpha);
     }
     prof_end(prof, pname, st, began);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }
 
+int launch_gemm_nt(const float *A, int64_t M, int K, const float *W, int N, const float *bias, const float *R,
+                   float *C, int act_tanh, hipStream_t st, Profiler *prof) {
+    GemmNT g;
+    g.A = A; g.M = M; g.K = K; g.lda = 0; g.a_rm = false; g.W = W; g.N = N; g.ldw = K; g.bias = bias; g.R = R;
+    g.C = C; g.ldc = 0; g.c_rm = false; g.act_tanh = act_tanh; g.alpha = 1.f;
+    return launch_gemm_nt_ex(g, st, prof);
+}
+
 // ------------------------------------------------------------------------------------------ TN
-template <int BJ, int WI, int WJ>
-__global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restrict__ A, int I,
-                                                           const float *__restrict__ Bm, int J, int64_t M,
+template <int BJ, int WI, int WJ, bool IN_RM>
+__global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restrict__ A, int I, int64_t lda,
+                                                           const float *__restrict__ Bm, int J, int64_t ldb, int64_t M,
                                                            int64_t chunk, float *__restrict__ slabs, int IT, int JT) {
     constexpr int BI = 128, PS = 272;   // panel stride in LDS: 16 rows * 16 + 16 pad (bank shift 16)
     constexpr int WAVES_J = BJ / WJ;
@@ -249,16 +279,19 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
         for (int q = 0; q < 2; ++q) {
             const int e = tid + 256 * q, panel = e >> 6, rem = e & 63, row = rem >> 2, c4 = (rem & 3) * 4;
             const int64_t gr = rr + row;
-            ra[q] = gr < r1 ? *reinterpret_cast<const float4 *>(A + ((int64_t)(i0 / 16 + panel) * M + gr) * 16 + c4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *src = IN_RM ? A + gr * lda + i0 + panel * 16 + c4
+                                     : A + ((int64_t)(i0 / 16 + panel) * M + gr) * 16 + c4;
+            ra[q] = gr < r1 ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int q = 0; q < NBL; ++q) {
             const int e = tid + 256 * q, panel = e >> 6, rem = e & 63, row = rem >> 2, c4 = (rem & 3) * 4;
             const int64_t gr = rr + row;
-            if (e < PB * 64)
-                rb[q] = gr < r1 ? *reinterpret_cast<const float4 *>(Bm + ((int64_t)(j0 / 16 + panel) * M + gr) * 16 + c4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < PB * 64) {
+                const float *src = IN_RM ? Bm + gr * ldb + j0 + panel * 16 + c4
+                                         : Bm + ((int64_t)(j0 / 16 + panel) * M + gr) * 16 + c4;
+                rb[q] = gr < r1 ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -355,47 +388,72 @@ int tn_splits(int I, int J, int64_t M) {
         tiles = ((int64_t)I * J + 255) / 256;
     }
     int64_t S = (1024 + tiles - 1) / tiles;
-    const int64_t max_s = (M + 511) / 512;   // at least 512 rows per split
+    const int64_t max_s = (M + 127) / 128;   // at least 128 rows per split
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
     if (S > 1024) S = 1024;
     return (int)S;
 }
 
-int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, float *slabs, int *S_out,
-                   hipStream_t st, Profiler *prof) {
-    if (I % 16 != 0 || J % 16 != 0) return fail(UPAMD_E_INVALID, "gemm_tn: I and J must be multiples of 16 (I=%d J=%d)", I, J);
-    const int S = tn_splits(I, J, M);
+bool gemm_tn_mfma_ok(const GemmTN &g) {
+    if (!tn_use_mfma(g.I, g.J)) return false;
+    if (g.in_rm && (g.lda % 4 != 0 || g.ldb % 4 != 0)) return false;
+    if (reinterpret_cast<uintptr_t>(g.A) % 16 || reinterpret_cast<uintptr_t>(g.Bm) % 16) return false;
+    return true;
+}
+
+template <bool IN_RM>
+static void launch_tn_layout(const GemmTN &g, int S, int64_t chunk, hipStream_t st) {
+    const int IT = g.I / 128;
+    if (g.J % 128 == 0) {
+        const int JT = g.J / 128;
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<128, 64, 64, IN_RM>), dim3(S * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
+                           g.ldb, g.M, chunk, g.slabs, IT, JT);
+    } else if (g.J % 64 == 0) {
+        const int JT = g.J / 64;
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<64, 64, 32, IN_RM>), dim3(S * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
+                           g.ldb, g.M, chunk, g.slabs, IT, JT);
+    } else {
+        const int JT = g.J / 32;
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<32, 32, 32, IN_RM>), dim3(S * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
+                           g.ldb, g.M, chunk, g.slabs, IT, JT);
+    }
+}
+
+int launch_gemm_tn_ex(const GemmTN &g, int *S_out, hipStream_t st, Profiler *prof) {
+    if (g.I % 16 != 0 || g.J % 16 != 0) return fail(UPAMD_E_INVALID, "gemm_tn: I and J must be multiples of 16 (I=%d J=%d)", g.I, g.J);
+    const bool mfma = gemm_tn_mfma_ok(g);
+    if (!mfma && g.in_rm) return fail(UPAMD_E_INVALID, "gemm_tn: row-major operands need the MFMA path (I=%d J=%d)", g.I, g.J);
+    const int S = tn_splits(g.I, g.J, g.M);
     *S_out = S;
-    if (M <= 0) {
-        UPAMD_HIP(hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)I * J, st));
+    if (g.M <= 0) {
+        UPAMD_HIP(hipMemsetAsync(g.slabs, 0, sizeof(float) * (size_t)g.I * g.J, st));
         return 0;
     }
-    int64_t chunk = (M + S - 1) / S;
+    int64_t chunk = (g.M + S - 1) / S;
     chunk = (chunk + 15) / 16 * 16;
-    const double flops = 2.0 * (double)M * I * J;
-    const double bytes = 4.0 * ((double)M * (I + J) + (double)S * I * J);
-    const char *pname = !tn_use_mfma(I, J) ? "gemm_tn_generic" : (J % 128 == 0 ? "gemm_tn_128" : (J % 64 == 0 ? "gemm_tn_64" : "gemm_tn_32"));
+    const double flops = 2.0 * (double)g.M * g.I * g.J;
+    const double bytes = 4.0 * ((double)g.M * (g.I + g.J) + (double)S * g.I * g.J);
+    const char *pname = !mfma ? "gemm_tn_generic" : (g.J % 128 == 0 ? "gemm_tn_128" : (g.J % 64 == 0 ? "gemm_tn_64" : "gemm_tn_32"));
     int began = prof_begin(prof, pname, st, flops, bytes);
     if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
-    if (tn_use_mfma(I, J)) {
-        const int IT = I / 128;
-        if (J % 128 == 0) {
-            const int JT = J / 128;
-            hipLaunchKernelGGL((gemm_tn_mfma_kernel<128, 64, 64>), dim3(S * IT * JT), dim3(256), 0, st, A, I, Bm, J, M, chunk, slabs, IT, JT);
-        } else if (J % 64 == 0) {
-            const int JT = J / 64;
-            hipLaunchKernelGGL((gemm_tn_mfma_kernel<64, 64, 32>), dim3(S * IT * JT), dim3(256), 0, st, A, I, Bm, J, M, chunk, slabs, IT, JT);
-        } else {
-            const int JT = J / 32;
-            hipLaunchKernelGGL((gemm_tn_mfma_kernel<32, 32, 32>), dim3(S * IT * JT), dim3(256), 0, st, A, I, Bm, J, M, chunk, slabs, IT, JT);
-        }
+    if (mfma) {
+        if (g.in_rm) launch_tn_layout<true>(g, S, chunk, st);
+        else launch_tn_layout<false>(g, S, chunk, st);
     } else {
-        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((I * J + 255) / 256, S), dim3(256), 0, st, A, I, Bm, J, M, chunk, slabs);
+        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((g.I * g.J + 255) / 256, S), dim3(256), 0, st, g.A, g.I, g.Bm, g.J, g.M, chunk,
+                           g.slabs);
     }
     prof_end(prof, pname, st, began);
     UPAMD_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, float *slabs, int *S_out,
+                   hipStream_t st, Profiler *prof) {
+    GemmTN g;
+    g.A = A; g.I = I; g.lda = 0; g.Bm = Bm; g.J = J; g.ldb = 0; g.M = M; g.in_rm = false; g.slabs = slabs;
+    return launch_gemm_tn_ex(g, S_out, st, prof);
 }
 
 __global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int S, int I, int J, int mode, int jkeep,

@@ -224,7 +224,8 @@ int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, co
 __global__ __launch_bounds__(256) void he_feat_fwd_kernel(PackedView pk, MbView mb, int NP,
                                                           const float *__restrict__ PQ, const float *__restrict__ bias,
                                                           const float *__restrict__ C, float *__restrict__ FE) {
-    const int b = blockIdx.x, t = mb.idx[b];
+    // one workgroup per (graph, 16-column panel): 16 candidates x 16 columns in flight per pass
+    const int b = blockIdx.x / NP, p = blockIdx.x % NP, t = mb.idx[b];
     const int32_t *m = META(t);
     const int nh = m[2];
     if (nh == 0) return;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void he_feat_fwd_kernel(PackedView pk, MbView 
         const int i = pk.he_src[m[11] + q], j = pk.he_dst[m[11] + q];
         const bool live = pk.he_live[m[11] + q] != 0;
         const int64_t row = q0 + q;
-        for (int p = 0; p < NP; ++p) {
+        {
             const float bc = bias[p * 16 + c];
             float mm = 0.f;
             if (live) {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void he_feat_fwd_kernel(PackedView pk, MbView 
 int launch_he_feat_fwd(const PackedView &pk, const MbView &mb, int D, const float *PQ, const float *bias,
                        const float *C, float *FE, hipStream_t st) {
     if (mb.Nhe == 0) return 0;
-    hipLaunchKernelGGL(he_feat_fwd_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, D / 16, PQ, bias, C, FE);
+    hipLaunchKernelGGL(he_feat_fwd_kernel, dim3(mb.B * (D / 16)), dim3(256), 0, st, pk, mb, D / 16, PQ, bias, C, FE);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

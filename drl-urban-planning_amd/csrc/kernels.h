@@ -53,6 +53,24 @@ void prof_end(Profiler *prof, const char *name, hipStream_t st, int began);
 // C[M,N](pm) = act( A[M,K](pm) * W[N,K]^T (row-major, ld = K) + bias[N] + R[M,N](pm) )
 int launch_gemm_nt(const float *A, int64_t M, int K, const float *W, int N, const float *bias, const float *R,
                    float *C, int act_tanh, hipStream_t st, Profiler *prof);
+// general form: A / C (and R) either panel-major or row-major (ld in floats), W row-major with ld = ldw
+struct GemmNT {
+    const float *A; int64_t M; int K; int64_t lda; bool a_rm;
+    const float *W; int N; int64_t ldw;
+    const float *bias; const float *R;
+    float *C; int64_t ldc; bool c_rm;
+    int act_tanh; float alpha;
+};
+bool gemm_nt_mfma_ok(const GemmNT &g);
+int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof);
+struct GemmTN {
+    const float *A; int I; int64_t lda;
+    const float *Bm; int J; int64_t ldb;
+    int64_t M; bool in_rm;      // both inputs panel-major, or both row-major [M][ld]
+    float *slabs;
+};
+bool gemm_tn_mfma_ok(const GemmTN &g);
+int launch_gemm_tn_ex(const GemmTN &g, int *S_out, hipStream_t st, Profiler *prof);
 // slabs[S][I][J] = partial sums over row chunks of A[M,I](pm)^T * Bm[M,J](pm);  returns S via *S_out
 int tn_splits(int I, int J, int64_t M);
 int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, float *slabs, int *S_out,

@@ -200,6 +200,22 @@ int upamd_adam_step(int64_t begin, int64_t end, float *params_dev, const float *
                     double weight_decay, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The two fp32-MFMA GEMM building blocks of the engine, exposed for kernel-level parity tests and
+ * micro-benchmarks.  They stand in for the reference's nn.Linear products (and their autograd) on
+ * [nodes, D] / [edges, 2D] tensors (urban_planning/models/state_encoder.py:19,59-82,110-130).
+ * Layouts: row_major = 1 -> [rows][ld]; 0 -> panel-major [cols/16][rows][16] (ld ignored).
+ * ------------------------------------------------------------------------------------------ */
+/* C[M,N] = alpha * act(A[M,K] * W[N,K]^T + bias[N] + R[M,N]);  W row-major with leading dimension ldw */
+int upamd_gemm_nt(const float *A_dev, int64_t M, int32_t K, int64_t lda, int32_t a_row_major, const float *W_dev,
+                  int32_t N, int64_t ldw, const float *bias_dev, const float *R_dev, float *C_dev, int64_t ldc,
+                  int32_t c_row_major, int32_t act_tanh, float alpha, void *stream);
+/* out[I,J] (row-major, overwritten) = A[M,I]^T * B[M,J], deterministic split-K through scratch_dev
+ * (upamd_gemm_tn_scratch_floats(I, J, M) floats) */
+int64_t upamd_gemm_tn_scratch_floats(int32_t I, int32_t J, int64_t M);
+int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev, int32_t J, int64_t ldb, int64_t M,
+                  int32_t row_major, float *scratch_dev, float *out_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing of the dominant kernels (HIP events on the launch stream), for bench.py.
  * ------------------------------------------------------------------------------------------ */
 int upamd_profile_enable(upamd_engine *eng, int32_t on);
