@@ -14,6 +14,8 @@
 //
 // Replaces the reference's nn.Linear calls on padded [B,E,2D] / [B,N,D] tensors
 // (urban_planning/models/state_encoder.py:19,59-82,110-130; policy.py:19-43) and their autograd.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace upamd {
@@ -27,8 +29,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 // ------------------------------------------------------------------------------------------ NT
-template <int BN, int WM, int WN, bool A_RM, bool C_RM>
-__global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K, int64_t lda,
+template <int BN, int WM, int WN, bool A_RM, bool C_RM, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K, int64_t lda,
                                                            const float *__restrict__ W, int N, int64_t ldw,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ R, float *__restrict__ C,
@@ -113,31 +115,48 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    // operands swapped on purpose: D[row = n][col = m], so a lane's 4 consecutive accumulator
+                    // registers are 4 consecutive columns of one output row -> 16-byte stores in the epilogue
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         if (kp + 1 < KP) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < TI; ++i) {
+        const int64_t gm = m0 + wr * WM + i * 32 + l31;
+        if (gm >= M) continue;
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int gn = n0 + wc * WN + j * 32 + l31;
-            const float bv = bias ? bias[gn] : 0.f;
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const int64_t gm = m0 + wr * WM + i * 32 + row;
-                if (gm < M) {
-                    const int64_t o = C_RM ? gm * ldc + gn : ((int64_t)(gn >> 4) * M + gm) * 16 + (gn & 15);
-                    float v = acc[i][j][r] + bv;
-                    if (R) v += R[o];
-                    if (act_tanh) v = fast_tanh(v);
-                    C[o] = v * alpha;
+            for (int q = 0; q < 4; ++q) {
+                const int gn = n0 + wc * WN + j * 32 + 8 * q + 4 * lhi;      // 4 consecutive columns gn..gn+3
+                const int64_t o = C_RM ? gm * ldc + gn : ((int64_t)(gn >> 4) * M + gm) * 16 + (gn & 15);
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * q + t] + (bias ? bias[gn + t] : 0.f);
+                if (R) {
+                    if (C_RM) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] += R[o + t];
+                    } else {
+                        const float4 r4 = *reinterpret_cast<const float4 *>(R + o);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    }
+                }
+                if (act_tanh) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = fast_tanh(v[t]);
+                }
+                if (C_RM) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) C[o + t] = v[t] * alpha;
+                } else {
+                    *reinterpret_cast<float4 *>(C + o) = make_float4(v[0] * alpha, v[1] * alpha, v[2] * alpha, v[3] * alpha);
                 }
             }
-        }
+    }
 }
 
 // generic fallback (panel-major, any N % 16 == 0): one thread per output element
@@ -189,21 +208,30 @@ bool gemm_nt_mfma_ok(const GemmNT &g) {
     return true;
 }
 
-template <bool A_RM, bool C_RM>
+static int nt_min_waves() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("UPAMD_GEMM_MINW");
+        v = e ? atoi(e) : 2;
+    }
+    return v;
+}
+
+template <bool A_RM, bool C_RM, int MINW>
 static void launch_nt_layout(const GemmNT &g, hipStream_t st) {
     const int MT = (int)((g.M + 127) / 128);
     const int MT8 = (MT + 7) / 8 * 8;
     if (g.N % 128 == 0) {
         const int NT = g.N / 128;
-        hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM, MINW>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
                            g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
     } else if (g.N % 64 == 0) {
         const int NT = g.N / 64;
-        hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64, 32, A_RM, C_RM>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64, 32, A_RM, C_RM, MINW>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
                            g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
     } else {
         const int NT = g.N / 32;
-        hipLaunchKernelGGL((gemm_nt_mfma_kernel<32, 32, 32, A_RM, C_RM>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<32, 32, 32, A_RM, C_RM, MINW>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
                            g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
     }
 }
@@ -215,14 +243,19 @@ int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
     if (g.K % 16 != 0 || g.N % 16 != 0) return fail(UPAMD_E_INVALID, "gemm_nt: K and N must be multiples of 16 (K=%d N=%d)", g.K, g.N);
     const double flops = 2.0 * (double)g.M * g.K * g.N;
     const double bytes = 4.0 * ((double)g.M * g.K + (double)g.M * g.N * (g.R ? 2 : 1) + (double)g.N * g.K);
-    const char *pname = !mfma ? "gemm_nt_generic" : (g.N % 128 == 0 ? "gemm_nt_128" : (g.N % 64 == 0 ? "gemm_nt_64" : "gemm_nt_32"));
+    const bool rm = g.a_rm || g.c_rm;
+    const char *pname = !mfma ? "gemm_nt_generic"
+                              : (g.N % 128 == 0 ? (rm ? "gemm_nt_128_rm" : "gemm_nt_128")
+                                                : (g.N % 64 == 0 ? (rm ? "gemm_nt_64_rm" : "gemm_nt_64") : (rm ? "gemm_nt_32_rm" : "gemm_nt_32")));
     int began = prof_begin(prof, pname, st, flops, bytes);
     if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
     if (mfma) {
-        if (g.a_rm && g.c_rm) launch_nt_layout<true, true>(g, st);
-        else if (g.a_rm) launch_nt_layout<true, false>(g, st);
-        else if (g.c_rm) launch_nt_layout<false, true>(g, st);
-        else launch_nt_layout<false, false>(g, st);
+        if (g.a_rm && g.c_rm) launch_nt_layout<true, true, 2>(g, st);
+        else if (g.a_rm) launch_nt_layout<true, false, 2>(g, st);
+        else if (g.c_rm) launch_nt_layout<false, true, 2>(g, st);
+        else if (nt_min_waves() == 3) launch_nt_layout<false, false, 3>(g, st);
+        else if (nt_min_waves() == 1) launch_nt_layout<false, false, 1>(g, st);
+        else launch_nt_layout<false, false, 2>(g, st);
     } else {
         const int64_t total = g.M * g.N;
         hipLaunchKernelGGL(gemm_nt_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g.A, g.M, g.K, g.W, g.N,
