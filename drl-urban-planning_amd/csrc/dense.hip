@@ -17,7 +17,7 @@ __device__ __forceinline__ float fast_tanh_d(float x) {
 __global__ __launch_bounds__(256) void smm_kernel(int I, int J, int K, const float *__restrict__ A, int64_t sa0,
                                                   int64_t sa1, const float *__restrict__ B, int64_t sb0, int64_t sb1,
                                                   const float *__restrict__ bias, float *__restrict__ C, int64_t ldc,
-                                                  int accumulate, int act_tanh, float out_scale) {
+                                                  int accumulate, int act_tanh, float out_scale, int kchunk) {
     __shared__ __attribute__((aligned(16))) float As[16][68];
     __shared__ __attribute__((aligned(16))) float Bs[16][68];
     const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
@@ -25,7 +25,13 @@ __global__ __launch_bounds__(256) void smm_kernel(int I, int J, int K, const flo
     float acc[4][4] = {};
     const bool a_k_fast = (sa1 == 1);
     const bool b_j_fast = (sb1 == 1);
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    // split-K: slice blockIdx.z of the reduction range, partial result into slab z of C
+    const int kbeg = blockIdx.z * kchunk;
+    if (gridDim.z > 1) {
+        C += (int64_t)blockIdx.z * I * ldc;
+        K = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    }
+    for (int k0 = kbeg; k0 < K; k0 += 16) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = tid + 256 * q;
@@ -73,7 +79,27 @@ int launch_smm(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, co
                hipStream_t st) {
     if (I <= 0 || J <= 0) return 0;
     dim3 grid((J + 63) / 64, (I + 63) / 64);
-    hipLaunchKernelGGL(smm_kernel, grid, dim3(256), 0, st, I, J, K, A, sa0, sa1, B, sb0, sb1, bias, C, ldc, accumulate, act_tanh, out_scale);
+    hipLaunchKernelGGL(smm_kernel, grid, dim3(256), 0, st, I, J, K, A, sa0, sa1, B, sb0, sb1, bias, C, ldc, accumulate, act_tanh, out_scale, K);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// split-K form: slabs[s][I][J] = partial products over K chunks (sum them with launch_reduce_slabs)
+int smm_splits(int K) {
+    int S = K / 64;
+    if (S > 32) S = 32;
+    if (S < 1) S = 1;
+    return S;
+}
+int launch_smm_splitk(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, const float *B, int64_t sb0,
+                      int64_t sb1, float *slabs, int *S_out, hipStream_t st) {
+    const int S = smm_splits(K);
+    *S_out = S;
+    if (I <= 0 || J <= 0) return 0;
+    int kchunk = (K + S - 1) / S;
+    kchunk = (kchunk + 15) / 16 * 16;
+    dim3 grid((J + 63) / 64, (I + 63) / 64, S);
+    hipLaunchKernelGGL(smm_kernel, grid, dim3(256), 0, st, I, J, K, A, sa0, sa1, B, sb0, sb1, nullptr, slabs, (int64_t)J, 0, 0, 1.f, kchunk);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

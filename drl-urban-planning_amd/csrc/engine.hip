@@ -48,6 +48,7 @@ int64_t slab_floats(const Dims &x, int64_t B, int64_t M, int64_t Nhe, int64_t Nr
     s = std::max<int64_t>(s, (int64_t)tn_splits(4 * x.D, x.h0l, Nhe) * 4 * x.D * x.h0l);    // land head
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.h0r, Nrn) * x.D * x.h0r);            // road head
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.D, B) * x.D * x.D);                  // per-sample D x D layers
+    s = std::max<int64_t>(s, (int64_t)smm_splits((int)B) * x.maxdim * x.maxdim);            // small per-sample layers (split-K)
     return s;
 }
 
@@ -179,11 +180,21 @@ struct Lin {
             int S = 1;
             CK(launch_gemm_tn_ex(g, &S, st, prof));
             CK(launch_reduce_slabs(slabs, S, N, K, 0, K, dW, K, st));
+        } else if (R >= 512) {      // long reduction over rows, small output: split-K, fixed-order reduce
+            int S = 1;
+            CK(launch_smm_splitk(N, K, R, dY, 1, ldy, X, ldx, 1, slabs, &S, st));
+            CK(launch_reduce_slabs(slabs, S, N, K, 0, K, dW, K, st));
         } else {
             CK(launch_smm(N, K, R, dY, 1, ldy, X, ldx, 1, nullptr, dW, K, 1, 0, 1.f, st));
         }
         if (db) CK(launch_colsum_rm(dY, R, N, ldy, db, st));
         return 0;
+    }
+    // Y[R,N] += X[R,K] W[N,K]^T
+    int nt_acc(const float *X, int64_t ldx, int R, int K, const float *W, int64_t ldw, int N, float *Y, int64_t ldy) const {
+        GemmNT g{X, R, K, ldx, true, W, N, ldw, nullptr, Y, Y, ldy, true, 0, 1.f};
+        if (R >= MIN_ROWS && gemm_nt_mfma_ok(g)) return launch_gemm_nt_ex(g, st, prof);
+        return launch_smm(R, N, K, X, ldx, 1, W, 1, ldw, nullptr, Y, ldy, 1, 0, 1.f, st);
     }
 };
 
@@ -501,11 +512,11 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     CK(lin.tn_acc(W("dq0"), D, B, D, W("C"), D, D, GR(P.q_w), GR(P.q_b)));
     CK(lin.nn(W("dq0"), D, B, D, PR(P.q_w), D, W("dC"), D));
     // collapsed products: Wkk = Wik Wk ; Wvv = Wiv Wv ; bvv = Wiv bv + biv
-    CK(launch_smm(D, D, D, W("dWkk"), D, 1, PR(P.k_w), 1, D, nullptr, gWin + (int64_t)D * D, D, 1, 0, 1.f, st));      // dWik += dWkk Wk^T
-    CK(launch_smm(D, D, D, Wik, 1, D, W("dWkk"), D, 1, nullptr, GR(P.k_w), D, 1, 0, 1.f, st));                         // dWk  += Wik^T dWkk
-    CK(launch_smm(D, D, D, W("dWvv"), D, 1, PR(P.v_w), 1, D, nullptr, gWin + 2LL * D * D, D, 1, 0, 1.f, st));         // dWiv += dWvv Wv^T
+    CK(lin.nt_acc(W("dWkk"), D, D, D, PR(P.k_w), D, D, gWin + (int64_t)D * D, D));                                   // dWik += dWkk Wk^T
+    CK(lin.tn_acc(Wik, D, D, D, W("dWkk"), D, D, GR(P.k_w), nullptr));                                               // dWk  += Wik^T dWkk
+    CK(lin.nt_acc(W("dWvv"), D, D, D, PR(P.v_w), D, D, gWin + 2LL * D * D, D));                                      // dWiv += dWvv Wv^T
     CK(launch_smm(D, D, 1, W("dbvv"), 1, 1, PR(P.v_b), 1, 1, nullptr, gWin + 2LL * D * D, D, 1, 0, 1.f, st));         // dWiv += dbvv (x) bv
-    CK(launch_smm(D, D, D, Wiv, 1, D, W("dWvv"), D, 1, nullptr, GR(P.v_w), D, 1, 0, 1.f, st));                         // dWv  += Wiv^T dWvv
+    CK(lin.tn_acc(Wiv, D, D, D, W("dWvv"), D, D, GR(P.v_w), nullptr));                                               // dWv  += Wiv^T dWvv
     CK(launch_smm(1, D, D, W("dbvv"), D, 1, Wiv, D, 1, nullptr, GR(P.v_b), D, 1, 0, 1.f, st));                         // dbv  += Wiv^T dbvv
     CK(launch_axpy(gbin + 2 * D, W("dbvv"), D, 1.f, st));                                                            // dbiv += dbvv
 
@@ -551,7 +562,6 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     CK(launch_gemm_tn(G, D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
     CK(launch_reduce_slabs(W("slabs"), S, D, 32, 0, x.F, GR(P.node_w), x.F, st));
     CK(launch_colsum_pm(G, mb.M, D, nullptr, W("cs_part"), GR(P.node_b), st));
-    CK(launch_smm(D, x.F, B, W("dC"), 1, D, W("curg"), UPAMD_NODE_PAD, 1, nullptr, GR(P.node_w), x.F, 1, 0, 1.f, st));
-    CK(launch_colsum_rm(W("dC"), B, D, D, GR(P.node_b), st));
+    CK(lin.tn_acc(W("dC"), D, B, D, W("curg"), UPAMD_NODE_PAD, x.F, GR(P.node_w), GR(P.node_b)));
     return UPAMD_OK;
 }

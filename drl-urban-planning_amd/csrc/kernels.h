@@ -111,6 +111,9 @@ int launch_pointer_bwd(const PackedView &pk, const MbView &mb, const float *z_he
 int launch_smm(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, const float *B, int64_t sb0,
                int64_t sb1, const float *bias, float *C, int64_t ldc, int accumulate, int act_tanh, float out_scale,
                hipStream_t st);
+int smm_splits(int K);
+int launch_smm_splitk(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, const float *B, int64_t sb0,
+                      int64_t sb1, float *slabs, int *S_out, hipStream_t st);
 // dst[j] += sum_i X[i*ld + j]   (row-major), deterministic
 int launch_colsum_rm(const float *X, int rows, int cols, int64_t ld, float *dst, hipStream_t st);
 // part[blk][col] = sum_{rows of blk} (w ? w[row] : 1) * X(pm)[row][col];  then dst[col] += sum_blk
