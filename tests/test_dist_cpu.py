@@ -1,0 +1,97 @@
+"""Data-parallel protocol on CPU (world size 2, gloo): global row counts once per epoch, loss scaled by
+GLOBAL counts on every rank, ONE all-reduce(sum) of the flat gradient buffer (+4 loss scalars) per step.
+The per-shard compute is done by the oracle here (the HIP engine needs a GPU); what is under test is
+`drl_urban_planning_amd.dist` and the scaling rule `PPOUpdater.step` applies."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import helpers
+from oracle import sgnn_oracle as orc
+from test_oracle_golden import CASE_HYPER
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _flat(P, names):
+    return torch.cat([(P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])).reshape(-1) for k in names])
+
+
+def _shard_loss(P, states, actions, adv, ret, old, exps, hy, inv_rows, inv_ind, heads):
+    """Sum-form loss of one shard with global scaling (what upamd_ppo_loss computes per rank)."""
+    xs = orc.tensorfy(states)
+    value = orc.value_forward(P, xs, heads)
+    logp, ent = orc.get_log_prob_entropy(P, xs, actions, heads)
+    ind = exps.nonzero(as_tuple=False).squeeze(1)
+    vl = (value - ret).pow(2).sum() * inv_rows
+    ratio = torch.exp(logp[ind] - old[ind])
+    s1 = ratio * adv[ind]
+    s2 = torch.clamp(ratio, 1 - hy['clip_epsilon'], 1 + hy['clip_epsilon']) * adv[ind]
+    sl = -torch.min(s1, s2).sum() * inv_ind
+    el = -ent[ind].sum() * inv_ind
+    loss = sl + hy['value_pred_coef'] * vl + hy['entropy_coef'] * el
+    return loss, torch.stack([loss.detach(), vl.detach(), sl.detach(), el.detach()])
+
+
+def _worker(rank, world, port, name, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'] = str(rank)
+    os.environ['WORLD_SIZE'] = str(world)
+    torch.set_num_threads(1)
+    from drl_urban_planning_amd.dist import DistContext, global_counts, shard_rows
+    ctx = DistContext.from_env(backend='gloo')
+    assert ctx.world == world and ctx.rank == rank
+    z, sd, states = helpers.load_case(name)
+    hy = CASE_HYPER[name]
+    heads = helpers.CASE_MODEL[name]['heads']
+    B = z['mb/adv'].shape[0]
+    rows = shard_rows(list(range(B)), rank, world)
+    P = helpers.oracle_params(sd)
+    names = list(P.keys())
+    exps_all = torch.from_numpy(z['exps'][:B]).float()
+    counts = global_counts(ctx, [[len(rows)], [int((exps_all[rows] != 0).sum())]], 'cpu')
+    assert counts[0][0] == B and counts[1][0] == int((exps_all != 0).sum())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[:B][rows], dtype=np.float32))
+    loss, scal = _shard_loss(P, [states[i] for i in rows], t(z['actions']), t(z['mb/adv']), t(z['mb/ret']),
+                             t(z['mb/old_logp']), exps_all[rows], hy, 1.0 / counts[0][0], 1.0 / counts[1][0], heads)
+    loss.backward()
+    buf = torch.cat([_flat(P, names), scal.float()])
+    ctx.all_reduce_sum(buf)                       # the one collective of a step
+    ctx.barrier()
+    if rank == 0:
+        np.save(os.path.join(out_dir, 'reduced.npy'), buf.numpy())
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['case_a'])
+def test_two_rank_gradient_allreduce_matches_full_batch(name, tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, name, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(str(tmp_path), 'reduced.npy'))
+    z, sd, states = helpers.load_case(name)
+    P = helpers.oracle_params(sd)
+    names = list(P.keys())
+    ref = np.concatenate([z[helpers.golden_key('grad/', k)].reshape(-1) for k in names])
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(got[:-4], ref, rtol=1e-4, atol=2e-6 * scale)
+    np.testing.assert_allclose(got[-4:], z['mb/losses'], rtol=1e-5, atol=1e-6)
+
+
+def test_shard_rows_and_single_rank_counts():
+    from drl_urban_planning_amd.dist import DistContext, global_counts, shard_rows
+    assert shard_rows(list(range(8)), 1, 2) == [4, 5, 6, 7]
+    with pytest.raises(ValueError):
+        shard_rows(list(range(7)), 0, 2)
+    assert global_counts(DistContext(), [[3, 4], [1, 2]], 'cpu') == [[3, 4], [1, 2]]
