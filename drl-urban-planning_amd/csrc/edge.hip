@@ -11,24 +11,27 @@
 // group, lanes = the 16 columns -- walking that node's incidence list sequentially: a CSR-by-
 // destination segment sum in a fixed order, no atomics, no cross-lane reduction, bit-reproducible.
 // Nodes are visited in the packer's degree-sorted order so the four lists a wave walks together have
-// (nearly) equal length.  16 waves per workgroup x 2 workgroups per CU = the full 8 waves per SIMD,
-// which is what hides the LDS latency behind the tanh arithmetic (the kernels are VALU-bound:
-// 2 transcendental pairs per incidence and column).
+// (nearly) equal length.  16 waves per workgroup x 2 workgroups per CU = the full 8 waves per SIMD.
+//
+// The kernels are VALU-bound (PMC: SQ_ACTIVE_INST_VALU saturated), so the inner loop is trimmed to the
+// transcendental minimum: P and Q are staged PRE-SCALED by 2*log2(e), so with E = 2^(P'_v + Q'_u + b')
+//   tanh(x) = 1 - 2 r,  r = 1 / (1 + E)          (v_exp_f32 + v_rcp_f32, abs error ~1e-7, clean saturation)
+// the forward only accumulates r (sum of tanh = 2 deg - 2 sum r) and the backward uses
+//   1 - tanh^2 = 4 (r - r^2).
 #include "kernels.h"
 
 namespace upamd {
-
-__device__ __forceinline__ float etanh(float x) {
-    // tanh(x) = 1 - 2 / (exp(2x) + 1) on v_exp_f32 / v_rcp_f32 (abs error ~1e-7, clean saturation)
-    float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-}
 
 #define META(t) (pk.meta + (int64_t)(t) * UPAMD_META_STRIDE)
 
 constexpr int EDGE_THREADS = 1024;
 constexpr int EDGE_WAVES = EDGE_THREADS / 64;
 constexpr int64_t LDS_LIMIT = 160 * 1024;
+constexpr float C2 = 2.8853900817779268f;      // 2 * log2(e)
+
+__device__ __forceinline__ float rcp1p_exp2(float x) {      // 1 / (1 + 2^x)
+    return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x) + 1.0f);
+}
 
 static inline int64_t a16(int64_t x) { return (x + 15) / 16 * 16; }
 
@@ -70,28 +73,31 @@ __device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool
     return L;
 }
 
-// interleave a graph's P and Q panel slices into LDS: PQ[v][c] = (P[v][c], Q[v][c])
+// interleave a graph's P and Q panel slices into LDS, pre-scaled: PQ[v][c] = C2 * (P[v][c], Q[v][c])
 __device__ __forceinline__ void stage_pq(float2 *PQl, const float *Pg, const float *Qg, int n) {
     const float4 *p4 = reinterpret_cast<const float4 *>(Pg);
     const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
     for (int i = threadIdx.x; i < n * 4; i += EDGE_THREADS) {
         const float4 pp = p4[i], qq = q4[i];
         float4 *d = reinterpret_cast<float4 *>(PQl + i * 4);       // 4 consecutive (P,Q) pairs = 32 B
-        d[0] = make_float4(pp.x, qq.x, pp.y, qq.y);
-        d[1] = make_float4(pp.z, qq.z, pp.w, qq.w);
+        d[0] = make_float4(C2 * pp.x, C2 * qq.x, C2 * pp.y, C2 * qq.y);
+        d[1] = make_float4(C2 * pp.z, C2 * qq.z, C2 * pp.w, C2 * qq.w);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// forward: H_out = H_in + S / (deg + 1e-6);  the last layer also emits the masked node mean and the
-// edge mean (= 1/2 sum_v S_v / e: every message is counted at both of its endpoints).
+// forward: H_out = H_in + S / (deg + 1e-6).  The last layer also emits the masked node mean, the edge
+// mean (= 1/2 sum_v S_v / e: every message is counted at both of its endpoints) and -- fused, while the
+// P/Q slices are still in LDS -- the land-use pointer-head inputs of the row's candidate edges
+// (state_encoder.py:207-210): FE = [m ; c ; m*c ; m-c] with m the candidate's last-layer message.
 // ------------------------------------------------------------------------------------------
 template <bool LAST, bool STAGE>
 __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
                                                                 const float *__restrict__ PQ,
                                                                 const float *__restrict__ bias,
                                                                 const float *__restrict__ Hin, float *__restrict__ Hout,
-                                                                float *__restrict__ hbarV, float *__restrict__ hbarE) {
+                                                                float *__restrict__ hbarV, float *__restrict__ hbarE,
+                                                                const float *__restrict__ Ccur, float *__restrict__ FE) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int t = mb.idx[b];
@@ -123,37 +129,30 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, M
     }
     __syncthreads();
 
-    const float bc = bias[p * 16 + c];
+    // scaled (P,Q) of node u for this lane's column
+    auto pq = [&](int u) -> float2 {
+        if (STAGE) return L.PQ[u * 16 + c];
+        return make_float2(C2 * Pg[u * 16 + c], C2 * Qg[u * 16 + c]);
+    };
+    const float bc = C2 * bias[p * 16 + c];
     float sumS = 0.f, sumH = 0.f;
     const int nchunks = (n + 3) >> 2;
     for (int j = w; j < nchunks; j += EDGE_WAVES) {
         const int vi = 4 * j + g;
         const bool valid = vi < n;
         const int v = L.ord[valid ? vi : n - 1];
-        float pv, qv;
-        if (STAGE) {
-            const float2 t2 = L.PQ[v * 16 + c];
-            pv = t2.x + bc; qv = t2.y + bc;
-        } else {
-            pv = Pg[v * 16 + c] + bc; qv = Qg[v * 16 + c] + bc;
-        }
+        const float2 own = pq(v);
+        const float pv = own.x + bc, qv = own.y + bc;
         int k = L.rp[v];
         const int k1 = valid ? L.rp[v + 1] : k;
         const float degf = (float)(k1 - k);
-        float acc = 0.f;
+        float accR = 0.f;                  // sum over incidences of r1 + r2
         for (; k < k1; ++k) {
-            const int u = L.nb[k];
-            float pu, qu;
-            if (STAGE) {
-                const float2 t2 = L.PQ[u * 16 + c];
-                pu = t2.x; qu = t2.y;
-            } else {
-                pu = Pg[u * 16 + c]; qu = Qg[u * 16 + c];
-            }
-            acc += etanh(pv + qu) + etanh(pu + qv);
+            const float2 nbv = pq(L.nb[k]);
+            accR += rcp1p_exp2(pv + nbv.y) + rcp1p_exp2(nbv.x + qv);
         }
         if (valid) {
-            const float S = 0.5f * acc;
+            const float S = degf - accR;   // 1/2 sum (tanh1 + tanh2) = 1/2 (2 deg - 2 accR)
             const float a = S / (degf + 1e-6f);
             float h;
             if (STAGE) {
@@ -167,6 +166,24 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, M
                 sumS += S;
                 if (L.nm[v]) sumH += h;
             }
+        }
+    }
+    if (LAST && FE && m[2] > 0) {
+        // pointer-head inputs of this row's candidate edges (4 candidates per wave pass)
+        const int nh = m[2];
+        const int64_t NH = mb.Nhe, q0 = mb.he_off[b];
+        const float cc = Ccur[(int64_t)b * (NP * 16) + p * 16 + c];
+        for (int q = 4 * w + g; q < nh; q += 4 * EDGE_WAVES) {
+            float mm = 0.f;
+            if (pk.he_live[m[11] + q]) {
+                const float2 vi2 = pq(pk.he_src[m[11] + q]), vj2 = pq(pk.he_dst[m[11] + q]);
+                mm = 1.f - (rcp1p_exp2(vi2.x + vj2.y + bc) + rcp1p_exp2(vj2.x + vi2.y + bc));
+            }
+            const int64_t row = q0 + q;
+            FE[((int64_t)p * NH + row) * 16 + c] = mm;
+            FE[((int64_t)(NP + p) * NH + row) * 16 + c] = cc;
+            FE[((int64_t)(2 * NP + p) * NH + row) * 16 + c] = mm * cc;
+            FE[((int64_t)(3 * NP + p) * NH + row) * 16 + c] = mm - cc;
         }
     }
     if (STAGE) {
@@ -195,7 +212,8 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, M
 }
 
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
-                    const float *Hin, float *Hout, float *hbarV, float *hbarE, hipStream_t st, Profiler *prof) {
+                    const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
+                    hipStream_t st, Profiler *prof) {
     const int NP = D / 16;
     bool stage = true;
     int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, true);
@@ -212,7 +230,7 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
             UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_>),                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
         hipLaunchKernelGGL((edge_fwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, Hout,  \
-                           hbarV, hbarE);                                                                             \
+                           hbarV, hbarE, Ccur, FE);                                                                   \
     } while (0)
     if (last && stage) UPAMD_EF(true, true);
     else if (last) UPAMD_EF(true, false);
@@ -229,6 +247,8 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
 //   dS_v = G_v / (deg_v + 1e-6) (+ 1/2 dhbarE / e on the last layer)
 //   dm_(v,u) = dS_v + dS_u (+ the pointer-head gradient of that edge on the last layer)
 //   dP_v = sum_u 1/2 dm (1 - tanh^2(P_v + Q_u + b)),   dQ_v = sum_u 1/2 dm (1 - tanh^2(P_u + Q_v + b))
+// The pointer-head term touches only the row's candidate edges: it is added from the packer's per-node
+// candidate-incidence lists after the main walk, so the main loop stays branch-free.
 // ------------------------------------------------------------------------------------------
 template <bool LAST, bool STAGE>
 __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, MbView mb, int NP,
@@ -270,9 +290,20 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
         }
         __syncthreads();
     }
-    const float bc = bias[p * 16 + c];
-    const uint16_t *heg = pk.inc_he + 2 * (int64_t)m[10];
-    const float *dMg = LAST && dMhe ? dMhe + ((int64_t)p * mb.Nhe + mb.he_off[b]) * 16 + c : nullptr;
+    auto pq = [&](int u) -> float2 {
+        if (STAGE) return L.PQ[u * 16 + c];
+        return make_float2(C2 * Pg[u * 16 + c], C2 * Qg[u * 16 + c]);
+    };
+    auto ds = [&](int u) -> float {
+        if (STAGE) return L.X[u * 16 + c];
+        return Gg[u * 16 + c] / ((float)(L.rp[u + 1] - L.rp[u]) + 1e-6f) + extra;
+    };
+    const float bc = C2 * bias[p * 16 + c];
+    const bool heads_on = LAST && dMhe != nullptr && m[2] > 0;
+    const int32_t *hpg = pk.hinc_ptr + m[13];
+    const uint16_t *hnb = pk.hinc_nbr + 2 * (int64_t)m[11];
+    const uint16_t *hhe = pk.hinc_he + 2 * (int64_t)m[11];
+    const float *dMg = heads_on ? dMhe + ((int64_t)p * mb.Nhe + mb.he_off[b]) * 16 + c : nullptr;
     float sumdP = 0.f;
     const int nchunks = (n + 3) >> 2;
     for (int j = w; j < nchunks; j += EDGE_WAVES) {
@@ -281,41 +312,28 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
         const int v = L.ord[valid ? vi : n - 1];
         int k = L.rp[v];
         const int k1 = valid ? L.rp[v + 1] : k;
-        float pv, qv, sv;
-        if (STAGE) {
-            const float2 t2 = L.PQ[v * 16 + c];
-            pv = t2.x + bc; qv = t2.y + bc;
-            sv = L.X[v * 16 + c];
-        } else {
-            pv = Pg[v * 16 + c] + bc; qv = Qg[v * 16 + c] + bc;
-            sv = Gg[v * 16 + c] / ((float)(k1 - k) + 1e-6f) + extra;
-        }
-        float accP = 0.f, accQ = 0.f;
-        int hnext = 0xFFFF;
-        if (LAST && dMg && k < k1) hnext = heg[k];
+        const float2 own = pq(v);
+        const float pv = own.x + bc, qv = own.y + bc, sv = ds(v);
+        float accP = 0.f, accQ = 0.f;     // sums of dm * (r - r^2); 1 - tanh^2 = 4 (r - r^2)
         for (; k < k1; ++k) {
             const int u = L.nb[k];
-            float pu, qu, su;
-            if (STAGE) {
-                const float2 t2 = L.PQ[u * 16 + c];
-                pu = t2.x; qu = t2.y;
-                su = L.X[u * 16 + c];
-            } else {
-                pu = Pg[u * 16 + c]; qu = Qg[u * 16 + c];
-                su = Gg[u * 16 + c] / ((float)(L.rp[u + 1] - L.rp[u]) + 1e-6f) + extra;
+            const float2 nbv = pq(u);
+            const float dm = sv + ds(u);
+            const float r1 = rcp1p_exp2(pv + nbv.y), r2 = rcp1p_exp2(nbv.x + qv);
+            accP = fmaf(dm, fmaf(-r1, r1, r1), accP);
+            accQ = fmaf(dm, fmaf(-r2, r2, r2), accQ);
+        }
+        if (heads_on && valid) {
+            for (int hk = hpg[v]; hk < hpg[v + 1]; ++hk) {
+                const float2 nbv = pq(hnb[hk]);
+                const float dmh = dMg[(int64_t)hhe[hk] * 16];
+                const float r1 = rcp1p_exp2(pv + nbv.y), r2 = rcp1p_exp2(nbv.x + qv);
+                accP = fmaf(dmh, fmaf(-r1, r1, r1), accP);
+                accQ = fmaf(dmh, fmaf(-r2, r2, r2), accQ);
             }
-            float dm = sv + su;
-            if (LAST && dMg) {
-                const int h = hnext;
-                hnext = (k + 1 < k1) ? (int)heg[k + 1] : 0xFFFF;
-                if (h != 0xFFFF) dm += dMg[(int64_t)h * 16];
-            }
-            const float t1 = etanh(pv + qu), t2v = etanh(pu + qv);
-            accP = fmaf(dm, 1.f - t1 * t1, accP);
-            accQ = fmaf(dm, 1.f - t2v * t2v, accQ);
         }
         if (valid) {
-            const float dP = 0.5f * accP, dQ = 0.5f * accQ;
+            const float dP = 2.f * accP, dQ = 2.f * accQ;       // 1/2 * 4
             dPQ[((int64_t)(2 * p) * M + o + v) * 16 + c] = dP;
             dPQ[((int64_t)(2 * p + 1) * M + o + v) * 16 + c] = dQ;
             sumdP += dP;

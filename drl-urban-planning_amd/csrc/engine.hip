@@ -115,6 +115,9 @@ PackedView make_view(const void *packed_dev, const upamd_pack_layout &L) {
     v.he_live = reinterpret_cast<const uint8_t *>(b + L.off_he_live);
     v.rn_node = reinterpret_cast<const uint16_t *>(b + L.off_rn_node);
     v.order = reinterpret_cast<const uint16_t *>(b + L.off_order);
+    v.hinc_ptr = reinterpret_cast<const int32_t *>(b + L.off_hinc_ptr);
+    v.hinc_nbr = reinterpret_cast<const uint16_t *>(b + L.off_hinc_nbr);
+    v.hinc_he = reinterpret_cast<const uint16_t *>(b + L.off_hinc_he);
     v.numerical = reinterpret_cast<const float *>(b + L.off_numerical);
     v.cur = reinterpret_cast<const float *>(b + L.off_cur);
     v.Fn = L.numerical_dim;
@@ -360,8 +363,9 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         const std::string sl = std::to_string(l);
         CK(launch_gemm_nt(W("H" + std::to_string(l - 1)), mb.M, D, W("Wcat" + std::to_string(l - 1)), 2 * D, nullptr, nullptr,
                           W("PQ" + sl), 0, st, prof));
+        // the last layer also writes the land-use pointer-head inputs FE (needs C, computed above)
         CK(launch_edge_fwd(pk, mb, D, l == x.L, W("PQ" + sl), PR(P.edge_b[l - 1]), W("H" + std::to_string(l - 1)), W("H" + sl),
-                           W("hbarV"), W("hbarE"), st, prof));
+                           W("hbarV"), W("hbarE"), W("C"), (l == x.L && mb.Nhe > 0) ? W("FE") : nullptr, st, prof));
     }
     const float *HL = W("H" + std::to_string(x.L));
     // attention (state_encoder.py:150-161)
@@ -391,7 +395,6 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     }
     // pointer heads (policy.py:19-65)
     if (mb.Nhe > 0) {
-        CK(launch_he_feat_fwd(pk, mb, D, W("PQ" + std::to_string(x.L)), PR(P.edge_b[x.L - 1]), W("C"), W("FE"), st));
         CK(launch_gemm_nt(W("FE"), mb.Nhe, 4 * D, PR(P.land_w[0]), x.h0l, PR(P.land_b0), nullptr, W("hidl"), 1, st, prof));
         CK(launch_rowdot_pm(W("hidl"), mb.Nhe, x.h0l, PR(P.land_w[1]), W("z_he"), st));
     }

@@ -217,50 +217,9 @@ int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, co
 }
 
 // ------------------------------------------------------------------------------------------
-// Land-use pointer head input (state_encoder.py:207-210): for each candidate edge (i,j) of a
-// stage-0 row: m = last layer's message, features [m ; c ; m*c ; m-c] (c = current-node embedding).
-// Only land_use_mask candidates are materialised (all other logits carry probability 0).
+// Land-use pointer head (state_encoder.py:207-210): the candidate features FE = [m ; c ; m*c ; m-c] are
+// produced by the last layer's edge_fwd kernel (edge.hip); here is their backward.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void he_feat_fwd_kernel(PackedView pk, MbView mb, int NP,
-                                                          const float *__restrict__ PQ, const float *__restrict__ bias,
-                                                          const float *__restrict__ C, float *__restrict__ FE) {
-    // one workgroup per (graph, 16-column panel): 16 candidates x 16 columns in flight per pass
-    const int b = blockIdx.x / NP, p = blockIdx.x % NP, t = mb.idx[b];
-    const int32_t *m = META(t);
-    const int nh = m[2];
-    if (nh == 0) return;
-    const int64_t o = mb.node_off[b], M = mb.M, q0 = mb.he_off[b], NH = mb.Nhe;
-    const int c = threadIdx.x & 15;
-    const int D = NP * 16;
-    for (int q = threadIdx.x >> 4; q < nh; q += 16) {
-        const int i = pk.he_src[m[11] + q], j = pk.he_dst[m[11] + q];
-        const bool live = pk.he_live[m[11] + q] != 0;
-        const int64_t row = q0 + q;
-        {
-            const float bc = bias[p * 16 + c];
-            float mm = 0.f;
-            if (live) {
-                const float Pi = PQ[((int64_t)(2 * p) * M + o + i) * 16 + c], Qj = PQ[((int64_t)(2 * p + 1) * M + o + j) * 16 + c];
-                const float Pj = PQ[((int64_t)(2 * p) * M + o + j) * 16 + c], Qi = PQ[((int64_t)(2 * p + 1) * M + o + i) * 16 + c];
-                mm = 0.5f * (fast_tanh(Pi + Qj + bc) + fast_tanh(Pj + Qi + bc));
-            }
-            const float cc = C[(int64_t)b * D + p * 16 + c];
-            FE[((int64_t)p * NH + row) * 16 + c] = mm;
-            FE[((int64_t)(NP + p) * NH + row) * 16 + c] = cc;
-            FE[((int64_t)(2 * NP + p) * NH + row) * 16 + c] = mm * cc;
-            FE[((int64_t)(3 * NP + p) * NH + row) * 16 + c] = mm - cc;
-        }
-    }
-}
-
-int launch_he_feat_fwd(const PackedView &pk, const MbView &mb, int D, const float *PQ, const float *bias,
-                       const float *C, float *FE, hipStream_t st) {
-    if (mb.Nhe == 0) return 0;
-    hipLaunchKernelGGL(he_feat_fwd_kernel, dim3(mb.B * (D / 16)), dim3(256), 0, st, pk, mb, D / 16, PQ, bias, C, FE);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
-}
-
 // dMhe(pm)[row][d] = live * (g1 + g3*c + g4);   dC_head[b][d] = sum_rows (g2 + g3*m - g4)
 __global__ __launch_bounds__(256) void he_feat_bwd_kernel(PackedView pk, MbView mb, int NP,
                                                           const float *__restrict__ FE, const float *__restrict__ C,

@@ -22,7 +22,8 @@ struct PackedView {   // device pointers into the packed replay (upamd_pack_layo
     const float *X;
     const uint8_t *nmask;
     const int32_t *rowptr;
-    const uint16_t *inc_nbr, *inc_he, *he_src, *he_dst, *rn_node, *order;
+    const uint16_t *inc_nbr, *inc_he, *he_src, *he_dst, *rn_node, *order, *hinc_nbr, *hinc_he;
+    const int32_t *hinc_ptr;
     const uint8_t *he_live;
     const float *numerical, *cur;
     int Fn;
@@ -84,7 +85,8 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
 int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st);
 int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage);
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
-                    const float *Hin, float *Hout, float *hbarV, float *hbarE, hipStream_t st, Profiler *prof);
+                    const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
+                    hipStream_t st, Profiler *prof);
 int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
                     float *dbias_part, hipStream_t st, Profiler *prof);
@@ -93,8 +95,6 @@ int launch_attn_fwd(const PackedView &pk, const MbView &mb, int D, int heads, co
 int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     const float *alpha, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL, float *dr,
                     hipStream_t st);
-int launch_he_feat_fwd(const PackedView &pk, const MbView &mb, int D, const float *PQ, const float *bias,
-                       const float *C, float *FE, hipStream_t st);
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
                        const float *dFE, float *dMhe, float *dC_head, hipStream_t st);
 int launch_road_gather(const PackedView &pk, const MbView &mb, int D, const float *HL, float *XR, hipStream_t st);

@@ -175,6 +175,9 @@ extern "C" int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *p
     L.off_numerical = place(T * (int64_t)numerical_dim * 4);
     L.off_cur = place(T * UPAMD_NODE_PAD * 4);
     L.off_order = place(nodes * 2);
+    L.off_hinc_ptr = place((nodes + T) * 4);
+    L.off_hinc_nbr = place(2 * he * 2);
+    L.off_hinc_he = place(2 * he * 2);
     L.total_bytes = off;
     *layout = L;
     return UPAMD_OK;
@@ -200,6 +203,9 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
     float *numerical = reinterpret_cast<float *>(base + L.off_numerical);
     float *cur = reinterpret_cast<float *>(base + L.off_cur);
     uint16_t *order = reinterpret_cast<uint16_t *>(base + L.off_order);
+    int32_t *hinc_ptr = reinterpret_cast<int32_t *>(base + L.off_hinc_ptr);
+    uint16_t *hinc_nbr = reinterpret_cast<uint16_t *>(base + L.off_hinc_nbr);
+    uint16_t *hinc_he = reinterpret_cast<uint16_t *>(base + L.off_hinc_he);
     const int F = L.node_dim, Fn = L.numerical_dim;
 
     int rc = parallel_for(T, n_threads, [&](int64_t t) -> int {
@@ -266,6 +272,25 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
                 return (rp[a + 1] - rp[a]) > (rp[b + 1] - rp[b]);
             });
             std::memcpy(order + o_node, ord.data(), sizeof(uint16_t) * n);
+        }
+        // candidate-incidence lists: for every LIVE candidate edge h = (i, j): i <- (j, h), j <- (i, h)
+        {
+            int32_t *hp = hinc_ptr + o_rp;
+            for (int v = 0; v <= n; ++v) hp[v] = 0;
+            for (int q = 0; q < nh; ++q)
+                if (he_live[o_he + q]) {
+                    hp[he_src[o_he + q] + 1]++;
+                    hp[he_dst[o_he + q] + 1]++;
+                }
+            for (int v = 0; v < n; ++v) hp[v + 1] += hp[v];
+            std::vector<int32_t> hf(hp, hp + n);
+            uint16_t *hn = hinc_nbr + 2 * o_he, *hh = hinc_he + 2 * o_he;
+            for (int q = 0; q < nh; ++q)
+                if (he_live[o_he + q]) {
+                    const int i = he_src[o_he + q], j = he_dst[o_he + q];
+                    hn[hf[i]] = (uint16_t)j; hh[hf[i]] = (uint16_t)q; hf[i]++;
+                    hn[hf[j]] = (uint16_t)i; hh[hf[j]] = (uint16_t)q; hf[j]++;
+                }
         }
         // per-state dense fields
         std::memcpy(numerical + t * Fn, s.numerical, sizeof(float) * Fn);

@@ -33,7 +33,8 @@ class PackLayout(C.Structure):
                 ('off_inc_nbr', C.c_int64), ('off_inc_he', C.c_int64), ('off_he_src', C.c_int64),
                 ('off_he_dst', C.c_int64), ('off_he_live', C.c_int64), ('off_he_slot', C.c_int64),
                 ('off_rn_node', C.c_int64), ('off_numerical', C.c_int64), ('off_cur', C.c_int64),
-                ('off_order', C.c_int64), ('total_bytes', C.c_int64)]
+                ('off_order', C.c_int64), ('off_hinc_ptr', C.c_int64), ('off_hinc_nbr', C.c_int64),
+                ('off_hinc_he', C.c_int64), ('total_bytes', C.c_int64)]
 
 
 class Minibatch(C.Structure):

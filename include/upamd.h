@@ -109,6 +109,9 @@ typedef struct upamd_pack_layout {
     int64_t off_cur;       /* f32   [T][UPAMD_NODE_PAD]                                          */
     int64_t off_order;     /* u16   [total_nodes]       per graph: node ids sorted by degree (descending,
                                                          stable) -- the processing order of the edge kernels */
+    int64_t off_hinc_ptr;  /* int32 [total_nodes + T]   per graph n+1 offsets into the candidate-incidence lists */
+    int64_t off_hinc_nbr;  /* u16   [2*total_he]        per node: neighbour across each incident LIVE candidate edge */
+    int64_t off_hinc_he;   /* u16   [2*total_he]        ... and that candidate's local index                         */
     int64_t total_bytes;
 } upamd_pack_layout;
 

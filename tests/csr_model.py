@@ -68,6 +68,24 @@ def pack_state(state, action):
         fill[j] += 1
     rn_node = np.flatnonzero(road_mask) if stage_id == 1 else np.zeros(0, dtype=np.int64)
     order = np.argsort(-cnt, kind='stable')          # edge-kernel processing order: degree descending, stable
+    # candidate-incidence lists: live candidate h = (i, j): i <- (j, h), j <- (i, h)
+    hcnt = np.zeros(n, dtype=np.int64)
+    for q in range(he_slot.size):
+        if he_live[q]:
+            hcnt[he_src[q]] += 1
+            hcnt[he_dst[q]] += 1
+    hinc_ptr = np.zeros(n + 1, dtype=np.int64)
+    hinc_ptr[1:] = np.cumsum(hcnt)
+    hfill = hinc_ptr[:-1].copy()
+    hinc_nbr = np.zeros(int(hinc_ptr[-1]), dtype=np.int64)
+    hinc_he = np.zeros(int(hinc_ptr[-1]), dtype=np.int64)
+    for q in range(he_slot.size):
+        if he_live[q]:
+            i, j = he_src[q], he_dst[q]
+            hinc_nbr[hfill[i]], hinc_he[hfill[i]] = j, q
+            hfill[i] += 1
+            hinc_nbr[hfill[j]], hinc_he[hfill[j]] = i, q
+            hfill[j] += 1
     act = -1
     if stage_id == 0:
         a = int(action[0])
@@ -79,7 +97,8 @@ def pack_state(state, action):
         act = int(pos[0]) if pos.size else -1
     return dict(n=n, e=e, stage=stage_id, X=feat[:n].astype(np.float64), nmask=node_mask[:n].copy(),
                 row_ptr=row_ptr, inc_nbr=inc_nbr, inc_he=inc_he, he_src=he_src, he_dst=he_dst, he_live=he_live,
-                he_slot=he_slot, rn_node=rn_node, act=act, order=order, numerical=numerical.astype(np.float64).ravel(),
+                he_slot=he_slot, rn_node=rn_node, act=act, order=order, hinc_ptr=hinc_ptr, hinc_nbr=hinc_nbr,
+                hinc_he=hinc_he, numerical=numerical.astype(np.float64).ravel(),
                 cur=cur.astype(np.float64), stage_vec=stage.astype(np.float64), pad_n=feat.shape[0],
                 pad_e=edge_index.shape[0], n_mask=int(node_mask.sum()))
 

@@ -23,6 +23,9 @@ def _check(replay):
     he_slot = pk.section('he_slot', np.int32, L.total_he)
     rn_node = pk.section('rn_node', np.uint16, L.total_rn)
     order = pk.section('order', np.uint16, L.total_nodes)
+    hinc_ptr = pk.section('hinc_ptr', np.int32, L.total_nodes + T)
+    hinc_nbr = pk.section('hinc_nbr', np.uint16, 2 * L.total_he)
+    hinc_he = pk.section('hinc_he', np.uint16, 2 * L.total_he)
     numerical = pk.section('numerical', np.float32, T * synth.NUMERICAL_DIM).reshape(T, -1)
     cur = pk.section('cur', np.float32, T * native.NODE_PAD).reshape(T, -1)
     meta_dev = pk.section('meta', np.int32, T * native.META_STRIDE).reshape(T, -1)
@@ -48,6 +51,10 @@ def _check(replay):
         np.testing.assert_array_equal(he_slot[ho:ho + m[2]], g['he_slot'])
         np.testing.assert_array_equal(rn_node[ro:ro + m[3]], g['rn_node'])
         np.testing.assert_array_equal(order[no:no + n], g['order'])
+        np.testing.assert_array_equal(hinc_ptr[rp:rp + n + 1], g['hinc_ptr'])
+        nhi = int(g['hinc_ptr'][-1])
+        np.testing.assert_array_equal(hinc_nbr[2 * ho:2 * ho + nhi], g['hinc_nbr'])
+        np.testing.assert_array_equal(hinc_he[2 * ho:2 * ho + nhi], g['hinc_he'])
         np.testing.assert_array_equal(numerical[t], replay.states[t][0])
         np.testing.assert_array_equal(cur[t, :synth.NODE_DIM], replay.states[t][3])
     return pk
