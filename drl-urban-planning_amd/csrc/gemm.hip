@@ -278,7 +278,7 @@ int launch_gemm_nt(const float *A, int64_t M, int K, const float *W, int N, cons
 template <int BJ, int WI, int WJ, bool IN_RM>
 __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restrict__ A, int I, int64_t lda,
                                                            const float *__restrict__ Bm, int J, int64_t ldb, int64_t M,
-                                                           int64_t chunk, float *__restrict__ slabs, int IT, int JT) {
+                                                           int64_t chunk, float *__restrict__ slabs, int IT, int JT, int S) {
     constexpr int BI = 128, PS = 272;   // panel stride in LDS: 16 rows * 16 + 16 pad (bank shift 16)
     constexpr int WAVES_J = BJ / WJ;
     constexpr int TI = WI / 32, TJ = WJ / 32;
@@ -288,8 +288,12 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
     __shared__ __attribute__((aligned(16))) float As[2][PA * PS];
     __shared__ __attribute__((aligned(16))) float Bs[2][PB * PS];
 
+    // XCD-aware order: workgroup id -> XCD id % 8; all tiles of one row-split run on the same XCD so the
+    // split's A / B row chunks are fetched from HBM once and shared through that XCD's L2
     const int tiles = IT * JT;
-    const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
+    if (split >= S) return;
     const int it = tile / JT, jt = tile % JT;
     const int i0 = it * BI, j0 = jt * BJ;
     const int64_t r0 = (int64_t)split * chunk;
@@ -440,16 +444,16 @@ static void launch_tn_layout(const GemmTN &g, int S, int64_t chunk, hipStream_t 
     const int IT = g.I / 128;
     if (g.J % 128 == 0) {
         const int JT = g.J / 128;
-        hipLaunchKernelGGL((gemm_tn_mfma_kernel<128, 64, 64, IN_RM>), dim3(S * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
-                           g.ldb, g.M, chunk, g.slabs, IT, JT);
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<128, 64, 64, IN_RM>), dim3((S + 7) / 8 * 8 * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
+                           g.ldb, g.M, chunk, g.slabs, IT, JT, S);
     } else if (g.J % 64 == 0) {
         const int JT = g.J / 64;
-        hipLaunchKernelGGL((gemm_tn_mfma_kernel<64, 64, 32, IN_RM>), dim3(S * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
-                           g.ldb, g.M, chunk, g.slabs, IT, JT);
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<64, 64, 32, IN_RM>), dim3((S + 7) / 8 * 8 * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
+                           g.ldb, g.M, chunk, g.slabs, IT, JT, S);
     } else {
         const int JT = g.J / 32;
-        hipLaunchKernelGGL((gemm_tn_mfma_kernel<32, 32, 32, IN_RM>), dim3(S * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
-                           g.ldb, g.M, chunk, g.slabs, IT, JT);
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<32, 32, 32, IN_RM>), dim3((S + 7) / 8 * 8 * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
+                           g.ldb, g.M, chunk, g.slabs, IT, JT, S);
     }
 }
 
