@@ -274,6 +274,61 @@ def test_wide_model_matches_oracle(D, L, heads, n_range, T):
     _check_grads(eng, grads, lambda nm: (P[nm].grad if P[nm].grad is not None else torch.zeros_like(P[nm])).numpy())
 
 
+def test_maximum_size_graphs_and_mixed_pads():
+    """Graphs at the padding limits of the shipped configs (1000 nodes / 3000 edges, no padding left: the
+    un-staged fallback of the edge kernels) mixed with small graphs that use different pad sizes."""
+    from drl_urban_planning_amd import synth
+    cfg = helpers.make_cfg(D=32, L=2, heads=2, S=(64, 16), max_nodes=1000, max_edges=3000)
+    _, _, ac = helpers.build_product(cfg, seed=11)
+    sd = helpers.perturbed_state_dict(ac, 12, scale=0.05)
+    states, actions = [], []
+    for i, (n, e, N, E, stage) in enumerate([(1000, 3000, 1000, 3000, 0), (40, 100, 64, 128, 0), (1000, 3000, 1000, 3000, 1),
+                                              (700, 2800, 1500, 4000, 0), (25, 60, 1000, 3000, 1)]):
+        rng = np.random.default_rng(1000 + i)
+        s, a = synth.make_state(rng, n, e, N, E, stage)
+        states.append(s)
+        actions.append(a)
+    actions = np.stack(actions)
+    T = len(states)
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, states, actions)
+    value, logp, ent = _forward(eng, pk, mb, flat)
+    P = helpers.oracle_params(sd)
+    g = torch.Generator().manual_seed(5)
+    adv, ret = torch.randn(T, 1, generator=g), torch.randn(T, 1, generator=g)
+    # the oracle needs equal pads inside one call: evaluate row by row (rows are independent)
+    v0, lp0, en0 = [], [], []
+    with torch.no_grad():
+        for b in range(T):
+            xs = orc.tensorfy(states[b:b + 1])
+            v0.append(orc.value_forward(P, xs, 2))
+            lp, en = orc.get_log_prob_entropy(P, xs, torch.from_numpy(actions[b:b + 1]).float(), 2)
+            lp0.append(lp)
+            en0.append(en)
+    v0, lp0, en0 = torch.cat(v0), torch.cat(lp0), torch.cat(en0)
+    np.testing.assert_allclose(value.cpu().numpy(), v0[:, 0].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp0[:, 0].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ent.cpu().numpy(), en0[:, 0].numpy(), rtol=1e-4, atol=1e-5)
+    old = lp0 + 0.3 * torch.randn(T, 1, generator=g)
+    loss = 0
+    for b in range(T):
+        xs = orc.tensorfy(states[b:b + 1])
+        vb = orc.value_forward(P, xs, 2)
+        lpb, enb = orc.get_log_prob_entropy(P, xs, torch.from_numpy(actions[b:b + 1]).float(), 2)
+        ratio = torch.exp(lpb - old[b:b + 1])
+        surr = torch.min(ratio * adv[b:b + 1], torch.clamp(ratio, 0.8, 1.2) * adv[b:b + 1])
+        loss = loss + (-surr.sum() + 0.5 * (vb - ret[b:b + 1]).pow(2).sum() - 0.01 * enb.sum()) / T
+    loss.backward()
+    dvalue, dlogp, dent = (torch.empty(T, device=DEV) for _ in range(3))
+    losses = torch.zeros(4, device=DEV)
+    eng.ppo_loss(T, value, logp, ent, adv[:, 0].to(DEV), ret[:, 0].to(DEV), old[:, 0].to(DEV), torch.ones(T, device=DEV), 0.2,
+                 0.5, 0.01, 1.0 / T, 1.0 / T, dvalue, dlogp, dent, losses)
+    assert abs(float(losses[0]) - float(loss)) <= 1e-4 * max(1.0, abs(float(loss)))
+    grads = torch.zeros(eng.n_floats, device=DEV)
+    eng.backward(pk, mb, flat, dvalue, dlogp, dent, grads)
+    torch.cuda.synchronize()
+    _check_grads(eng, grads, lambda nm: (P[nm].grad if P[nm].grad is not None else torch.zeros_like(P[nm])).numpy())
+
+
 def test_full_size_properties():
     """BASELINE-size minibatch (2048 HLG-shaped graphs, D=256, L=3) through size-independent properties:
     padding invariance, row-order invariance (bit-exact), run-to-run determinism of the gradients."""
