@@ -123,9 +123,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    ctx = DistContext.from_env(device=dev)
+    # one process per GPU; UPAMD_DIST_BACKEND=gloo + fewer GPUs than ranks is a debugging aid only (lets the
+    # multi-process path be exercised on a 1-GPU box), the real launch is one rank per GPU over RCCL
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    ctx = DistContext.from_env(backend=os.environ.get('UPAMD_DIST_BACKEND'), device=dev)
     if ctx.world != args.gpus:
         raise RuntimeError('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, ctx.world))
     rank = ctx.rank
@@ -206,7 +209,9 @@ def main():
     flops_sample = algorithmic_flops_per_sample(nodes_per_sample, edges_per_sample, w['D'], w['L'])
     out['algorithmic'] = {'flops_per_sample_step': flops_sample, 'tflops': value / ctx.world * flops_sample / 1e12,
                           'frac_of_fp32_mfma_peak': value / ctx.world * flops_sample / 1e12 / PEAK_FP32_MFMA_TFLOPS}
-    dom = 'gemm_nt_128' if 'gemm_nt_128' in kern else (sorted(kern, key=lambda k: -kern[k]['total_ms'])[0] if kern else None)
+    mfma_kernels = {k: v for k, v in kern.items() if v['flops'] > 0}
+    dom = 'gemm_nt_128' if 'gemm_nt_128' in kern else (sorted(mfma_kernels, key=lambda k: -mfma_kernels[k]['total_ms'])[0]
+                                                       if mfma_kernels else None)
     if dom is not None:
         st = kern[dom]
         ach = st['flops'] / (st['total_ms'] * 1e-3) / 1e12
