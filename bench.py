@@ -115,6 +115,7 @@ def main():
     ap.add_argument('--workload', default='hlg_d256', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--sub-batches', type=int, default=1, help='2 = overlap the two halves of a minibatch on two streams')
     args = ap.parse_args()
 
     from drl_urban_planning_amd import PPOUpdater, synth, DistContext
@@ -137,7 +138,8 @@ def main():
     policy_net, value_net, ac = build_networks(cfg, seed=0)              # identical weights on every rank
     ac.to(dev)
     up = PPOUpdater(policy_net, value_net, lr=4e-4, eps=1e-5, weight_decay=0.0, gamma=1.0, tau=0.0, clip_epsilon=0.2,
-                    value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4, mini_batch_size=w['B'], dist_ctx=ctx)
+                    value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4, mini_batch_size=w['B'], dist_ctx=ctx,
+                    sub_batches=args.sub_batches)
     need = args.steps + args.warmup
     T = max(w['T'], w['B'] * ((need + 3) // 4))
     t_gen = time.time()

@@ -54,7 +54,8 @@ class PPOUpdater:
 
     def __init__(self, policy_net, value_net, lr=4e-4, eps=1e-5, weight_decay=0.0, betas=(0.9, 0.999), gamma=1.0,
                  tau=0.0, clip_epsilon=0.2, value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4,
-                 mini_batch_size=256, batch_stage=False, max_grad_norm=1.0, dist_ctx=None, pack_threads=0):
+                 mini_batch_size=256, batch_stage=False, max_grad_norm=1.0, dist_ctx=None, pack_threads=0,
+                 sub_batches=1):
         self.policy_net, self.value_net = policy_net, value_net
         self.backend = backend_of(policy_net)
         self.lr, self.eps, self.weight_decay, self.betas = lr, eps, weight_decay, betas
@@ -66,6 +67,12 @@ class PPOUpdater:
         self.max_grad_norm = max_grad_norm
         self.dist = dist_ctx or DistContext()
         self.pack_threads = pack_threads
+        # sub_batches = 2: the two halves of every minibatch run on two HIP streams so the MFMA-bound GEMMs of
+        # one half overlap the VALU-bound message passing of the other; their gradients are summed afterwards
+        # (same arithmetic as two data-parallel ranks on one GPU)
+        self.sub_batches = int(sub_batches)
+        if self.sub_batches not in (1, 2) or mini_batch_size % self.sub_batches != 0:
+            raise ValueError('sub_batches must be 1 or 2 and divide mini_batch_size')
         self.loss_iter = 0
         self.clip_pending = True              # the generator lists are live until the first call
         self.group_steps = [0, 0, 0]          # Adam step counts: encoder+value / land head / road head
@@ -100,6 +107,9 @@ class PPOUpdater:
         if getattr(self, '_rowbuf_B', None) != B:
             self._rows = [torch.empty(B, device=dev) for _ in range(6)]   # value, logp, ent, dvalue, dlogp, dent
             self._rowbuf_B = B
+        if self.sub_batches > 1 and getattr(self, '_streams', None) is None:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.sub_batches)]
+            self._sub_grads = [torch.zeros_like(self.grads) for _ in range(self.sub_batches)]
         return engine
 
     def detach(self):
@@ -149,7 +159,11 @@ class PPOUpdater:
             it.order = np.concatenate([it.order[st == 0], it.order[st == 1]])
         nb = int(math.floor(T / B))
         row_lists = [it.order[i * B:(i + 1) * B] for i in range(nb)]
-        sched = packer.Schedule(it.packed, row_lists, dev)
+        if self.sub_batches > 1:      # schedule items 2k, 2k+1 = the two halves of minibatch k
+            h = B // self.sub_batches
+            sched = packer.Schedule(it.packed, [r[j * h:(j + 1) * h] for r in row_lists for j in range(self.sub_batches)], dev)
+        else:
+            sched = packer.Schedule(it.packed, row_lists, dev)
         # per-minibatch global counts (rows, rows with exps != 0, land-use rows, road rows): known on the
         # host, exchanged with ONE tiny all-reduce per epoch when data-parallel
         counts = [[B] * nb, [int((it.exps_np[r] != 0).sum()) for r in row_lists],
@@ -165,16 +179,39 @@ class PPOUpdater:
         engine, B = self.engine, self.mini_batch_size
         value_b, logp_b, ent_b, dvalue, dlogp, dent = self._rows
         nflt = engine.n_floats
-        mb, _ = ep.sched.minibatch(k)
-        idx = ep.order_dev[k * B:(k + 1) * B]
         inv_rows = 1.0 / ep.rows_glob[k]
         inv_ind = 1.0 / ep.ind_glob[k] if ep.ind_glob[k] > 0 else float('nan')
-        engine.forward(it.packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
-        engine.ppo_loss(B, value_b, logp_b, ent_b, it.adv[idx], it.ret[idx], it.old_logp[idx], it.exps[idx],
-                        self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
-                        dvalue, dlogp, dent, self.grads[nflt:])
-        self.grads[:nflt].zero_()
-        engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
+        if self.sub_batches == 1:
+            mb, _ = ep.sched.minibatch(k)
+            idx = ep.order_dev[k * B:(k + 1) * B]
+            engine.forward(it.packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
+            engine.ppo_loss(B, value_b, logp_b, ent_b, it.adv[idx], it.ret[idx], it.old_logp[idx], it.exps[idx],
+                            self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
+                            dvalue, dlogp, dent, self.grads[nflt:])
+            self.grads[:nflt].zero_()
+            engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
+        else:
+            S, h = self.sub_batches, B // self.sub_batches
+            main = torch.cuda.current_stream()
+            ready = main.record_event()
+            for j in range(S):
+                st = self._streams[j]
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    mb, _ = ep.sched.minibatch(S * k + j)
+                    lo, hi = j * h, (j + 1) * h
+                    idx = ep.order_dev[k * B + lo:k * B + hi]
+                    g = self._sub_grads[j]
+                    engine.forward(it.packed, mb, self.flat, value_b[lo:hi], logp_b[lo:hi], ent_b[lo:hi], keep=True, slot=j)
+                    engine.ppo_loss(h, value_b[lo:hi], logp_b[lo:hi], ent_b[lo:hi], it.adv[idx], it.ret[idx],
+                                    it.old_logp[idx], it.exps[idx], self.clip_epsilon, self.value_pred_coef,
+                                    self.entropy_coef, inv_rows, inv_ind, dvalue[lo:hi], dlogp[lo:hi], dent[lo:hi],
+                                    g[nflt:])
+                    g[:nflt].zero_()
+                    engine.backward(it.packed, mb, self.flat, dvalue[lo:hi], dlogp[lo:hi], dent[lo:hi], g, slot=j)
+            for j in range(S):
+                main.wait_stream(self._streams[j])
+            torch.add(self._sub_grads[0], self._sub_grads[1], out=self.grads)
         if self.dist.world > 1:
             self.dist.all_reduce_sum(self.grads)          # ONE collective per optimizer step
         if loss_out is not None:

@@ -32,7 +32,7 @@ class NativeEngine:
         self.handle = h
         self.table, self.n_floats, self.groups = native.param_table(desc)
         self.index = {name: (off, rows, cols, grp) for name, off, rows, cols, grp in self.table}
-        self.ws = None
+        self.ws_slots = {}        # scratch workspaces; slot > 0 = concurrent sub-batches on side streams
 
     def __del__(self):
         try:
@@ -65,29 +65,36 @@ class NativeEngine:
                 else flat[off:off + rows] for name, off, rows, cols, _ in self.table}
 
     # ---- workspace
-    def ensure_workspace(self, mb):
+    @property
+    def ws(self):
+        return self.ws_slots.get(0)
+
+    def ensure_workspace(self, mb, slot=0):
         need = C.c_int64()
         native.check(self.lib.upamd_workspace_bytes(self.handle, C.byref(mb), 1, C.byref(need)), 'upamd_workspace_bytes')
-        if self.ws is None or self.ws.numel() < need.value:
-            self.ws = None
-            self.ws = torch.empty(int(need.value * 1.05) + 4096, dtype=torch.uint8, device=self.device)
-        return self.ws
+        ws = self.ws_slots.get(slot)
+        if ws is None or ws.numel() < need.value:
+            self.ws_slots[slot] = None
+            ws = torch.empty(int(need.value * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+            self.ws_slots[slot] = ws
+        return ws
 
-    def _ws_args(self):
-        base = self.ws.data_ptr()
+    def _ws_args(self, slot=0):
+        ws = self.ws_slots[slot]
+        base = ws.data_ptr()
         aligned = (base + 255) // 256 * 256
-        return C.c_void_p(aligned), C.c_int64(self.ws.numel() - (aligned - base)), aligned - base
+        return C.c_void_p(aligned), C.c_int64(ws.numel() - (aligned - base)), aligned - base
 
     # ---- forward / backward
-    def forward(self, packed, mb, flat_params, value, logp, ent, keep=True):
-        self.ensure_workspace(mb)
-        wsp, wsb, _ = self._ws_args()
+    def forward(self, packed, mb, flat_params, value, logp, ent, keep=True, slot=0):
+        self.ensure_workspace(mb, slot)
+        wsp, wsb, _ = self._ws_args(slot)
         native.check(self.lib.upamd_forward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
                                             _ptr(flat_params), wsp, wsb, _ptr(value), _ptr(logp), _ptr(ent),
                                             1 if keep else 0, _stream()), 'upamd_forward')
 
-    def backward(self, packed, mb, flat_params, dvalue, dlogp, dent, grads):
-        wsp, wsb, _ = self._ws_args()
+    def backward(self, packed, mb, flat_params, dvalue, dlogp, dent, grads, slot=0):
+        wsp, wsb, _ = self._ws_args(slot)
         native.check(self.lib.upamd_backward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
                                              _ptr(flat_params), wsp, wsb, _ptr(dvalue), _ptr(dlogp), _ptr(dent),
                                              _ptr(grads), _stream()), 'upamd_backward')
