@@ -126,8 +126,12 @@ class PPOUpdater:
         engine, dev = self.engine, self.engine.device
         agent = self.policy_net.agent
         T = len(batch.states)
+        if not hasattr(self, '_pack_cache'):
+            self._pack_cache = {}
         packed = packer.pack_replay(batch.states, np.asarray(batch.actions), agent.node_dim,
-                                    agent.numerical_feature_size, n_threads=self.pack_threads).to(dev)
+                                    agent.numerical_feature_size, n_threads=self.pack_threads,
+                                    reuse=self._pack_cache).to(dev)
+        torch.cuda.current_stream(dev).synchronize()      # the pinned staging buffer may be refilled next iteration
         rewards = self._to_f32(batch.rewards, dev)
         masks = self._to_f32(batch.masks, dev)
         exps_np = np.asarray(batch.exps, dtype=np.float32)

@@ -99,8 +99,13 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError('native library %s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
-                           '(or `make -C %s`). The HIP path has no Python fallback.' % (LIB_PATH, CSRC))
+        # not built yet: compile it in-tree (hipcc is part of the image); there is no Python fallback to run instead
+        try:
+            build()
+        except Exception as exc:
+            raise RuntimeError('native library %s not found and building it failed (%s). Run `python -c "import '
+                               '__graft_entry__ as g; g.build()"` (or `make -C %s`). The HIP path has no Python '
+                               'fallback.' % (LIB_PATH, exc, CSRC))
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         try:
