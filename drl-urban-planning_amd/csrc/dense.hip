@@ -295,6 +295,16 @@ int launch_scale(float *dst, int64_t n, float alpha, hipStream_t st) {
     UPAMD_HIP(hipGetLastError());
     return 0;
 }
+// dst[p*16 + c] += src[(2p)*16 + c]: the P half of a [2D] vector in P/Q panel order
+__global__ void add_p_panels_kernel(float *__restrict__ dst, const float *__restrict__ src, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D) dst[i] += src[(2 * (i >> 4)) * 16 + (i & 15)];
+}
+int launch_add_p_panels(float *dst, const float *src, int D, hipStream_t st) {
+    hipLaunchKernelGGL(add_p_panels_kernel, dim3((D + 255) / 256), dim3(256), 0, st, dst, src, D);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
 int launch_axpy(float *dst, const float *src, int64_t n, float alpha, hipStream_t st) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n, alpha);

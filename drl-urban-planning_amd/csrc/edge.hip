@@ -304,7 +304,7 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
     const uint16_t *hnb = pk.hinc_nbr + 2 * (int64_t)m[11];
     const uint16_t *hhe = pk.hinc_he + 2 * (int64_t)m[11];
     const float *dMg = heads_on ? dMhe + ((int64_t)p * mb.Nhe + mb.he_off[b]) * 16 + c : nullptr;
-    float sumdP = 0.f;
+    float sumdP = 0.f, sumdQ = 0.f;
     const int nchunks = (n + 3) >> 2;
     for (int j = w; j < nchunks; j += EDGE_WAVES) {
         const int vi = 4 * j + g;
@@ -337,17 +337,23 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
             dPQ[((int64_t)(2 * p) * M + o + v) * 16 + c] = dP;
             dPQ[((int64_t)(2 * p + 1) * M + o + v) * 16 + c] = dQ;
             sumdP += dP;
+            sumdQ += dQ;
         }
     }
-    sumdP += __shfl_xor(sumdP, 16);
-    sumdP += __shfl_xor(sumdP, 32);
-    if (g == 0) L.red[w * 16 + c] = sumdP;
+    // per-graph column sums of dP and dQ (bias gradient = sum dP; layer 1 also needs sum dQ), P/Q panel order
+    sumdP += __shfl_xor(sumdP, 16); sumdP += __shfl_xor(sumdP, 32);
+    sumdQ += __shfl_xor(sumdQ, 16); sumdQ += __shfl_xor(sumdQ, 32);
+    if (g == 0) {
+        L.red[(w * 2 + 0) * 16 + c] = sumdP;
+        L.red[(w * 2 + 1) * 16 + c] = sumdQ;
+    }
     __syncthreads();
-    if (tid < 16) {
+    if (tid < 32) {
+        const int which = tid >> 4, cc = tid & 15;
         float tot = 0.f;
 #pragma unroll
-        for (int q = 0; q < EDGE_WAVES; ++q) tot += L.red[q * 16 + tid];
-        dbias_part[(int64_t)b * (NP * 16) + p * 16 + tid] = tot;
+        for (int q = 0; q < EDGE_WAVES; ++q) tot += L.red[(q * 2 + which) * 16 + cc];
+        dbias_part[(int64_t)b * (NP * 32) + (2 * p + which) * 16 + cc] = tot;
     }
 }
 

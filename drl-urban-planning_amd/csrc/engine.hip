@@ -44,7 +44,7 @@ Dims dims_of(const upamd_model_desc &d) {
 int64_t slab_floats(const Dims &x, int64_t B, int64_t M, int64_t Nhe, int64_t Nrn) {
     int64_t s = 0;
     s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, x.D, M) * 2 * x.D * x.D);          // GCN weight grads
-    s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, 32, M) * x.D * 32);                    // node encoder
+    s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, 32, M) * 2 * x.D * 32);            // node encoder (G^1 and dPQ_1 parts)
     s = std::max<int64_t>(s, (int64_t)tn_splits(4 * x.D, x.h0l, Nhe) * 4 * x.D * x.h0l);    // land head
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.h0r, Nrn) * x.D * x.h0r);            // road head
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.D, B) * x.D * x.D);                  // per-sample D x D layers
@@ -71,6 +71,8 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     add("Wkk", (int64_t)D * D); add("Wvv", (int64_t)D * D); add("bvv", D);
     add("W1T", 4LL * D * x.h0l); add("R1T", (int64_t)D * x.h0r);
     add("wt", (int64_t)x.maxdim * x.maxdim);          // transposed-weight scratch of the per-sample layers
+    add("W1c", 2LL * D * 32); add("b1c", 2LL * D);    // first GCN layer collapsed onto the raw node features
+    add("Tn", 2LL * D * 32); add("cs1", 2LL * D);     // backward of that collapse
     add("Xp", 2 * M * 16);
     add("U0", B * x.Fn);
     for (int i = 0; i < d.n_num; ++i) add("U" + std::to_string(i + 1), B * d.num_hidden[i]);
@@ -94,7 +96,7 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     add("dWkk", (int64_t)D * D); add("dWvv", (int64_t)D * D); add("dbvv", D);
     add("dz_he", NH); add("dz_rn", NR); add("dprel", NH * x.h0l); add("dFE", NH * 4 * D); add("dMhe", NH * D);
     add("dprer", NR * x.h0r); add("dXR", NR * D);
-    add("G0", M * D); add("G1", M * D); add("dPQ", M * 2 * D); add("dbias_part", B * D);
+    add("G0", M * D); add("G1", M * D); add("dPQ", M * 2 * D); add("dbias_part", B * 2 * D);
     add("slabs", slab_floats(x, B, M, NH, NR));
     const int64_t maxrows = std::max(M, std::max(NH, NR));
     add("cs_part", (int64_t)colsum_pm_blocks(maxrows) * std::max(4 * D, 64));
@@ -358,11 +360,17 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     // node encoder on all nodes and on the current node (state_encoder.py:189-191)
     CK(launch_gemm_nt(W("Xp"), mb.M, 32, W("We_pad"), D, PR(P.node_b), nullptr, W("H0"), 0, st, prof));
     CK(launch_smm(B, D, x.F, W("curg"), UPAMD_NODE_PAD, 1, PR(P.node_w), 1, x.F, PR(P.node_b), W("C"), D, 0, 0, 1.f, st));
-    // GCN layers (state_encoder.py:194-197)
+    // GCN layers (state_encoder.py:194-197).  Layer 1 reads its P/Q straight from the raw node features:
+    // PQ_1 = H_0 Wcat_1^T = Xp (Wcat_1 We)^T + Wcat_1 be  (K = 32 instead of D: saves one full-size node GEMM)
+    CK(lin.nn(W("Wcat0"), D, 2 * D, D, W("We_pad"), 32, W("W1c"), 32));
+    CK(launch_smm(1, 2 * D, D, PR(P.node_b), D, 1, W("Wcat0"), 1, D, nullptr, W("b1c"), 2 * D, 0, 0, 1.f, st));
     for (int l = 1; l <= x.L; ++l) {
         const std::string sl = std::to_string(l);
-        CK(launch_gemm_nt(W("H" + std::to_string(l - 1)), mb.M, D, W("Wcat" + std::to_string(l - 1)), 2 * D, nullptr, nullptr,
-                          W("PQ" + sl), 0, st, prof));
+        if (l == 1)
+            CK(launch_gemm_nt(W("Xp"), mb.M, 32, W("W1c"), 2 * D, W("b1c"), nullptr, W("PQ1"), 0, st, prof));
+        else
+            CK(launch_gemm_nt(W("H" + std::to_string(l - 1)), mb.M, D, W("Wcat" + std::to_string(l - 1)), 2 * D, nullptr, nullptr,
+                              W("PQ" + sl), 0, st, prof));
         // the last layer also writes the land-use pointer-head inputs FE (needs C, computed above)
         CK(launch_edge_fwd(pk, mb, D, l == x.L, W("PQ" + sl), PR(P.edge_b[l - 1]), W("H" + std::to_string(l - 1)), W("H" + sl),
                            W("hbarV"), W("hbarE"), W("C"), (l == x.L && mb.Nhe > 0) ? W("FE") : nullptr, st, prof));
@@ -555,16 +563,29 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         const bool last = (l == x.L);
         CK(launch_edge_bwd(pk, mb, D, last, W("PQ" + sl), PR(P.edge_b[l - 1]), G, dhbarE, x.W,
                            (last && mb.Nhe > 0) ? W("dMhe") : nullptr, W("dPQ"), W("dbias_part"), st, prof));
-        CK(launch_reduce_rows_add(W("dbias_part"), B, D, GR(P.edge_b[l - 1]), st));
+        // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
+        UPAMD_HIP(hipMemsetAsync(W("cs1"), 0, sizeof(float) * (size_t)2 * D, st));
+        CK(launch_reduce_rows_add(W("dbias_part"), B, 2 * D, W("cs1"), st));
+        CK(launch_add_p_panels(GR(P.edge_b[l - 1]), W("cs1"), D, st));
         CK(launch_gemm_tn(W("dPQ"), 2 * D, W("H" + sp), D, mb.M, W("slabs"), &S, st, prof));
         CK(launch_reduce_slabs(W("slabs"), S, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D, st));
-        CK(launch_gemm_nt(W("dPQ"), mb.M, 2 * D, W("WcatT" + sp), D, nullptr, G, Gn, 0, st, prof));
-        std::swap(G, Gn);
+        if (l > 1) {
+            CK(launch_gemm_nt(W("dPQ"), mb.M, 2 * D, W("WcatT" + sp), D, nullptr, G, Gn, 0, st, prof));
+            std::swap(G, Gn);
+        }
     }
-    // ---- node encoder
+    // ---- node encoder.  G^0 = G^1 + dPQ_1 Wcat_1 is never formed (it is only needed for the encoder's own
+    // gradients): dWe = G^0^T X = G^1^T X + Wcat_1^T (dPQ_1^T X),  dbe = colsum(G^1) + Wcat_1^T colsum(dPQ_1).
+    // G holds G^1 and "dPQ" holds dPQ_1 here; this replaces a full-size dgrad GEMM by two K = M, J = 32 ones.
     CK(launch_gemm_tn(G, D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
     CK(launch_reduce_slabs(W("slabs"), S, D, 32, 0, x.F, GR(P.node_w), x.F, st));
     CK(launch_colsum_pm(G, mb.M, D, nullptr, W("cs_part"), GR(P.node_b), st));
+    UPAMD_HIP(hipMemsetAsync(W("Tn"), 0, sizeof(float) * (size_t)2 * D * 32, st));
+    CK(launch_gemm_tn(W("dPQ"), 2 * D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
+    CK(launch_reduce_slabs(W("slabs"), S, 2 * D, 32, 0, 32, W("Tn"), 32, st));
+    CK(launch_smm(D, x.F, 2 * D, W("WcatT0"), 2 * D, 1, W("Tn"), 32, 1, nullptr, GR(P.node_w), x.F, 1, 0, 1.f, st));
+    // "cs1" still holds colsum(dPQ_1) from the last (l = 1) iteration of the loop above
+    CK(launch_smm(1, D, 2 * D, W("cs1"), 2 * D, 1, W("WcatT0"), 1, 2 * D, nullptr, GR(P.node_b), D, 1, 0, 1.f, st));
     CK(lin.tn_acc(W("dC"), D, B, D, W("curg"), UPAMD_NODE_PAD, x.F, GR(P.node_w), GR(P.node_b)));
     return UPAMD_OK;
 }

@@ -133,6 +133,7 @@ int launch_prep_wcat(const float *W, int D, float *Wcat, float *WcatT, hipStream
 int launch_pad_cols(const float *W, int rows, int cols, int cols_pad, float *out, hipStream_t st);
 int launch_transpose(const float *W, int rows, int cols, float *out, hipStream_t st);
 int launch_axpy(float *dst, const float *src, int64_t n, float alpha, hipStream_t st);   // dst += alpha*src
+int launch_add_p_panels(float *dst, const float *src, int D, hipStream_t st);   // dst[D] += P half of src[2D] (P/Q panel order)
 int launch_scale(float *dst, int64_t n, float alpha, hipStream_t st);                     // dst *= alpha
 int launch_ppo_loss(int B, const float *value, const float *logp, const float *ent, const float *adv,
                     const float *ret, const float *old_logp, const float *exps, float clip_eps, float cv, float ce,
