@@ -72,7 +72,7 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     add("W1T", 4LL * D * x.h0l); add("R1T", (int64_t)D * x.h0r);
     add("wt", (int64_t)x.maxdim * x.maxdim);          // transposed-weight scratch of the per-sample layers
     add("W1c", 2LL * D * 32); add("b1c", 2LL * D);    // first GCN layer collapsed onto the raw node features
-    add("Tn", 2LL * D * 32); add("cs1", 2LL * D);     // backward of that collapse
+    add("Tn", 2LL * D * 32); add("cs1", 2LL * D); add("dWc1", 2LL * D * D);   // backward of that collapse
     add("Xp", 2 * M * 16);
     add("U0", B * x.Fn);
     for (int i = 0; i < d.n_num; ++i) add("U" + std::to_string(i + 1), B * d.num_hidden[i]);
@@ -567,11 +567,20 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         UPAMD_HIP(hipMemsetAsync(W("cs1"), 0, sizeof(float) * (size_t)2 * D, st));
         CK(launch_reduce_rows_add(W("dbias_part"), B, 2 * D, W("cs1"), st));
         CK(launch_add_p_panels(GR(P.edge_b[l - 1]), W("cs1"), D, st));
-        CK(launch_gemm_tn(W("dPQ"), 2 * D, W("H" + sp), D, mb.M, W("slabs"), &S, st, prof));
-        CK(launch_reduce_slabs(W("slabs"), S, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D, st));
         if (l > 1) {
+            CK(launch_gemm_tn(W("dPQ"), 2 * D, W("H" + sp), D, mb.M, W("slabs"), &S, st, prof));
+            CK(launch_reduce_slabs(W("slabs"), S, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D, st));
             CK(launch_gemm_nt(W("dPQ"), mb.M, 2 * D, W("WcatT" + sp), D, nullptr, G, Gn, 0, st, prof));
             std::swap(G, Gn);
+        } else {
+            // layer 1: H_0 = Xp We^T + be, so dWcat_1 = dPQ_1^T H_0 = (dPQ_1^T Xp) We^T + colsum(dPQ_1) (x) be --
+            // two J = 32 reductions over the nodes instead of a full-size weight-gradient GEMM
+            UPAMD_HIP(hipMemsetAsync(W("Tn"), 0, sizeof(float) * (size_t)2 * D * 32, st));
+            CK(launch_gemm_tn(W("dPQ"), 2 * D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
+            CK(launch_reduce_slabs(W("slabs"), S, 2 * D, 32, 0, 32, W("Tn"), 32, st));
+            CK(launch_smm(2 * D, D, 32, W("Tn"), 32, 1, W("We_pad"), 1, 32, nullptr, W("dWc1"), D, 0, 0, 1.f, st));
+            CK(launch_smm(2 * D, D, 1, W("cs1"), 1, 1, PR(P.node_b), 1, 1, nullptr, W("dWc1"), D, 1, 0, 1.f, st));
+            CK(launch_reduce_slabs(W("dWc1"), 1, 2 * D, D, 2, D, GR(P.edge_w[0]), 2 * D, st));
         }
     }
     // ---- node encoder.  G^0 = G^1 + dPQ_1 Wcat_1 is never formed (it is only needed for the encoder's own
@@ -580,11 +589,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     CK(launch_gemm_tn(G, D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
     CK(launch_reduce_slabs(W("slabs"), S, D, 32, 0, x.F, GR(P.node_w), x.F, st));
     CK(launch_colsum_pm(G, mb.M, D, nullptr, W("cs_part"), GR(P.node_b), st));
-    UPAMD_HIP(hipMemsetAsync(W("Tn"), 0, sizeof(float) * (size_t)2 * D * 32, st));
-    CK(launch_gemm_tn(W("dPQ"), 2 * D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
-    CK(launch_reduce_slabs(W("slabs"), S, 2 * D, 32, 0, 32, W("Tn"), 32, st));
+    // "Tn" = dPQ_1^T Xp and "cs1" = colsum(dPQ_1) come from the l = 1 iteration of the loop above
     CK(launch_smm(D, x.F, 2 * D, W("WcatT0"), 2 * D, 1, W("Tn"), 32, 1, nullptr, GR(P.node_w), x.F, 1, 0, 1.f, st));
-    // "cs1" still holds colsum(dPQ_1) from the last (l = 1) iteration of the loop above
     CK(launch_smm(1, D, 2 * D, W("cs1"), 2 * D, 1, W("WcatT0"), 1, 2 * D, nullptr, GR(P.node_b), D, 1, 0, 1.f, st));
     CK(lin.tn_acc(W("dC"), D, B, D, W("curg"), UPAMD_NODE_PAD, x.F, GR(P.node_w), GR(P.node_b)));
     return UPAMD_OK;
