@@ -14,8 +14,6 @@
 //
 // Replaces the reference's nn.Linear calls on padded [B,E,2D] / [B,N,D] tensors
 // (urban_planning/models/state_encoder.py:19,59-82,110-130; policy.py:19-43) and their autograd.
-#include <cstdlib>
-
 #include "kernels.h"
 
 namespace upamd {
@@ -29,8 +27,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 // ------------------------------------------------------------------------------------------ NT
-template <int BN, int WM, int WN, bool A_RM, bool C_RM, int MINW>
-__global__ __launch_bounds__(256, MINW) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K, int64_t lda,
+template <int BN, int WM, int WN, bool A_RM, bool C_RM, int PK>
+__global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K, int64_t lda,
                                                            const float *__restrict__ W, int N, int64_t ldw,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ R, float *__restrict__ C,
@@ -40,8 +38,9 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_mfma_kernel(const float *__
     constexpr int TI = WM / 32, TJ = WN / 32;
     constexpr int NB = (BN * 4 + 255) / 256;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
-    __shared__ float As[2][BM * LD];
-    __shared__ float Bs[2][BN * LD];
+    // PK = K panels (of 16) per pipeline stage / barrier (2 measured slower than 1: 106 vs 113 TFLOP/s)
+    __shared__ float As[2][PK][BM * LD];
+    __shared__ float Bs[2][PK][BN * LD];
 
     // XCD-aware mapping: workgroup id -> XCD id % 8 (observed dispatch); all N-tiles of an M-tile
     // land on one XCD so the A panel is fetched from HBM once and re-read from that XCD's L2.
@@ -63,35 +62,42 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_mfma_kernel(const float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KP = K >> 4;
-    float4 ra[2], rb[NB];
-    auto load_tiles = [&](int kp) {
+    const int KS = (K >> 4) / PK;      // pipeline stages
+    float4 ra[PK][2], rb[PK][NB];
+    auto load_tiles = [&](int ks) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
-            const int64_t gm = m0 + row;
-            const float *src = A_RM ? A + gm * lda + kp * 16 + c4 : A + ((int64_t)kp * M + gm) * 16 + c4;
-            ra[q] = gm < M ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int pp = 0; pp < PK; ++pp) {
+            const int kp = ks * PK + pp;
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
-            if (e < BN * 4) rb[q] = *reinterpret_cast<const float4 *>(W + (int64_t)(n0 + row) * ldw + kp * 16 + c4);
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
+                const int64_t gm = m0 + row;
+                const float *src = A_RM ? A + gm * lda + kp * 16 + c4 : A + ((int64_t)kp * M + gm) * 16 + c4;
+                ra[pp][q] = gm < M ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
+                if (e < BN * 4) rb[pp][q] = *reinterpret_cast<const float4 *>(W + (int64_t)(n0 + row) * ldw + kp * 16 + c4);
+            }
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
-            float *d = &As[buf][row * LD + c4];
-            d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w;
-        }
+        for (int pp = 0; pp < PK; ++pp) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
-            if (e < BN * 4) {
-                float *d = &Bs[buf][row * LD + c4];
-                d[0] = rb[q].x; d[1] = rb[q].y; d[2] = rb[q].z; d[3] = rb[q].w;
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
+                float *d = &As[buf][pp][row * LD + c4];
+                d[0] = ra[pp][q].x; d[1] = ra[pp][q].y; d[2] = ra[pp][q].z; d[3] = ra[pp][q].w;
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
+                if (e < BN * 4) {
+                    float *d = &Bs[buf][pp][row * LD + c4];
+                    d[0] = rb[pp][q].x; d[1] = rb[pp][q].y; d[2] = rb[pp][q].z; d[3] = rb[pp][q].w;
+                }
             }
         }
     };
@@ -99,27 +105,30 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_mfma_kernel(const float *__
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
-    for (int kp = 0; kp < KP; ++kp) {
-        const int buf = kp & 1;
-        if (kp + 1 < KP) load_tiles(kp + 1);
-        const float *as = &As[buf][(wr * WM + l31) * LD + lhi];
-        const float *bs = &Bs[buf][(wc * WN + l31) * LD + lhi];
+    for (int ks = 0; ks < KS; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < KS) load_tiles(ks + 1);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            float a[TI], b[TJ];
+        for (int pp = 0; pp < PK; ++pp) {
+            const float *as = &As[buf][pp][(wr * WM + l31) * LD + lhi];
+            const float *bs = &Bs[buf][pp][(wc * WN + l31) * LD + lhi];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) a[i] = as[i * 32 * LD + 2 * s];
+            for (int s = 0; s < 8; ++s) {
+                float a[TI], b[TJ];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) b[j] = bs[j * 32 * LD + 2 * s];
+                for (int i = 0; i < TI; ++i) a[i] = as[i * 32 * LD + 2 * s];
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+                for (int j = 0; j < TJ; ++j) b[j] = bs[j * 32 * LD + 2 * s];
 #pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    // operands swapped on purpose: D[row = n][col = m], so a lane's 4 consecutive accumulator
-                    // registers are 4 consecutive columns of one output row -> 16-byte stores in the epilogue
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        // operands swapped on purpose: D[row = n][col = m], so a lane's 4 consecutive accumulator
+                        // registers are 4 consecutive columns of one output row -> 16-byte stores in the epilogue
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
         }
-        if (kp + 1 < KP) store_tiles(buf ^ 1);
+        if (ks + 1 < KS) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
@@ -208,30 +217,21 @@ bool gemm_nt_mfma_ok(const GemmNT &g) {
     return true;
 }
 
-static int nt_min_waves() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("UPAMD_GEMM_MINW");
-        v = e ? atoi(e) : 2;
-    }
-    return v;
-}
-
-template <bool A_RM, bool C_RM, int MINW>
+template <bool A_RM, bool C_RM, int PK>
 static void launch_nt_layout(const GemmNT &g, hipStream_t st) {
     const int MT = (int)((g.M + 127) / 128);
     const int MT8 = (MT + 7) / 8 * 8;
     if (g.N % 128 == 0) {
         const int NT = g.N / 128;
-        hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM, MINW>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM, PK>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
                            g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
     } else if (g.N % 64 == 0) {
         const int NT = g.N / 64;
-        hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64, 32, A_RM, C_RM, MINW>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64, 32, A_RM, C_RM, PK>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
                            g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
     } else {
         const int NT = g.N / 32;
-        hipLaunchKernelGGL((gemm_nt_mfma_kernel<32, 32, 32, A_RM, C_RM, MINW>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<32, 32, 32, A_RM, C_RM, PK>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
                            g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
     }
 }
@@ -250,12 +250,10 @@ int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
     int began = prof_begin(prof, pname, st, flops, bytes);
     if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
     if (mfma) {
-        if (g.a_rm && g.c_rm) launch_nt_layout<true, true, 2>(g, st);
-        else if (g.a_rm) launch_nt_layout<true, false, 2>(g, st);
-        else if (g.c_rm) launch_nt_layout<false, true, 2>(g, st);
-        else if (nt_min_waves() == 3) launch_nt_layout<false, false, 3>(g, st);
-        else if (nt_min_waves() == 1) launch_nt_layout<false, false, 1>(g, st);
-        else launch_nt_layout<false, false, 2>(g, st);
+        if (g.a_rm && g.c_rm) launch_nt_layout<true, true, 1>(g, st);
+        else if (g.a_rm) launch_nt_layout<true, false, 1>(g, st);
+        else if (g.c_rm) launch_nt_layout<false, true, 1>(g, st);
+        else launch_nt_layout<false, false, 1>(g, st);
     } else {
         const int64_t total = g.M * g.N;
         hipLaunchKernelGGL(gemm_nt_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g.A, g.M, g.K, g.W, g.N,
