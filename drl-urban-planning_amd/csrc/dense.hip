@@ -295,6 +295,41 @@ int launch_scale(float *dst, int64_t n, float alpha, hipStream_t st) {
     UPAMD_HIP(hipGetLastError());
     return 0;
 }
+// Land-use head, first Linear W1 = [Wa | Wb | Wc | Wd] ([h0][4D]) in factorised form:
+//   W1f = [Wa + Wd | Wc] ([h0][2D]),  Wbd = Wb - Wd ([h0][D])
+__global__ void prep_land_head_kernel(const float *__restrict__ W1, int D, int h0, float *__restrict__ W1f,
+                                      float *__restrict__ Wbd) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= h0 * D) return;
+    const int k = g / D, d = g % D;
+    const float *w = W1 + (int64_t)k * 4 * D;
+    W1f[(int64_t)k * 2 * D + d] = w[d] + w[3 * D + d];
+    W1f[(int64_t)k * 2 * D + D + d] = w[2 * D + d];
+    Wbd[g] = w[D + d] - w[3 * D + d];
+}
+int launch_prep_land_head(const float *W1, int D, int h0, float *W1f, float *Wbd, hipStream_t st) {
+    hipLaunchKernelGGL(prep_land_head_kernel, dim3((h0 * D + 255) / 256), dim3(256), 0, st, W1, D, h0, W1f, Wbd);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+// ... and its gradient: gW1 += [dW1f_a + ... ] mapped back onto the four blocks
+__global__ void land_head_w_scatter_kernel(const float *__restrict__ dW1f, const float *__restrict__ dWbd, int D, int h0,
+                                           float *__restrict__ gW1) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= h0 * D) return;
+    const int k = g / D, d = g % D;
+    const float a = dW1f[(int64_t)k * 2 * D + d], cgrad = dW1f[(int64_t)k * 2 * D + D + d], bd = dWbd[g];
+    float *w = gW1 + (int64_t)k * 4 * D;
+    w[d] += a;                 // Wa
+    w[D + d] += bd;            // Wb
+    w[2 * D + d] += cgrad;     // Wc
+    w[3 * D + d] += a - bd;    // Wd
+}
+int launch_land_head_w_scatter(const float *dW1f, const float *dWbd, int D, int h0, float *gW1, hipStream_t st) {
+    hipLaunchKernelGGL(land_head_w_scatter_kernel, dim3((h0 * D + 255) / 256), dim3(256), 0, st, dW1f, dWbd, D, h0, gW1);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
 // dst[p*16 + c] += src[(2p)*16 + c]: the P half of a [2D] vector in P/Q panel order
 __global__ void add_p_panels_kernel(float *__restrict__ dst, const float *__restrict__ src, int D) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

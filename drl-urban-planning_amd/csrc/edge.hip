@@ -88,8 +88,10 @@ __device__ __forceinline__ void stage_pq(float2 *PQl, const float *Pg, const flo
 // ------------------------------------------------------------------------------------------
 // forward: H_out = H_in + S / (deg + 1e-6).  The last layer also emits the masked node mean, the edge
 // mean (= 1/2 sum_v S_v / e: every message is counted at both of its endpoints) and -- fused, while the
-// P/Q slices are still in LDS -- the land-use pointer-head inputs of the row's candidate edges
-// (state_encoder.py:207-210): FE = [m ; c ; m*c ; m-c] with m the candidate's last-layer message.
+// P/Q slices are still in LDS -- the land-use pointer-head inputs of the row's candidate edges.  The head's
+// first Linear acts on [m ; c ; m*c ; m-c] (state_encoder.py:207-210, m = the candidate's last-layer message);
+// with W1 = [Wa|Wb|Wc|Wd] that is (Wa+Wd) m + Wc (m*c) + (Wb-Wd) c, so only FE = [m ; m*c] is materialised and
+// the c-only term becomes a per-row bias.
 // ------------------------------------------------------------------------------------------
 template <bool LAST, bool STAGE>
 __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
@@ -181,9 +183,7 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, M
             }
             const int64_t row = q0 + q;
             FE[((int64_t)p * NH + row) * 16 + c] = mm;
-            FE[((int64_t)(NP + p) * NH + row) * 16 + c] = cc;
-            FE[((int64_t)(2 * NP + p) * NH + row) * 16 + c] = mm * cc;
-            FE[((int64_t)(3 * NP + p) * NH + row) * 16 + c] = mm - cc;
+            FE[((int64_t)(NP + p) * NH + row) * 16 + c] = mm * cc;
         }
     }
     if (STAGE) {

@@ -45,7 +45,7 @@ int64_t slab_floats(const Dims &x, int64_t B, int64_t M, int64_t Nhe, int64_t Nr
     int64_t s = 0;
     s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, x.D, M) * 2 * x.D * x.D);          // GCN weight grads
     s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, 32, M) * 2 * x.D * 32);            // node encoder (G^1 and dPQ_1 parts)
-    s = std::max<int64_t>(s, (int64_t)tn_splits(4 * x.D, x.h0l, Nhe) * 4 * x.D * x.h0l);    // land head
+    s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, x.h0l, Nhe) * 2 * x.D * x.h0l);    // land head
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.h0r, Nrn) * x.D * x.h0r);            // road head
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.D, B) * x.D * x.D);                  // per-sample D x D layers
     s = std::max<int64_t>(s, (int64_t)smm_splits((int)B) * x.maxdim * x.maxdim);            // small per-sample layers (split-K)
@@ -69,7 +69,8 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
         add("WcatT" + std::to_string(l), 2LL * D * D);
     }
     add("Wkk", (int64_t)D * D); add("Wvv", (int64_t)D * D); add("bvv", D);
-    add("W1T", 4LL * D * x.h0l); add("R1T", (int64_t)D * x.h0r);
+    add("W1f", 2LL * D * x.h0l); add("W1fT", 2LL * D * x.h0l); add("Wbd", (int64_t)D * x.h0l); add("R1T", (int64_t)D * x.h0r);
+    add("constb", B * x.h0l); add("dconst", B * x.h0l); add("dW1f", 2LL * D * x.h0l); add("dWbd", (int64_t)D * x.h0l);
     add("wt", (int64_t)x.maxdim * x.maxdim);          // transposed-weight scratch of the per-sample layers
     add("W1c", 2LL * D * 32); add("b1c", 2LL * D);    // first GCN layer collapsed onto the raw node features
     add("Tn", 2LL * D * 32); add("cs1", 2LL * D); add("dWc1", 2LL * D * D);   // backward of that collapse
@@ -85,7 +86,7 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     add("s", B * x.heads * D); add("o", B * D); add("att", B * D);
     add("SV", B * x.W);
     for (int i = 0; i < d.n_value; ++i) add("V" + std::to_string(i + 1), B * d.value_hidden[i]);
-    add("FE", NH * 4 * D); add("hidl", NH * x.h0l); add("z_he", NH); add("p_he", NH);
+    add("FE", NH * 2 * D); add("hidl", NH * x.h0l); add("z_he", NH); add("p_he", NH);
     add("XR", NR * D); add("hidr", NR * x.h0r); add("z_rn", NR); add("p_rn", NR);
     add("lse", B); add("entk", B);
     // backward temporaries
@@ -94,7 +95,7 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     add("do", B * D); add("ds", B * x.heads * D); add("dr", B * x.heads * D);
     add("dq1", B * D); add("dq0", B * D); add("dC", B * D); add("dC_head", B * D);
     add("dWkk", (int64_t)D * D); add("dWvv", (int64_t)D * D); add("dbvv", D);
-    add("dz_he", NH); add("dz_rn", NR); add("dprel", NH * x.h0l); add("dFE", NH * 4 * D); add("dMhe", NH * D);
+    add("dz_he", NH); add("dz_rn", NR); add("dprel", NH * x.h0l); add("dFE", NH * 2 * D); add("dMhe", NH * D);
     add("dprer", NR * x.h0r); add("dXR", NR * D);
     add("G0", M * D); add("G1", M * D); add("dPQ", M * 2 * D); add("dbias_part", B * 2 * D);
     add("slabs", slab_floats(x, B, M, NH, NR));
@@ -288,7 +289,7 @@ extern "C" int upamd_ws_tensor(upamd_engine *eng, const upamd_minibatch *mb, con
     else if (n.rfind("PQ", 0) == 0 || n == "dPQ") { r = M; c = 2 * x.D; k = 1; }
     else if (n == "G0" || n == "G1") { r = M; c = x.D; k = 1; }
     else if (n == "Xp") { r = M; c = 32; k = 1; }
-    else if (n == "FE" || n == "dFE") { r = NH; c = 4 * x.D; k = 1; }
+    else if (n == "FE" || n == "dFE") { r = NH; c = 2 * x.D; k = 1; }
     else if (n == "hidl" || n == "dprel") { r = NH; c = x.h0l; k = 1; }
     else if (n == "dMhe") { r = NH; c = x.D; k = 1; }
     else if (n == "XR" || n == "dXR") { r = NR; c = x.D; k = 1; }
@@ -403,7 +404,12 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     }
     // pointer heads (policy.py:19-65)
     if (mb.Nhe > 0) {
-        CK(launch_gemm_nt(W("FE"), mb.Nhe, 4 * D, PR(P.land_w[0]), x.h0l, PR(P.land_b0), nullptr, W("hidl"), 1, st, prof));
+        // factorised first Linear: hid = tanh(FE [Wa+Wd | Wc]^T + ((Wb-Wd) c_b + b1)), the bias rows are
+        // pre-written into hid and accumulated in place
+        CK(launch_prep_land_head(PR(P.land_w[0]), D, x.h0l, W("W1f"), W("Wbd"), st));
+        CK(lin.nt(W("C"), D, B, D, W("Wbd"), D, PR(P.land_b0), x.h0l, W("constb"), x.h0l, 0, 1.f));
+        CK(launch_he_bias_rows(pk, mb, x.h0l, W("constb"), W("hidl"), st));
+        CK(launch_gemm_nt(W("FE"), mb.Nhe, 2 * D, W("W1f"), x.h0l, nullptr, W("hidl"), W("hidl"), 1, st, prof));
         CK(launch_rowdot_pm(W("hidl"), mb.Nhe, x.h0l, PR(P.land_w[1]), W("z_he"), st));
     }
     if (mb.Nrn > 0) {
@@ -539,10 +545,19 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_colsum_pm(W("hidl"), mb.Nhe, x.h0l, W("dz_he"), W("cs_part"), GR(P.land_w[1]), st));          // dw2 += sum dz * hid
         CK(launch_rowdot_bwd_pm(W("hidl"), mb.Nhe, x.h0l, PR(P.land_w[1]), W("dz_he"), W("dprel"), st));
         CK(launch_colsum_pm(W("dprel"), mb.Nhe, x.h0l, nullptr, W("cs_part"), GR(P.land_b0), st));
-        CK(launch_gemm_tn(W("FE"), 4 * D, W("dprel"), x.h0l, mb.Nhe, W("slabs"), &S, st, prof));
-        CK(launch_reduce_slabs(W("slabs"), S, 4 * D, x.h0l, 1, x.h0l, GR(P.land_w[0]), 4 * D, st));
-        CK(launch_transpose(PR(P.land_w[0]), x.h0l, 4 * D, W("W1T"), st));
-        CK(launch_gemm_nt(W("dprel"), mb.Nhe, x.h0l, W("W1T"), 4 * D, nullptr, nullptr, W("dFE"), 0, st, prof));
+        // dW1f = dpre^T FE, mapped back onto [Wa|Wb|Wc|Wd] together with dWbd = dconst^T C
+        UPAMD_HIP(hipMemsetAsync(W("dW1f"), 0, sizeof(float) * (size_t)2 * D * x.h0l, st));
+        UPAMD_HIP(hipMemsetAsync(W("dWbd"), 0, sizeof(float) * (size_t)D * x.h0l, st));
+        CK(launch_gemm_tn(W("FE"), 2 * D, W("dprel"), x.h0l, mb.Nhe, W("slabs"), &S, st, prof));
+        CK(launch_reduce_slabs(W("slabs"), S, 2 * D, x.h0l, 1, x.h0l, W("dW1f"), 2 * D, st));
+        CK(launch_he_segsum(pk, mb, x.h0l, W("dprel"), W("dconst"), st));
+        CK(lin.tn_acc(W("dconst"), x.h0l, B, x.h0l, W("C"), D, D, W("dWbd"), nullptr));
+        CK(launch_land_head_w_scatter(W("dW1f"), W("dWbd"), D, x.h0l, GR(P.land_w[0]), st));
+        // dC from the bias term, then dFE = dpre W1f and the feature backward
+        CK(lin.nn(W("dconst"), x.h0l, B, x.h0l, W("Wbd"), D, W("dC_head"), D));
+        CK(launch_axpy(W("dC"), W("dC_head"), (int64_t)B * D, 1.f, st));
+        CK(launch_transpose(W("W1f"), x.h0l, 2 * D, W("W1fT"), st));
+        CK(launch_gemm_nt(W("dprel"), mb.Nhe, x.h0l, W("W1fT"), 2 * D, nullptr, nullptr, W("dFE"), 0, st, prof));
         CK(launch_he_feat_bwd(pk, mb, D, W("FE"), W("C"), W("dFE"), W("dMhe"), W("dC_head"), st));
         CK(launch_axpy(W("dC"), W("dC_head"), (int64_t)B * D, 1.f, st));
     }

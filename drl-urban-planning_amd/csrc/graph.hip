@@ -217,33 +217,40 @@ int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, co
 }
 
 // ------------------------------------------------------------------------------------------
-// Land-use pointer head (state_encoder.py:207-210): the candidate features FE = [m ; c ; m*c ; m-c] are
-// produced by the last layer's edge_fwd kernel (edge.hip); here is their backward.
+// Land-use pointer head (state_encoder.py:207-210, policy.py:19-43) in factorised form: the candidate
+// features FE = [m ; m*c] come from the last layer's edge_fwd kernel (edge.hip); here are the per-row bias,
+// the per-graph segment sums and the feature backward.
 // ------------------------------------------------------------------------------------------
-// dMhe(pm)[row][d] = live * (g1 + g3*c + g4);   dC_head[b][d] = sum_rows (g2 + g3*m - g4)
-__global__ __launch_bounds__(256) void he_feat_bwd_kernel(PackedView pk, MbView mb, int NP,
-                                                          const float *__restrict__ FE, const float *__restrict__ C,
-                                                          const float *__restrict__ dFE, float *__restrict__ dMhe,
-                                                          float *__restrict__ dC_head) {
+// hid(pm)[row][k] = constb[b(row)][k]: the per-row bias (Wb - Wd) c_b + b1 of the factorised first Linear,
+// written into the hidden buffer that the GEMM then accumulates onto (R == C in place)
+__global__ __launch_bounds__(256) void he_bias_rows_kernel(PackedView pk, MbView mb, int h0,
+                                                           const float *__restrict__ constb, float *__restrict__ hid) {
+    const int b = blockIdx.x, t = mb.idx[b];
+    const int nh = META(t)[2];
+    const int64_t q0 = mb.he_off[b], NH = mb.Nhe;
+    for (int i = threadIdx.x; i < nh * h0; i += 256) {
+        const int q = i / h0, k = i % h0;
+        hid[((int64_t)(k >> 4) * NH + q0 + q) * 16 + (k & 15)] = constb[(int64_t)b * h0 + k];
+    }
+}
+int launch_he_bias_rows(const PackedView &pk, const MbView &mb, int h0, const float *constb, float *hid, hipStream_t st) {
+    if (mb.Nhe == 0) return 0;
+    hipLaunchKernelGGL(he_bias_rows_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, h0, constb, hid);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// dconst[b][k] = sum over the row's candidates of dpre(pm)[row][k]   (fixed order, one workgroup per graph)
+__global__ __launch_bounds__(256) void he_segsum_kernel(PackedView pk, MbView mb, int h0,
+                                                        const float *__restrict__ dpre, float *__restrict__ dconst) {
     __shared__ float part[256];
     const int b = blockIdx.x, t = mb.idx[b];
-    const int32_t *m = META(t);
-    const int nh = m[2];
-    const int D = NP * 16;
-    const int c = threadIdx.x & 15, qg = threadIdx.x >> 4;
+    const int nh = META(t)[2];
     const int64_t q0 = mb.he_off[b], NH = mb.Nhe;
-    for (int p = 0; p < NP; ++p) {
+    const int c = threadIdx.x & 15, qg = threadIdx.x >> 4;
+    for (int p = 0; p < h0 / 16; ++p) {
         float acc = 0.f;
-        const float cc = C[(int64_t)b * D + p * 16 + c];
-        for (int q = qg; q < nh; q += 16) {
-            const int64_t row = q0 + q;
-            const float live = pk.he_live[m[11] + q] ? 1.f : 0.f;
-            const float mm = FE[((int64_t)p * NH + row) * 16 + c];
-            const float g1 = dFE[((int64_t)p * NH + row) * 16 + c], g2 = dFE[((int64_t)(NP + p) * NH + row) * 16 + c];
-            const float g3 = dFE[((int64_t)(2 * NP + p) * NH + row) * 16 + c], g4 = dFE[((int64_t)(3 * NP + p) * NH + row) * 16 + c];
-            dMhe[((int64_t)p * NH + row) * 16 + c] = live * (g1 + g3 * cc + g4);
-            acc += g2 + g3 * mm - g4;
-        }
+        for (int q = qg; q < nh; q += 16) acc += dpre[((int64_t)p * NH + q0 + q) * 16 + c];
         __syncthreads();
         part[qg * 16 + c] = acc;
         __syncthreads();
@@ -251,14 +258,51 @@ __global__ __launch_bounds__(256) void he_feat_bwd_kernel(PackedView pk, MbView 
             float tot = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) tot += part[q * 16 + threadIdx.x];
-            dC_head[(int64_t)b * D + p * 16 + threadIdx.x] = tot;
+            dconst[(int64_t)b * h0 + p * 16 + threadIdx.x] = tot;
         }
+    }
+}
+int launch_he_segsum(const PackedView &pk, const MbView &mb, int h0, const float *dpre, float *dconst, hipStream_t st) {
+    hipLaunchKernelGGL(he_segsum_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, h0, dpre, dconst);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// backward of FE = [m ; m*c]:  dMhe(pm)[row][d] = live * (g1 + g2 * c),  dC_head[b][d] = sum_rows g2 * m
+__global__ __launch_bounds__(256) void he_feat_bwd_kernel(PackedView pk, MbView mb, int NP,
+                                                          const float *__restrict__ FE, const float *__restrict__ C,
+                                                          const float *__restrict__ dFE, float *__restrict__ dMhe,
+                                                          float *__restrict__ dC_head) {
+    __shared__ float part[256];
+    const int b = blockIdx.x / NP, p = blockIdx.x % NP, t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int nh = m[2];
+    const int D = NP * 16;
+    const int c = threadIdx.x & 15, qg = threadIdx.x >> 4;
+    const int64_t q0 = mb.he_off[b], NH = mb.Nhe;
+    float acc = 0.f;
+    const float cc = C[(int64_t)b * D + p * 16 + c];
+    for (int q = qg; q < nh; q += 16) {
+        const int64_t row = q0 + q;
+        const float live = pk.he_live[m[11] + q] ? 1.f : 0.f;
+        const float mm = FE[((int64_t)p * NH + row) * 16 + c];
+        const float g1 = dFE[((int64_t)p * NH + row) * 16 + c], g2 = dFE[((int64_t)(NP + p) * NH + row) * 16 + c];
+        dMhe[((int64_t)p * NH + row) * 16 + c] = live * (g1 + g2 * cc);
+        acc += g2 * mm;
+    }
+    part[qg * 16 + c] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += part[q * 16 + threadIdx.x];
+        dC_head[(int64_t)b * D + p * 16 + threadIdx.x] = tot;
     }
 }
 
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
                        const float *dFE, float *dMhe, float *dC_head, hipStream_t st) {
-    hipLaunchKernelGGL(he_feat_bwd_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, D / 16, FE, C, dFE, dMhe, dC_head);
+    hipLaunchKernelGGL(he_feat_bwd_kernel, dim3(mb.B * (D / 16)), dim3(256), 0, st, pk, mb, D / 16, FE, C, dFE, dMhe, dC_head);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

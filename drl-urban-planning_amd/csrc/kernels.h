@@ -97,6 +97,8 @@ int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, co
                     hipStream_t st);
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
                        const float *dFE, float *dMhe, float *dC_head, hipStream_t st);
+int launch_he_bias_rows(const PackedView &pk, const MbView &mb, int h0, const float *constb, float *hid, hipStream_t st);
+int launch_he_segsum(const PackedView &pk, const MbView &mb, int h0, const float *dpre, float *dconst, hipStream_t st);
 int launch_road_gather(const PackedView &pk, const MbView &mb, int D, const float *HL, float *XR, hipStream_t st);
 int launch_road_scatter_add(const PackedView &pk, const MbView &mb, int D, const float *dXR, float *GL, hipStream_t st);
 // masked softmax over each row's candidate list: logp, entropy (+ probabilities kept for backward)
@@ -133,6 +135,8 @@ int launch_prep_wcat(const float *W, int D, float *Wcat, float *WcatT, hipStream
 int launch_pad_cols(const float *W, int rows, int cols, int cols_pad, float *out, hipStream_t st);
 int launch_transpose(const float *W, int rows, int cols, float *out, hipStream_t st);
 int launch_axpy(float *dst, const float *src, int64_t n, float alpha, hipStream_t st);   // dst += alpha*src
+int launch_prep_land_head(const float *W1, int D, int h0, float *W1f, float *Wbd, hipStream_t st);
+int launch_land_head_w_scatter(const float *dW1f, const float *dWbd, int D, int h0, float *gW1, hipStream_t st);
 int launch_add_p_panels(float *dst, const float *src, int D, hipStream_t st);   // dst[D] += P half of src[2D] (P/Q panel order)
 int launch_scale(float *dst, int64_t n, float alpha, hipStream_t st);                     // dst *= alpha
 int launch_ppo_loss(int B, const float *value, const float *logp, const float *ent, const float *adv,
