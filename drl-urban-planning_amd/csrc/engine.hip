@@ -112,7 +112,6 @@ PackedView make_view(const void *packed_dev, const upamd_pack_layout &L) {
     v.nmask = reinterpret_cast<const uint8_t *>(b + L.off_nmask);
     v.rowptr = reinterpret_cast<const int32_t *>(b + L.off_rowptr);
     v.inc_nbr = reinterpret_cast<const uint16_t *>(b + L.off_inc_nbr);
-    v.inc_he = reinterpret_cast<const uint16_t *>(b + L.off_inc_he);
     v.he_src = reinterpret_cast<const uint16_t *>(b + L.off_he_src);
     v.he_dst = reinterpret_cast<const uint16_t *>(b + L.off_he_dst);
     v.he_live = reinterpret_cast<const uint8_t *>(b + L.off_he_live);

@@ -22,7 +22,7 @@ struct PackedView {   // device pointers into the packed replay (upamd_pack_layo
     const float *X;
     const uint8_t *nmask;
     const int32_t *rowptr;
-    const uint16_t *inc_nbr, *inc_he, *he_src, *he_dst, *rn_node, *order, *hinc_nbr, *hinc_he;
+    const uint16_t *inc_nbr, *he_src, *he_dst, *rn_node, *order, *hinc_nbr, *hinc_he;
     const int32_t *hinc_ptr;
     const uint8_t *he_live;
     const float *numerical, *cur;

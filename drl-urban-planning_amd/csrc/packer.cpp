@@ -166,7 +166,6 @@ extern "C" int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *p
     L.off_nmask = place(nodes);
     L.off_rowptr = place((nodes + T) * 4);
     L.off_inc_nbr = place(2 * edges * 2);
-    L.off_inc_he = place(2 * edges * 2);
     L.off_he_src = place(he * 2);
     L.off_he_dst = place(he * 2);
     L.off_he_live = place(he);
@@ -194,7 +193,6 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
     uint8_t *nmask = reinterpret_cast<uint8_t *>(base + L.off_nmask);
     int32_t *rowptr = reinterpret_cast<int32_t *>(base + L.off_rowptr);
     uint16_t *inc_nbr = reinterpret_cast<uint16_t *>(base + L.off_inc_nbr);
-    uint16_t *inc_he = reinterpret_cast<uint16_t *>(base + L.off_inc_he);
     uint16_t *he_src = reinterpret_cast<uint16_t *>(base + L.off_he_src);
     uint16_t *he_dst = reinterpret_cast<uint16_t *>(base + L.off_he_dst);
     uint8_t *he_live = reinterpret_cast<uint8_t *>(base + L.off_he_live);
@@ -255,13 +253,11 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
         if (rp[n] != 2 * e) return -1;
         std::vector<int32_t> fill(rp, rp + n);
         uint16_t *nb = inc_nbr + 2 * o_edge;
-        uint16_t *ih = inc_he + 2 * o_edge;
         for (int k = 0; k < E; ++k)
             if (s.edge_mask[k]) {
                 const int i = (int)s.edge_index[2 * k], j = (int)s.edge_index[2 * k + 1];
-                const uint16_t h = (stage == 0 && he_of_slot[k] >= 0) ? (uint16_t)he_of_slot[k] : (uint16_t)0xFFFF;
-                nb[fill[i]] = (uint16_t)j; ih[fill[i]] = h; fill[i]++;
-                nb[fill[j]] = (uint16_t)i; ih[fill[j]] = h; fill[j]++;
+                nb[fill[i]++] = (uint16_t)j;
+                nb[fill[j]++] = (uint16_t)i;
             }
         // processing order of the edge kernels: nodes by degree, descending (stable), so that the four
         // nodes a wave handles together have similar neighbour counts

@@ -30,7 +30,7 @@ class PackLayout(C.Structure):
     _fields_ = [('T', C.c_int64), ('total_nodes', C.c_int64), ('total_edges', C.c_int64), ('total_he', C.c_int64),
                 ('total_rn', C.c_int64), ('node_dim', C.c_int32), ('numerical_dim', C.c_int32),
                 ('off_meta', C.c_int64), ('off_x', C.c_int64), ('off_nmask', C.c_int64), ('off_rowptr', C.c_int64),
-                ('off_inc_nbr', C.c_int64), ('off_inc_he', C.c_int64), ('off_he_src', C.c_int64),
+                ('off_inc_nbr', C.c_int64), ('off_he_src', C.c_int64),
                 ('off_he_dst', C.c_int64), ('off_he_live', C.c_int64), ('off_he_slot', C.c_int64),
                 ('off_rn_node', C.c_int64), ('off_numerical', C.c_int64), ('off_cur', C.c_int64),
                 ('off_order', C.c_int64), ('off_hinc_ptr', C.c_int64), ('off_hinc_nbr', C.c_int64),

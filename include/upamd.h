@@ -99,7 +99,6 @@ typedef struct upamd_pack_layout {
     int64_t off_nmask;     /* u8    [total_nodes]                                                */
     int64_t off_rowptr;    /* int32 [total_nodes + T]   per graph n+1 local incidence offsets    */
     int64_t off_inc_nbr;   /* u16   [2*total_edges]     neighbour (local node id) per incidence  */
-    int64_t off_inc_he;    /* u16   [2*total_edges]     local head-edge index or 0xFFFF          */
     int64_t off_he_src;    /* u16   [total_he]                                                   */
     int64_t off_he_dst;    /* u16   [total_he]                                                   */
     int64_t off_he_live;   /* u8    [total_he]          0 if the candidate edge is not a live edge */

@@ -16,7 +16,6 @@ def _check(replay):
     nmask = pk.section('nmask', np.uint8, L.total_nodes)
     rowptr = pk.section('rowptr', np.int32, L.total_nodes + T)
     inc_nbr = pk.section('inc_nbr', np.uint16, 2 * L.total_edges)
-    inc_he = pk.section('inc_he', np.uint16, 2 * L.total_edges)
     he_src = pk.section('he_src', np.uint16, L.total_he)
     he_dst = pk.section('he_dst', np.uint16, L.total_he)
     he_live = pk.section('he_live', np.uint8, L.total_he)
@@ -43,8 +42,6 @@ def _check(replay):
         np.testing.assert_array_equal(nmask[no:no + n].astype(bool), g['nmask'])
         np.testing.assert_array_equal(rowptr[rp:rp + n + 1], g['row_ptr'])
         np.testing.assert_array_equal(inc_nbr[2 * eo:2 * eo + 2 * e], g['inc_nbr'])
-        np.testing.assert_array_equal(inc_he[2 * eo:2 * eo + 2 * e].astype(np.int64),
-                                      np.where(g['inc_he'] < 0, 0xFFFF, g['inc_he']))
         np.testing.assert_array_equal(he_src[ho:ho + m[2]], g['he_src'])
         np.testing.assert_array_equal(he_dst[ho:ho + m[2]], g['he_dst'])
         np.testing.assert_array_equal(he_live[ho:ho + m[2]], g['he_live'])
