@@ -349,7 +349,7 @@ int launch_road_scatter_add(const PackedView &pk, const MbView &mb, int D, const
 // Masked-softmax pointer head over each row's candidate list (policy.py:49-52,58-61,87-104 with
 // torch.distributions.Categorical): log_prob of the taken action, entropy.  One wave per row.
 // Rows whose stage is neither 0 nor 1 get logp = entropy = 0 (policy.py:90-91).  A row with no
-// valid candidate reproduces the reference's uniform distribution over the padded row.
+// valid candidate reproduces the reference's fp32 behaviour on an all-pad row (log_prob = entropy = 0).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -377,9 +377,10 @@ __global__ __launch_bounds__(256) void pointer_fwd_kernel(PackedView pk, MbView 
     const int64_t off = stage == 0 ? mb.he_off[b] : mb.rn_off[b];
     const float *z = (stage == 0 ? z_he : z_rn) + off;
     float *pp = (stage == 0 ? p_he : p_rn) + off;
-    const float npad = (float)(stage == 0 ? m[8] : m[7]);
     if (cnt == 0) {
-        if (lane == 0) { logp[b] = -logf(npad); ent[b] = logf(npad); lse_out[b] = 0.f; }
+        // no valid candidate: every logit is the pad constant -2^32+1; in fp32 its logsumexp over the padded row
+        // is absorbed (|pad| >> log N), so the reference's normalised logits are all 0: log_prob = 0, entropy = 0
+        if (lane == 0) { logp[b] = 0.f; ent[b] = 0.f; lse_out[b] = 0.f; }
         return;
     }
     float mx = -INFINITY;

@@ -241,9 +241,9 @@ class CsrModel:
                 hs = dict(kind='road', acts=acts, z=z, npad=g['pad_n'])
             if hs['kind'] is not None:
                 z = hs['z']
-                if z.size == 0:        # no valid candidate: uniform over the padded row (reference behaviour)
-                    logp[b] = -np.log(hs['npad'])
-                    ent[b] = np.log(hs['npad'])
+                if z.size == 0:        # no valid candidate: the reference's fp32 normalised logits are all 0
+                    logp[b] = 0.0       # (logsumexp of N copies of -2^32+1 is absorbed in fp32)
+                    ent[b] = 0.0
                     hs['p'] = z
                 else:
                     mx = z.max()
