@@ -228,6 +228,34 @@ def test_update_params_matches_reference(name):
     np.testing.assert_allclose(up.last_losses, z['upd2/scalars'][n1:], rtol=2e-4, atol=5e-6)
 
 
+@pytest.mark.parametrize('name', ['case_a', 'case_b'])
+def test_virtual_ranks_match_reference(name):
+    """Data-parallel arithmetic on the real kernels without a cluster: every minibatch is split into two halves
+    that run as two "virtual ranks" (separate streams, workspaces and gradient buffers, losses scaled by the
+    GLOBAL row counts), their gradients are summed, then clip + Adam -- must reproduce the reference's update."""
+    from drl_urban_planning_amd import PPOUpdater, synth
+    from test_oracle_golden import CASE_HYPER, CASE_EPOCHS, CASE_SEED, CASE_B
+    if CASE_B[name] % 2:
+        pytest.skip('odd minibatch size')
+    z, sd, states = helpers.load_case(name)
+    cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
+    hy = CASE_HYPER[name]
+    policy_net, value_net, ac = helpers.build_product(cfg)
+    ac.load_state_dict(sd)
+    ac.to(DEV)
+    up = PPOUpdater(policy_net, value_net, lr=hy['lr'], eps=hy['eps'], weight_decay=hy['weight_decay'],
+                    gamma=hy['gamma'], tau=hy['tau'], clip_epsilon=hy['clip_epsilon'],
+                    value_pred_coef=hy['value_pred_coef'], entropy_coef=hy['entropy_coef'],
+                    num_optim_epoch=CASE_EPOCHS[name], mini_batch_size=CASE_B[name], sub_batches=2)
+    replay = synth.Replay(states, z['actions'], z['masks'], z['rewards'], z['exps'])
+    np.random.seed(CASE_SEED[name] + 11)
+    up.update_params(replay, 0)
+    np.testing.assert_allclose(up.last_losses, z['upd/scalars'], rtol=1e-4, atol=2e-6)
+    mine = {k: v.detach().cpu().numpy() for k, v in ac.state_dict().items()}
+    for k in mine:
+        assert _rel_l2(mine[k], z['upd_sd/' + k]) <= 1e-4, (k, _rel_l2(mine[k], z['upd_sd/' + k]))
+
+
 def _random_case(D, L, heads, S, land, road, value, T, max_nodes, max_edges, seed, road_fraction, n_range):
     from drl_urban_planning_amd import synth
     cfg = helpers.make_cfg(D=D, L=L, S=S, heads=heads, land_head=land, road_head=road, value_head=value,
