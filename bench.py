@@ -116,11 +116,20 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--sub-batches', type=int, default=1, help='2 = overlap the two halves of a minibatch on two streams')
+    ap.add_argument('--minibatch', type=int, default=0, help='override the per-GPU PPO minibatch of the workload (exploration)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak (default): the minibatch per GPU is fixed; strong: the GLOBAL minibatch is fixed and split')
     args = ap.parse_args()
 
     from drl_urban_planning_amd import PPOUpdater, synth, DistContext
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.minibatch:
+        w['B'] = args.minibatch
+    if args.scaling == 'strong':
+        if w['B'] % args.gpus:
+            raise RuntimeError('--scaling strong needs the minibatch (%d) divisible by --gpus' % w['B'])
+        w['B'] //= args.gpus
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs a GPU (the HIP path has no CPU fallback)')
@@ -199,7 +208,7 @@ def main():
     out = {
         'metric': 'PPO-update samples/sec', 'value': value, 'unit': 'samples/s', 'n_gpus': ctx.world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %s-shaped graphs (n~%.0f nodes, e~%.0f edges live; pads %d/%d), SGNN %d layers x %d, '
                                'PPO minibatch %d per GPU, replay %d states resident in HBM'
                                % (args.workload, w['community'].upper(), nodes_per_sample, edges_per_sample, w['max_nodes'],
@@ -220,7 +229,20 @@ def main():
         out['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'launches': st['launches'],
                            'avg_launch_ms': st['total_ms'] / st['launches'],
-                           'algorithmic_flops_per_launch': st['flops'] / st['launches']}
+                           'algorithmic_flops_per_launch': st['flops'] / st['launches'],
+                           'algorithmic_bytes_per_launch': st['bytes'] / st['launches']}
+        # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (FETCH_SIZE / WRITE_SIZE,
+        # --kernel-trace only), so the figure is read from the committed summary of those passes over this same
+        # command (tools/pmc_traffic.py -> profiles/pmc_traffic.json); null when that file is absent
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+        if args.workload == 'hlg_d256' and not args.minibatch and os.path.exists(pmc):
+            with open(pmc) as fh:
+                k = json.load(fh).get('kernels', {}).get(dom)
+            if k:
+                out['roofline']['traffic'] = k['hbm_bytes_per_launch']
+                out['roofline']['traffic_source'] = ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + '
+                                                     'WRITE_SIZE, separate passes over bench.py, averaged over %d launches'
+                                                     % k['launches'])
         out['kernel_ms_per_step'] = {k: v['total_ms'] / args.steps for k, v in kern.items()}
     if ctx.world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(w)
