@@ -7,17 +7,22 @@
 // Work decomposition: one 1024-thread workgroup per (graph, 16-column panel).  In the panel-major
 // layout the graph's P, Q and H slices for those 16 columns are contiguous runs of n*64 B; they are
 // staged into LDS once with coalesced 16-byte loads (P/Q interleaved so a neighbour costs one
-// ds_read_b64), then every gather hits LDS.  A wave handles FOUR nodes at a time -- one per 16-lane
-// group, lanes = the 16 columns -- walking that node's incidence list sequentially: a CSR-by-
-// destination segment sum in a fixed order, no atomics, no cross-lane reduction, bit-reproducible.
-// Nodes are visited in the packer's degree-sorted order so the four lists a wave walks together have
-// (nearly) equal length.  16 waves per workgroup x 2 workgroups per CU = the full 8 waves per SIMD.
+// ds_read_b128 for two columns), then every gather hits LDS.  A wave handles EIGHT nodes at a time --
+// one per 8-lane group, each lane owning two adjacent columns -- walking that node's incidence list
+// sequentially: a CSR-by-destination segment sum in a fixed order, no atomics, no cross-lane reduction,
+// bit-reproducible.  Nodes are visited in the packer's degree-sorted order so the eight lists a wave walks
+// together have (nearly) equal length; chunks of eight are dealt to the 16 waves in serpentine order.
+// 16 waves per workgroup x 2 workgroups per CU = the full 8 waves per SIMD.
 //
-// The kernels are VALU-bound (PMC: SQ_ACTIVE_INST_VALU saturated), so the inner loop is trimmed to the
-// transcendental minimum: P and Q are staged PRE-SCALED by 2*log2(e), so with E = 2^(P'_v + Q'_u + b')
-//   tanh(x) = 1 - 2 r,  r = 1 / (1 + E)          (v_exp_f32 + v_rcp_f32, abs error ~1e-7, clean saturation)
-// the forward only accumulates r (sum of tanh = 2 deg - 2 sum r) and the backward uses
-//   1 - tanh^2 = 4 (r - r^2).
+// The kernels are VALU-issue bound (PMC: SQ_ACTIVE_INST_VALU ~80 % of the SIMD cycles), so the walk is trimmed to
+// the minimum: P and Q are staged as 2^(2 log2e P), 2^(2 log2e Q) ("exp form", stage_pq_exp below), so with
+//   E = 2^(2 log2e (P_v + Q_u + b)) = eP_v * eb * eQ_u,   r = 1 / (1 + E) = v_rcp_f32(fma(eP_v eb, eQ_u, 1))
+//   tanh(x) = 1 - 2 r                                      (abs error ~1e-7, clean saturation)
+// the forward only accumulates r (sum of tanh = 2 deg - 2 sum r) and the backward uses 1 - tanh^2 = 4 (r - r^2):
+// 2 FMAs + 2 v_rcp_f32 per incidence and column, no exponential in the loop.  Workgroups whose slice leaves the
+// safe exponent range fall back to the linear form (P, Q pre-scaled by 2 log2e, v_exp_f32 in the loop).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace upamd {
@@ -85,6 +90,37 @@ __device__ __forceinline__ void stage_pq(float2 *PQl, const float *Pg, const flo
     }
 }
 
+// Exp-form staging: PQ[v][c] = (2^(C2 P), 2^(C2 Q)).  2^(P'_v + Q'_u + b') = 2^(P'_v + b') * 2^(Q'_u) moves both
+// exponentials out of the incidence loop (n*32 v_exp_f32 per item instead of 2 per incidence and column):
+//   r = 1 / (1 + E) = rcp(fma(eP_v, eQ_u, 1)).
+// Only valid while no factor over/underflows: every |C2 P|, |C2 Q| <= EF_LIMIT and |C2 b| <= EF_BIAS_LIMIT keep
+// all factors and products inside [2^-118, 2^118].  The function returns false otherwise and the workgroup
+// re-stages in linear form and walks with the exponentials inside the loop (same math, any magnitude).
+constexpr float EF_LIMIT = 56.f, EF_BIAS_LIMIT = 6.f;
+
+__device__ __forceinline__ bool stage_pq_exp(float2 *PQl, const float *Pg, const float *Qg, int n) {
+    const float4 *p4 = reinterpret_cast<const float4 *>(Pg);
+    const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < n * 4; i += EDGE_THREADS) {
+        const float4 pp = p4[i], qq = q4[i];
+        const float ax = C2 * pp.x, ay = C2 * pp.y, az = C2 * pp.z, aw = C2 * pp.w;
+        const float bx = C2 * qq.x, by = C2 * qq.y, bz = C2 * qq.z, bw = C2 * qq.w;
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fmaxf(fabsf(az), fabsf(aw))),
+                             fmaxf(fmaxf(fabsf(bx), fabsf(by)), fmaxf(fabsf(bz), fabsf(bw)))));
+        float4 *d = reinterpret_cast<float4 *>(PQl + i * 4);
+        d[0] = make_float4(__builtin_amdgcn_exp2f(ax), __builtin_amdgcn_exp2f(bx), __builtin_amdgcn_exp2f(ay),
+                           __builtin_amdgcn_exp2f(by));
+        d[1] = make_float4(__builtin_amdgcn_exp2f(az), __builtin_amdgcn_exp2f(bz), __builtin_amdgcn_exp2f(aw),
+                           __builtin_amdgcn_exp2f(bw));
+    }
+    return mx <= EF_LIMIT;
+}
+
+__device__ __forceinline__ float rcp1p_mul(float a, float b) {      // 1 / (1 + a*b)
+    return __builtin_amdgcn_rcpf(fmaf(a, b, 1.0f));
+}
+
 // ------------------------------------------------------------------------------------------
 // forward: H_out = H_in + S / (deg + 1e-6).  The last layer also emits the masked node mean, the edge
 // mean (= 1/2 sum_v S_v / e: every message is counted at both of its endpoints) and -- fused, while the
@@ -107,15 +143,17 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, M
     const int n = m[0], e = m[1];
     const int64_t o = mb.node_off[b], M = mb.M;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int c = lane & 15, g = lane >> 4;
+    const int ca = 2 * (lane & 7), g = lane >> 3;      // this lane's two columns (ca, ca+1); node slot within the wave
     const EdgeLds L = carve(smem, n, e, STAGE, false);
 
     const float *Pg = PQ + ((int64_t)(2 * p) * M + o) * 16;
     const float *Qg = PQ + ((int64_t)(2 * p + 1) * M + o) * 16;
     const float *Hg = Hin + ((int64_t)p * M + o) * 16;
     float *Ho = Hout + ((int64_t)p * M + o) * 16;
+    const float2 bc = make_float2(C2 * bias[p * 16 + ca], C2 * bias[p * 16 + ca + 1]);
+    bool ok = false;
     if (STAGE) {
-        stage_pq(L.PQ, Pg, Qg, n);
+        ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
         const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
         for (int i = tid; i < n * 4; i += EDGE_THREADS) reinterpret_cast<float4 *>(L.X)[i] = h4[i];
     }
@@ -129,74 +167,110 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, M
         L.ord[i] = og[i];
         L.nm[i] = nmg[i];
     }
-    __syncthreads();
+    bool ef = false;                       // LDS holds the exp form (workgroup-uniform)
+    if (STAGE) {
+        ef = !__syncthreads_or(ok ? 0 : 1);
+        if (!ef) {                         // magnitudes outside the exp-form range: linear form, exponentials in the loop
+            stage_pq(L.PQ, Pg, Qg, n);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
 
-    // scaled (P,Q) of node u for this lane's column
-    auto pq = [&](int u) -> float2 {
-        if (STAGE) return L.PQ[u * 16 + c];
-        return make_float2(C2 * Pg[u * 16 + c], C2 * Qg[u * 16 + c]);
+    // (P_ca, Q_ca, P_ca+1, Q_ca+1) of node u: exp form or scaled linear form
+    auto pq4 = [&](int u) -> float4 {
+        if (STAGE) return *reinterpret_cast<const float4 *>(L.PQ + u * 16 + ca);
+        const float2 pp = *reinterpret_cast<const float2 *>(Pg + u * 16 + ca);
+        const float2 qq = *reinterpret_cast<const float2 *>(Qg + u * 16 + ca);
+        return make_float4(C2 * pp.x, C2 * qq.x, C2 * pp.y, C2 * qq.y);
     };
-    const float bc = C2 * bias[p * 16 + c];
-    float sumS = 0.f, sumH = 0.f;
-    const int nchunks = (n + 3) >> 2;
-    for (int j = w; j < nchunks; j += EDGE_WAVES) {
-        const int vi = 4 * j + g;
-        const bool valid = vi < n;
-        const int v = L.ord[valid ? vi : n - 1];
-        const float2 own = pq(v);
-        const float pv = own.x + bc, qv = own.y + bc;
-        int k = L.rp[v];
-        const int k1 = valid ? L.rp[v + 1] : k;
-        const float degf = (float)(k1 - k);
-        float accR = 0.f;                  // sum over incidences of r1 + r2
-        for (; k < k1; ++k) {
-            const float2 nbv = pq(L.nb[k]);
-            accR += rcp1p_exp2(pv + nbv.y) + rcp1p_exp2(nbv.x + qv);
-        }
-        if (valid) {
-            const float S = degf - accR;   // 1/2 sum (tanh1 + tanh2) = 1/2 (2 deg - 2 accR)
-            const float a = S / (degf + 1e-6f);
-            float h;
-            if (STAGE) {
-                h = L.X[v * 16 + c] + a;
-                L.X[v * 16 + c] = h;
-            } else {
-                h = Hg[v * 16 + c] + a;
-                Ho[v * 16 + c] = h;
+    float2 sumS = make_float2(0.f, 0.f), sumH = make_float2(0.f, 0.f);
+    auto walk = [&](auto efc) {
+        constexpr bool EF = decltype(efc)::value;
+        // r for an own-side value (bias folded in) and a neighbour-side value
+        auto r = [](float a, float nb) -> float { return EF ? rcp1p_mul(a, nb) : rcp1p_exp2(a + nb); };
+        const float2 eb = make_float2(EF ? __builtin_amdgcn_exp2f(bc.x) : bc.x, EF ? __builtin_amdgcn_exp2f(bc.y) : bc.y);
+        auto fold = [&](float x, float bb) -> float { return EF ? x * bb : x + bb; };
+        const int nchunks = (n + 7) >> 3;
+        // chunks are dealt to the waves in serpentine order (0..15, 31..16, 32..47, ...): the degree-sorted chunks get
+        // shorter and shorter, so plain round-robin would give wave 0 the longest chunk of every round
+        for (int rnd = 0, j = w; rnd * EDGE_WAVES < nchunks; ++rnd, j = rnd * EDGE_WAVES + ((rnd & 1) ? EDGE_WAVES - 1 - w : w)) {
+            if (j >= nchunks) continue;
+            const int vi = 8 * j + g;
+            const bool valid = vi < n;
+            const int v = L.ord[valid ? vi : n - 1];
+            const float4 own = pq4(v);
+            const float pv0 = fold(own.x, eb.x), qv0 = fold(own.y, eb.x), pv1 = fold(own.z, eb.y), qv1 = fold(own.w, eb.y);
+            int k = L.rp[v];
+            const int k1 = valid ? L.rp[v + 1] : k;
+            const float degf = (float)(k1 - k);
+            float acc0 = 0.f, acc1 = 0.f;          // sums over incidences of r1 + r2, per column
+            for (; k < k1; ++k) {
+                const float4 nb = pq4(L.nb[k]);
+                acc0 += r(pv0, nb.y) + r(qv0, nb.x);
+                acc1 += r(pv1, nb.w) + r(qv1, nb.z);
             }
-            if (LAST) {
-                sumS += S;
-                if (L.nm[v]) sumH += h;
+            if (valid) {
+                const float S0 = degf - acc0, S1 = degf - acc1;     // 1/2 sum (tanh1 + tanh2) = 1/2 (2 deg - 2 acc)
+                const float den = degf + 1e-6f;
+                float2 h;
+                if (STAGE) {
+                    float2 *hx = reinterpret_cast<float2 *>(L.X + v * 16 + ca);
+                    h = *hx;
+                    h.x += S0 / den;
+                    h.y += S1 / den;
+                    *hx = h;
+                } else {
+                    h = *reinterpret_cast<const float2 *>(Hg + v * 16 + ca);
+                    h.x += S0 / den;
+                    h.y += S1 / den;
+                    *reinterpret_cast<float2 *>(Ho + v * 16 + ca) = h;
+                }
+                if (LAST) {
+                    sumS.x += S0;
+                    sumS.y += S1;
+                    if (L.nm[v]) {
+                        sumH.x += h.x;
+                        sumH.y += h.y;
+                    }
+                }
             }
         }
-    }
-    if (LAST && FE && m[2] > 0) {
-        // pointer-head inputs of this row's candidate edges (4 candidates per wave pass)
-        const int nh = m[2];
-        const int64_t NH = mb.Nhe, q0 = mb.he_off[b];
-        const float cc = Ccur[(int64_t)b * (NP * 16) + p * 16 + c];
-        for (int q = 4 * w + g; q < nh; q += 4 * EDGE_WAVES) {
-            float mm = 0.f;
-            if (pk.he_live[m[11] + q]) {
-                const float2 vi2 = pq(pk.he_src[m[11] + q]), vj2 = pq(pk.he_dst[m[11] + q]);
-                mm = 1.f - (rcp1p_exp2(vi2.x + vj2.y + bc) + rcp1p_exp2(vj2.x + vi2.y + bc));
+        if (LAST && FE && m[2] > 0) {
+            // pointer-head inputs of this row's candidate edges (8 candidates per wave pass)
+            const int nh = m[2];
+            const int64_t NH = mb.Nhe, q0 = mb.he_off[b];
+            const float2 cc = *reinterpret_cast<const float2 *>(Ccur + (int64_t)b * (NP * 16) + p * 16 + ca);
+            for (int q = 8 * w + g; q < nh; q += 8 * EDGE_WAVES) {
+                float2 mm = make_float2(0.f, 0.f);
+                if (pk.he_live[m[11] + q]) {
+                    const float4 vi4 = pq4(pk.he_src[m[11] + q]), vj4 = pq4(pk.he_dst[m[11] + q]);
+                    mm.x = 1.f - (r(fold(vi4.x, eb.x), vj4.y) + r(fold(vj4.x, eb.x), vi4.y));
+                    mm.y = 1.f - (r(fold(vi4.z, eb.y), vj4.w) + r(fold(vj4.z, eb.y), vi4.w));
+                }
+                const int64_t row = q0 + q;
+                *reinterpret_cast<float2 *>(FE + ((int64_t)p * NH + row) * 16 + ca) = mm;
+                *reinterpret_cast<float2 *>(FE + ((int64_t)(NP + p) * NH + row) * 16 + ca) = make_float2(mm.x * cc.x, mm.y * cc.y);
             }
-            const int64_t row = q0 + q;
-            FE[((int64_t)p * NH + row) * 16 + c] = mm;
-            FE[((int64_t)(NP + p) * NH + row) * 16 + c] = mm * cc;
         }
-    }
+    };
+    if (ef) walk(std::true_type{});
+    else walk(std::false_type{});
     if (STAGE) {
         __syncthreads();
         float4 *o4 = reinterpret_cast<float4 *>(Ho);
         for (int i = tid; i < n * 4; i += EDGE_THREADS) o4[i] = reinterpret_cast<const float4 *>(L.X)[i];
     }
     if (LAST) {
-        sumS += __shfl_xor(sumS, 16); sumS += __shfl_xor(sumS, 32);
-        sumH += __shfl_xor(sumH, 16); sumH += __shfl_xor(sumH, 32);
+#pragma unroll
+        for (int sft = 8; sft <= 32; sft <<= 1) {
+            sumS.x += __shfl_xor(sumS.x, sft); sumS.y += __shfl_xor(sumS.y, sft);
+            sumH.x += __shfl_xor(sumH.x, sft); sumH.y += __shfl_xor(sumH.y, sft);
+        }
         if (g == 0) {
-            L.red[(w * 2 + 0) * 16 + c] = sumS;
-            L.red[(w * 2 + 1) * 16 + c] = sumH;
+            *reinterpret_cast<float2 *>(L.red + (w * 2 + 0) * 16 + ca) = sumS;
+            *reinterpret_cast<float2 *>(L.red + (w * 2 + 1) * 16 + ca) = sumH;
         }
         __syncthreads();
         if (tid < 32) {
@@ -265,7 +339,7 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
     const int n = m[0], e = m[1];
     const int64_t o = mb.node_off[b], M = mb.M;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int c = lane & 15, g = lane >> 4;
+    const int ca = 2 * (lane & 7), g = lane >> 3;      // this lane's two columns (ca, ca+1); node slot within the wave
     const EdgeLds L = carve(smem, n, e, STAGE, true);
 
     const float *Pg = PQ + ((int64_t)(2 * p) * M + o) * 16;
@@ -277,10 +351,23 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
     for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
     const uint16_t *og = pk.order + m[9];
     for (int i = tid; i < n; i += EDGE_THREADS) L.ord[i] = og[i];
-    if (STAGE) stage_pq(L.PQ, Pg, Qg, n);
-    __syncthreads();
-    float extra = 0.f;     // same for every node of the graph; depends on the lane's column only
-    if (LAST) extra = 0.5f * dhbarE[(int64_t)b * ld_dhbarE + p * 16 + c] / (float)e;
+    const float2 bc = make_float2(C2 * bias[p * 16 + ca], C2 * bias[p * 16 + ca + 1]);
+    bool ef = false;                       // LDS holds the exp form (workgroup-uniform), see stage_pq_exp
+    if (STAGE) {
+        const bool ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+        ef = !__syncthreads_or(ok ? 0 : 1);
+        if (!ef) {
+            stage_pq(L.PQ, Pg, Qg, n);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+    float2 extra = make_float2(0.f, 0.f);     // same for every node of the graph; depends on the lane's columns only
+    if (LAST) {
+        const float2 dh = *reinterpret_cast<const float2 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + ca);
+        extra = make_float2(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e);
+    }
     if (STAGE) {
         for (int i = tid; i < n * 16; i += EDGE_THREADS) {
             const int v = i >> 4;
@@ -290,62 +377,82 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
         }
         __syncthreads();
     }
-    auto pq = [&](int u) -> float2 {
-        if (STAGE) return L.PQ[u * 16 + c];
-        return make_float2(C2 * Pg[u * 16 + c], C2 * Qg[u * 16 + c]);
+    auto pq4 = [&](int u) -> float4 {
+        if (STAGE) return *reinterpret_cast<const float4 *>(L.PQ + u * 16 + ca);
+        const float2 pp = *reinterpret_cast<const float2 *>(Pg + u * 16 + ca);
+        const float2 qq = *reinterpret_cast<const float2 *>(Qg + u * 16 + ca);
+        return make_float4(C2 * pp.x, C2 * qq.x, C2 * pp.y, C2 * qq.y);
     };
-    auto ds = [&](int u) -> float {
-        if (STAGE) return L.X[u * 16 + c];
-        return Gg[u * 16 + c] / ((float)(L.rp[u + 1] - L.rp[u]) + 1e-6f) + extra;
+    auto ds2 = [&](int u) -> float2 {
+        if (STAGE) return *reinterpret_cast<const float2 *>(L.X + u * 16 + ca);
+        const float2 gg = *reinterpret_cast<const float2 *>(Gg + u * 16 + ca);
+        const float dg = (float)(L.rp[u + 1] - L.rp[u]) + 1e-6f;
+        return make_float2(gg.x / dg + extra.x, gg.y / dg + extra.y);
     };
-    const float bc = C2 * bias[p * 16 + c];
     const bool heads_on = LAST && dMhe != nullptr && m[2] > 0;
     const int32_t *hpg = pk.hinc_ptr + m[13];
     const uint16_t *hnb = pk.hinc_nbr + 2 * (int64_t)m[11];
     const uint16_t *hhe = pk.hinc_he + 2 * (int64_t)m[11];
-    const float *dMg = heads_on ? dMhe + ((int64_t)p * mb.Nhe + mb.he_off[b]) * 16 + c : nullptr;
-    float sumdP = 0.f, sumdQ = 0.f;
-    const int nchunks = (n + 3) >> 2;
-    for (int j = w; j < nchunks; j += EDGE_WAVES) {
-        const int vi = 4 * j + g;
-        const bool valid = vi < n;
-        const int v = L.ord[valid ? vi : n - 1];
-        int k = L.rp[v];
-        const int k1 = valid ? L.rp[v + 1] : k;
-        const float2 own = pq(v);
-        const float pv = own.x + bc, qv = own.y + bc, sv = ds(v);
-        float accP = 0.f, accQ = 0.f;     // sums of dm * (r - r^2); 1 - tanh^2 = 4 (r - r^2)
-        for (; k < k1; ++k) {
-            const int u = L.nb[k];
-            const float2 nbv = pq(u);
-            const float dm = sv + ds(u);
-            const float r1 = rcp1p_exp2(pv + nbv.y), r2 = rcp1p_exp2(nbv.x + qv);
-            accP = fmaf(dm, fmaf(-r1, r1, r1), accP);
-            accQ = fmaf(dm, fmaf(-r2, r2, r2), accQ);
-        }
-        if (heads_on && valid) {
-            for (int hk = hpg[v]; hk < hpg[v + 1]; ++hk) {
-                const float2 nbv = pq(hnb[hk]);
-                const float dmh = dMg[(int64_t)hhe[hk] * 16];
-                const float r1 = rcp1p_exp2(pv + nbv.y), r2 = rcp1p_exp2(nbv.x + qv);
-                accP = fmaf(dmh, fmaf(-r1, r1, r1), accP);
-                accQ = fmaf(dmh, fmaf(-r2, r2, r2), accQ);
+    const float *dMg = heads_on ? dMhe + ((int64_t)p * mb.Nhe + mb.he_off[b]) * 16 + ca : nullptr;
+    float2 sumdP = make_float2(0.f, 0.f), sumdQ = make_float2(0.f, 0.f);
+    auto walk = [&](auto efc) {
+        constexpr bool EF = decltype(efc)::value;
+        auto r = [](float a, float nb) -> float { return EF ? rcp1p_mul(a, nb) : rcp1p_exp2(a + nb); };
+        const float2 eb = make_float2(EF ? __builtin_amdgcn_exp2f(bc.x) : bc.x, EF ? __builtin_amdgcn_exp2f(bc.y) : bc.y);
+        auto fold = [&](float x, float bb) -> float { return EF ? x * bb : x + bb; };
+        const int nchunks = (n + 7) >> 3;
+        // chunks are dealt to the waves in serpentine order (0..15, 31..16, 32..47, ...): the degree-sorted chunks get
+        // shorter and shorter, so plain round-robin would give wave 0 the longest chunk of every round
+        for (int rnd = 0, j = w; rnd * EDGE_WAVES < nchunks; ++rnd, j = rnd * EDGE_WAVES + ((rnd & 1) ? EDGE_WAVES - 1 - w : w)) {
+            if (j >= nchunks) continue;
+            const int vi = 8 * j + g;
+            const bool valid = vi < n;
+            const int v = L.ord[valid ? vi : n - 1];
+            int k = L.rp[v];
+            const int k1 = valid ? L.rp[v + 1] : k;
+            const float4 own = pq4(v);
+            const float pv0 = fold(own.x, eb.x), qv0 = fold(own.y, eb.x), pv1 = fold(own.z, eb.y), qv1 = fold(own.w, eb.y);
+            const float2 sv = ds2(v);
+            // sums of dm * (r - r^2) per column; 1 - tanh^2 = 4 (r - r^2)
+            float aP0 = 0.f, aQ0 = 0.f, aP1 = 0.f, aQ1 = 0.f;
+            auto add = [&](const float4 &nb, float dm0, float dm1) {
+                const float r1 = r(pv0, nb.y), r2 = r(qv0, nb.x), r3 = r(pv1, nb.w), r4 = r(qv1, nb.z);
+                aP0 = fmaf(dm0, fmaf(-r1, r1, r1), aP0);
+                aQ0 = fmaf(dm0, fmaf(-r2, r2, r2), aQ0);
+                aP1 = fmaf(dm1, fmaf(-r3, r3, r3), aP1);
+                aQ1 = fmaf(dm1, fmaf(-r4, r4, r4), aQ1);
+            };
+            for (; k < k1; ++k) {
+                const int u = L.nb[k];
+                const float2 su = ds2(u);
+                add(pq4(u), sv.x + su.x, sv.y + su.y);
+            }
+            if (heads_on && valid) {
+                for (int hk = hpg[v]; hk < hpg[v + 1]; ++hk) {
+                    const float2 dmh = *reinterpret_cast<const float2 *>(dMg + (int64_t)hhe[hk] * 16);
+                    add(pq4(hnb[hk]), dmh.x, dmh.y);
+                }
+            }
+            if (valid) {
+                const float2 dP = make_float2(2.f * aP0, 2.f * aP1), dQ = make_float2(2.f * aQ0, 2.f * aQ1);     // 1/2 * 4
+                *reinterpret_cast<float2 *>(dPQ + ((int64_t)(2 * p) * M + o + v) * 16 + ca) = dP;
+                *reinterpret_cast<float2 *>(dPQ + ((int64_t)(2 * p + 1) * M + o + v) * 16 + ca) = dQ;
+                sumdP.x += dP.x; sumdP.y += dP.y;
+                sumdQ.x += dQ.x; sumdQ.y += dQ.y;
             }
         }
-        if (valid) {
-            const float dP = 2.f * accP, dQ = 2.f * accQ;       // 1/2 * 4
-            dPQ[((int64_t)(2 * p) * M + o + v) * 16 + c] = dP;
-            dPQ[((int64_t)(2 * p + 1) * M + o + v) * 16 + c] = dQ;
-            sumdP += dP;
-            sumdQ += dQ;
-        }
-    }
+    };
+    if (ef) walk(std::true_type{});
+    else walk(std::false_type{});
     // per-graph column sums of dP and dQ (bias gradient = sum dP; layer 1 also needs sum dQ), P/Q panel order
-    sumdP += __shfl_xor(sumdP, 16); sumdP += __shfl_xor(sumdP, 32);
-    sumdQ += __shfl_xor(sumdQ, 16); sumdQ += __shfl_xor(sumdQ, 32);
+#pragma unroll
+    for (int sft = 8; sft <= 32; sft <<= 1) {
+        sumdP.x += __shfl_xor(sumdP.x, sft); sumdP.y += __shfl_xor(sumdP.y, sft);
+        sumdQ.x += __shfl_xor(sumdQ.x, sft); sumdQ.y += __shfl_xor(sumdQ.y, sft);
+    }
     if (g == 0) {
-        L.red[(w * 2 + 0) * 16 + c] = sumdP;
-        L.red[(w * 2 + 1) * 16 + c] = sumdQ;
+        *reinterpret_cast<float2 *>(L.red + (w * 2 + 0) * 16 + ca) = sumdP;
+        *reinterpret_cast<float2 *>(L.red + (w * 2 + 1) * 16 + ca) = sumdQ;
     }
     __syncthreads();
     if (tid < 32) {
