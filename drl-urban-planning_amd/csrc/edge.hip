@@ -213,18 +213,18 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, M
             }
             if (valid) {
                 const float S0 = degf - acc0, S1 = degf - acc1;     // 1/2 sum (tanh1 + tanh2) = 1/2 (2 deg - 2 acc)
-                const float den = degf + 1e-6f;
+                const float inv = __builtin_amdgcn_rcpf(degf + 1e-6f);      // 1-ulp reciprocal instead of two IEEE divisions
                 float2 h;
                 if (STAGE) {
                     float2 *hx = reinterpret_cast<float2 *>(L.X + v * 16 + ca);
                     h = *hx;
-                    h.x += S0 / den;
-                    h.y += S1 / den;
+                    h.x = fmaf(S0, inv, h.x);
+                    h.y = fmaf(S1, inv, h.y);
                     *hx = h;
                 } else {
                     h = *reinterpret_cast<const float2 *>(Hg + v * 16 + ca);
-                    h.x += S0 / den;
-                    h.y += S1 / den;
+                    h.x = fmaf(S0, inv, h.x);
+                    h.y = fmaf(S1, inv, h.y);
                     *reinterpret_cast<float2 *>(Ho + v * 16 + ca) = h;
                 }
                 if (LAST) {
@@ -369,11 +369,18 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
         extra = make_float2(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e);
     }
     if (STAGE) {
-        for (int i = tid; i < n * 16; i += EDGE_THREADS) {
-            const int v = i >> 4;
-            float ex = 0.f;
-            if (LAST) ex = 0.5f * dhbarE[(int64_t)b * ld_dhbarE + p * 16 + (i & 15)] / (float)e;
-            L.X[i] = Gg[i] / ((float)(L.rp[v + 1] - L.rp[v]) + 1e-6f) + ex;
+        float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);       // the thread's four columns are the same on every trip
+        if (LAST) {
+            const float4 dh = *reinterpret_cast<const float4 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + (tid & 3) * 4);
+            ex4 = make_float4(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e, 0.5f * dh.z / (float)e, 0.5f * dh.w / (float)e);
+        }
+        const float4 *g4 = reinterpret_cast<const float4 *>(Gg);
+        for (int i = tid; i < n * 4; i += EDGE_THREADS) {
+            const int v = i >> 2;
+            const float inv = __builtin_amdgcn_rcpf((float)(L.rp[v + 1] - L.rp[v]) + 1e-6f);
+            const float4 gg = g4[i];
+            reinterpret_cast<float4 *>(L.X)[i] = make_float4(fmaf(gg.x, inv, ex4.x), fmaf(gg.y, inv, ex4.y),
+                                                             fmaf(gg.z, inv, ex4.z), fmaf(gg.w, inv, ex4.w));
         }
         __syncthreads();
     }
@@ -386,8 +393,8 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
     auto ds2 = [&](int u) -> float2 {
         if (STAGE) return *reinterpret_cast<const float2 *>(L.X + u * 16 + ca);
         const float2 gg = *reinterpret_cast<const float2 *>(Gg + u * 16 + ca);
-        const float dg = (float)(L.rp[u + 1] - L.rp[u]) + 1e-6f;
-        return make_float2(gg.x / dg + extra.x, gg.y / dg + extra.y);
+        const float inv = __builtin_amdgcn_rcpf((float)(L.rp[u + 1] - L.rp[u]) + 1e-6f);
+        return make_float2(fmaf(gg.x, inv, extra.x), fmaf(gg.y, inv, extra.y));
     };
     const bool heads_on = LAST && dMhe != nullptr && m[2] > 0;
     const int32_t *hpg = pk.hinc_ptr + m[13];
