@@ -29,6 +29,9 @@ namespace upamd {
 
 #define META(t) (pk.meta + (int64_t)(t) * UPAMD_META_STRIDE)
 
+// Every kernel here is capped at 72 SGPRs (amdgpu_num_sgpr): the runtime's trap handler adds 16 SGPRs to each wave's
+// allocation, so a kernel above 80 SGPRs allocates 112 -> 7 waves per SIMD -> with 16-wave workgroups only ONE
+// workgroup per CU instead of two (measured: the last-layer forward went from 1.62 ms back to 1.05 ms).
 constexpr int EDGE_THREADS = 1024;
 constexpr int EDGE_WAVES = EDGE_THREADS / 64;
 constexpr int64_t LDS_LIMIT = 160 * 1024;
@@ -53,6 +56,18 @@ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage) 
     return b;
 }
 
+// Last layer: how many candidate edges per row can be staged next to the graph slice without giving up the
+// second resident workgroup per CU (<= 80 KB each), or at all (<= 160 KB).  `fixed` = bytes staged regardless of
+// the candidate count (backward: the per-node candidate-incidence pointers), `per_cand` = bytes per candidate.
+static int aux_capacity(int64_t lds, int64_t fixed, int per_cand) {
+    // never trade the second resident workgroup for it (some slack: the allocation granularity is not 1 byte)
+    const int64_t limit = lds <= LDS_LIMIT / 2 - 2048 ? LDS_LIMIT / 2 - 2048 : LDS_LIMIT;
+    if (lds + fixed > limit) return -1;                                          // not even the fixed part fits
+    int64_t cap = (limit - lds - fixed) / per_cand / 8 * 8;
+    if (cap > 4096) cap = 4096;
+    return (int)cap;
+}
+
 struct EdgeLds {
     float2 *PQ;
     float *X;          // H (forward) or dS (backward)
@@ -60,6 +75,7 @@ struct EdgeLds {
     uint16_t *nb, *ord;
     uint8_t *nm;
     float *red;
+    unsigned char *aux;   // last layer: the row's candidate-edge lists (sized by the launcher from the spare LDS)
 };
 
 __device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool stage, bool bwd) {
@@ -75,6 +91,7 @@ __device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool
     L.nm = reinterpret_cast<uint8_t *>(smem + o);
     if (!bwd) o += ((int64_t)n + 15) / 16 * 16;
     L.red = reinterpret_cast<float *>(smem + o);
+    L.aux = smem + o + EDGE_WAVES * 2 * 16 * 4;
     return L;
 }
 
@@ -130,12 +147,13 @@ __device__ __forceinline__ float rcp1p_mul(float a, float b) {      // 1 / (1 + 
 // the c-only term becomes a per-row bias.
 // ------------------------------------------------------------------------------------------
 template <bool LAST, bool STAGE>
-__global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
+__global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
                                                                 const float *__restrict__ PQ,
                                                                 const float *__restrict__ bias,
                                                                 const float *__restrict__ Hin, float *__restrict__ Hout,
                                                                 float *__restrict__ hbarV, float *__restrict__ hbarE,
-                                                                const float *__restrict__ Ccur, float *__restrict__ FE) {
+                                                                const float *__restrict__ Ccur, float *__restrict__ FE,
+                                                                int aux_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int t = mb.idx[b];
@@ -166,6 +184,19 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, M
     for (int i = tid; i < n; i += EDGE_THREADS) {
         L.ord[i] = og[i];
         L.nm[i] = nmg[i];
+    }
+    // last layer: the row's candidate edges (endpoints, live flag) next to the slice, so the pointer-head pass
+    // below does not chase them through global memory
+    const int nh = LAST ? m[2] : 0;
+    const bool cand_lds = LAST && FE && nh > 0 && nh <= aux_cap;
+    uint16_t *a_src = reinterpret_cast<uint16_t *>(L.aux), *a_dst = a_src + (aux_cap > 0 ? aux_cap : 0);
+    uint8_t *a_live = reinterpret_cast<uint8_t *>(a_dst + (aux_cap > 0 ? aux_cap : 0));
+    if (cand_lds) {
+        for (int i = tid; i < nh; i += EDGE_THREADS) {
+            a_src[i] = pk.he_src[m[11] + i];
+            a_dst[i] = pk.he_dst[m[11] + i];
+            a_live[i] = pk.he_live[m[11] + i];
+        }
     }
     bool ef = false;                       // LDS holds the exp form (workgroup-uniform)
     if (STAGE) {
@@ -237,15 +268,15 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_fwd_kernel(PackedView pk, M
                 }
             }
         }
-        if (LAST && FE && m[2] > 0) {
+        if (LAST && FE && nh > 0) {
             // pointer-head inputs of this row's candidate edges (8 candidates per wave pass)
-            const int nh = m[2];
             const int64_t NH = mb.Nhe, q0 = mb.he_off[b];
             const float2 cc = *reinterpret_cast<const float2 *>(Ccur + (int64_t)b * (NP * 16) + p * 16 + ca);
             for (int q = 8 * w + g; q < nh; q += 8 * EDGE_WAVES) {
                 float2 mm = make_float2(0.f, 0.f);
-                if (pk.he_live[m[11] + q]) {
-                    const float4 vi4 = pq4(pk.he_src[m[11] + q]), vj4 = pq4(pk.he_dst[m[11] + q]);
+                if (cand_lds ? a_live[q] : pk.he_live[m[11] + q]) {
+                    const float4 vi4 = pq4(cand_lds ? a_src[q] : pk.he_src[m[11] + q]);
+                    const float4 vj4 = pq4(cand_lds ? a_dst[q] : pk.he_dst[m[11] + q]);
                     mm.x = 1.f - (r(fold(vi4.x, eb.x), vj4.y) + r(fold(vj4.x, eb.x), vi4.y));
                     mm.y = 1.f - (r(fold(vi4.z, eb.y), vj4.w) + r(fold(vj4.z, eb.y), vi4.w));
                 }
@@ -296,6 +327,11 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
         lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, false);
         if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_fwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
     }
+    int aux_cap = 0;
+    if (last && FE) {
+        aux_cap = std::max(aux_capacity(lds, 0, 5), 0);       // u16 src + u16 dst + u8 live per candidate
+        lds += a16((int64_t)aux_cap * 5);
+    }
     const int began = prof_begin(prof, "edge_fwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
 #define UPAMD_EF(L_, S_)                                                                                              \
@@ -304,7 +340,7 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
             UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_>),                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
         hipLaunchKernelGGL((edge_fwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, Hout,  \
-                           hbarV, hbarE, Ccur, FE);                                                                   \
+                           hbarV, hbarE, Ccur, FE, aux_cap);                                                          \
     } while (0)
     if (last && stage) UPAMD_EF(true, true);
     else if (last) UPAMD_EF(true, false);
@@ -325,13 +361,13 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
 // candidate-incidence lists after the main walk, so the main loop stays branch-free.
 // ------------------------------------------------------------------------------------------
 template <bool LAST, bool STAGE>
-__global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, MbView mb, int NP,
+__global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) void edge_bwd_kernel(PackedView pk, MbView mb, int NP,
                                                                 const float *__restrict__ PQ,
                                                                 const float *__restrict__ bias,
                                                                 const float *__restrict__ G,
                                                                 const float *__restrict__ dhbarE, int ld_dhbarE,
                                                                 const float *__restrict__ dMhe, float *__restrict__ dPQ,
-                                                                float *__restrict__ dbias_part) {
+                                                                float *__restrict__ dbias_part, int aux_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int t = mb.idx[b];
@@ -351,6 +387,24 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
     for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
     const uint16_t *og = pk.order + m[9];
     for (int i = tid; i < n; i += EDGE_THREADS) L.ord[i] = og[i];
+    // last layer: the per-node candidate-incidence pointers (aux_cap >= 0) and, when they fit, the lists themselves
+    // are staged too -- otherwise every node pass would pay a global round trip just to learn it has no candidate
+    const bool heads_on = LAST && dMhe != nullptr && m[2] > 0;
+    const int32_t *hpg = pk.hinc_ptr + m[13];
+    const uint16_t *hnb = pk.hinc_nbr + 2 * (int64_t)m[11];
+    const uint16_t *hhe = pk.hinc_he + 2 * (int64_t)m[11];
+    const bool hp_lds = heads_on && aux_cap >= 0, hl_lds = hp_lds && m[2] <= aux_cap;
+    int *a_hp = reinterpret_cast<int *>(L.aux);
+    uint16_t *a_hnb = reinterpret_cast<uint16_t *>(L.aux + ((int64_t)n + 1 + 3) / 4 * 16);
+    uint16_t *a_hhe = a_hnb + 2 * (aux_cap > 0 ? aux_cap : 0);
+    if (hp_lds)
+        for (int i = tid; i <= n; i += EDGE_THREADS) a_hp[i] = hpg[i];
+    if (hl_lds) {
+        for (int i = tid; i < m[2]; i += EDGE_THREADS) {       // two entries (both endpoints) per candidate
+            reinterpret_cast<uint32_t *>(a_hnb)[i] = reinterpret_cast<const uint32_t *>(hnb)[i];
+            reinterpret_cast<uint32_t *>(a_hhe)[i] = reinterpret_cast<const uint32_t *>(hhe)[i];
+        }
+    }
     const float2 bc = make_float2(C2 * bias[p * 16 + ca], C2 * bias[p * 16 + ca + 1]);
     bool ef = false;                       // LDS holds the exp form (workgroup-uniform), see stage_pq_exp
     if (STAGE) {
@@ -396,10 +450,6 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
         const float inv = __builtin_amdgcn_rcpf((float)(L.rp[u + 1] - L.rp[u]) + 1e-6f);
         return make_float2(fmaf(gg.x, inv, extra.x), fmaf(gg.y, inv, extra.y));
     };
-    const bool heads_on = LAST && dMhe != nullptr && m[2] > 0;
-    const int32_t *hpg = pk.hinc_ptr + m[13];
-    const uint16_t *hnb = pk.hinc_nbr + 2 * (int64_t)m[11];
-    const uint16_t *hhe = pk.hinc_he + 2 * (int64_t)m[11];
     const float *dMg = heads_on ? dMhe + ((int64_t)p * mb.Nhe + mb.he_off[b]) * 16 + ca : nullptr;
     float2 sumdP = make_float2(0.f, 0.f), sumdQ = make_float2(0.f, 0.f);
     auto walk = [&](auto efc) {
@@ -435,9 +485,24 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_bwd_kernel(PackedView pk, M
                 add(pq4(u), sv.x + su.x, sv.y + su.y);
             }
             if (heads_on && valid) {
-                for (int hk = hpg[v]; hk < hpg[v + 1]; ++hk) {
-                    const float2 dmh = *reinterpret_cast<const float2 *>(dMg + (int64_t)hhe[hk] * 16);
-                    add(pq4(hnb[hk]), dmh.x, dmh.y);
+                // candidate gradients live in global memory: fetch HB of them per trip so their latencies overlap;
+                // a padding entry has dm = 0 and adds exactly nothing
+                constexpr int HB = 3;
+                const int hk1 = hp_lds ? a_hp[v + 1] : hpg[v + 1];
+                for (int hk = hp_lds ? a_hp[v] : hpg[v]; hk < hk1; hk += HB) {
+                    float2 dmh[HB];
+                    int uu[HB];
+#pragma unroll
+                    for (int i = 0; i < HB; ++i) {
+                        const bool in = hk + i < hk1;
+                        const int kk = in ? hk + i : hk;
+                        const int he = hl_lds ? a_hhe[kk] : hhe[kk];
+                        uu[i] = hl_lds ? a_hnb[kk] : hnb[kk];
+                        dmh[i] = *reinterpret_cast<const float2 *>(dMg + (int64_t)he * 16);
+                        if (!in) dmh[i] = make_float2(0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < HB; ++i) add(pq4(uu[i]), dmh[i].x, dmh[i].y);
                 }
             }
             if (valid) {
@@ -482,6 +547,12 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
         lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, false);
         if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_bwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
     }
+    int aux_cap = -1;
+    if (last && dMhe) {
+        const int64_t fixed = a16(((int64_t)mb.max_n + 1) * 4);
+        aux_cap = aux_capacity(lds, fixed, 8);               // two u16 lists with two entries per candidate
+        if (aux_cap >= 0) lds += fixed + a16((int64_t)aux_cap * 8);
+    }
     const int began = prof_begin(prof, "edge_bwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
 #define UPAMD_EB(L_, S_)                                                                                              \
@@ -490,7 +561,7 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
             UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_>),                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
         hipLaunchKernelGGL((edge_bwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G, dhbarE,  \
-                           ld_dhbarE, dMhe, dPQ, dbias_part);                                                         \
+                           ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap);                                                \
     } while (0)
     if (last && stage) UPAMD_EB(true, true);
     else if (last) UPAMD_EB(true, false);

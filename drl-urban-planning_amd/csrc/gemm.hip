@@ -422,7 +422,7 @@ int tn_splits(int I, int J, int64_t M) {
     } else {
         tiles = ((int64_t)I * J + 255) / 256;
     }
-    int64_t S = (1024 + tiles - 1) / tiles;
+    int64_t S = (768 + tiles - 1) / tiles;       // ~3 workgroups per CU: measured best (1024: -2 %, 512: -1 %)
     const int64_t max_s = (M + 127) / 128;   // at least 128 rows per split
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
