@@ -601,8 +601,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // gradients): dWe = G^0^T X = G^1^T X + Wcat_1^T (dPQ_1^T X),  dbe = colsum(G^1) + Wcat_1^T colsum(dPQ_1).
     // G holds G^1 and "dPQ" holds dPQ_1 here; this replaces a full-size dgrad GEMM by two K = M, J = 32 ones.
     CK(launch_gemm_tn(G, D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
-    CK(launch_reduce_slabs(W("slabs"), S, D, 32, 0, x.F, GR(P.node_w), x.F, st));
-    CK(launch_colsum_pm(G, mb.M, D, nullptr, W("cs_part"), GR(P.node_b), st));
+    // Xp's column 31 is all ones (gather_inputs), so column 31 of G^1^T Xp is colsum(G^1): straight into dbe
+    CK(launch_reduce_slabs(W("slabs"), S, D, 32, 0, x.F, GR(P.node_w), x.F, st, GR(P.node_b)));
     // "Tn" = dPQ_1^T Xp and "cs1" = colsum(dPQ_1) come from the l = 1 iteration of the loop above
     CK(launch_smm(D, x.F, 2 * D, W("WcatT0"), 2 * D, 1, W("Tn"), 32, 1, nullptr, GR(P.node_w), x.F, 1, 0, 1.f, st));
     CK(launch_smm(1, D, 2 * D, W("cs1"), 2 * D, 1, W("WcatT0"), 1, 2 * D, nullptr, GR(P.node_b), D, 1, 0, 1.f, st));

@@ -492,7 +492,7 @@ int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, flo
 }
 
 __global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int S, int I, int J, int mode, int jkeep,
-                                    float *__restrict__ dst, int ldd) {
+                                    float *__restrict__ dst, int ldd, float *__restrict__ last_col_dst) {
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= I * J) return;
     const int i = ij / J, j = ij % J;
@@ -500,6 +500,7 @@ __global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int S, int 
     for (int s = 0; s < S; ++s) acc += slabs[(int64_t)s * I * J + ij];
     if (mode == 0) {
         if (j < jkeep) dst[(int64_t)i * ldd + j] += acc;
+        if (last_col_dst && j == J - 1) last_col_dst[i] += acc;      // the B operand's last column was all ones: a column sum
     } else if (mode == 1) {
         dst[(int64_t)j * ldd + i] += acc;
     } else {
@@ -511,8 +512,9 @@ __global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int S, int 
 }
 
 int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int jkeep, float *dst, int ldd,
-                        hipStream_t st) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, slabs, S, I, J, mode, jkeep, dst, ldd);
+                        hipStream_t st, float *last_col_dst) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, slabs, S, I, J, mode, jkeep, dst, ldd,
+                       last_col_dst);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

@@ -28,6 +28,8 @@ __global__ __launch_bounds__(256) void gather_inputs_kernel(PackedView pk, MbVie
         const int v = i >> 3, q = i & 7;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < 6) val = *reinterpret_cast<const float4 *>(pk.X + (src0 + v) * UPAMD_NODE_PAD + q * 4);
+        if (q == 7) val.w = 1.0f;      // column 31 = 1: a weight-gradient GEMM against Xp also yields the column sums
+                                       // (the forward weights of that column are zero padding)
         const int panel = q >> 2, c4 = (q & 3) * 4;
         *reinterpret_cast<float4 *>(Xp + ((int64_t)panel * M + o + v) * 16 + c4) = val;
     }

@@ -79,7 +79,7 @@ int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, flo
 // dst (+)= sum_s slabs[s]:  mode 0: dst[i*ldd + j], j < jkeep;  mode 1: dst[j*ldd + i];
 // mode 2: GCN un-permute, slab row j' -> dst[((j'/32)*16 + j'%16)*ldd + ((j'/16)&1)*J + k]
 int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int jkeep, float *dst, int ldd,
-                        hipStream_t st);
+                        hipStream_t st, float *last_col_dst = nullptr);
 
 // ---- graph.hip -------------------------------------------------------------------------
 int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st);
