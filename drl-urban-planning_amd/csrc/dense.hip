@@ -222,23 +222,24 @@ int launch_tanh_bwd(float *dz, const float *y, int64_t n, hipStream_t st) {
 // state_value = [h_num ; mean nodes ; mean edges ; attended current node ; stage]  (state_encoder.py:204-205)
 __global__ void assemble_sv_kernel(PackedView pk, MbView mb, int D, int S_last, const float *__restrict__ Ulast,
                                    const float *__restrict__ hbarV, const float *__restrict__ hbarE,
-                                   const float *__restrict__ att, float *__restrict__ SV) {
+                                   const float *__restrict__ att, float *__restrict__ SV, int ld) {
     const int W = S_last + 3 * D + 3;
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (int64_t)mb.B * W) return;
-    const int b = (int)(g / W), j = (int)(g % W);
+    if (g >= (int64_t)mb.B * ld) return;
+    const int b = (int)(g / ld), j = (int)(g % ld);
     float v;
     if (j < S_last) v = Ulast[(int64_t)b * S_last + j];
     else if (j < S_last + D) v = hbarV[(int64_t)b * D + j - S_last];
     else if (j < S_last + 2 * D) v = hbarE[(int64_t)b * D + j - S_last - D];
     else if (j < S_last + 3 * D) v = att[(int64_t)b * D + j - S_last - 2 * D];
-    else v = (pk.meta[(int64_t)mb.idx[b] * UPAMD_META_STRIDE + 4] == (j - S_last - 3 * D)) ? 1.f : 0.f;
+    else if (j < W) v = (pk.meta[(int64_t)mb.idx[b] * UPAMD_META_STRIDE + 4] == (j - S_last - 3 * D)) ? 1.f : 0.f;
+    else v = 0.f;                                   // row padding up to ld
     SV[g] = v;
 }
 int launch_assemble_sv(const PackedView &pk, const MbView &mb, int D, int S_last, const float *Ulast,
-                       const float *hbarV, const float *hbarE, const float *att, float *SV, hipStream_t st) {
-    const int64_t tot = (int64_t)mb.B * (S_last + 3 * D + 3);
-    hipLaunchKernelGGL(assemble_sv_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pk, mb, D, S_last, Ulast, hbarV, hbarE, att, SV);
+                       const float *hbarV, const float *hbarE, const float *att, float *SV, int ld, hipStream_t st) {
+    const int64_t tot = (int64_t)mb.B * ld;
+    hipLaunchKernelGGL(assemble_sv_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pk, mb, D, S_last, Ulast, hbarV, hbarE, att, SV, ld);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

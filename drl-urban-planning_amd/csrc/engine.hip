@@ -24,6 +24,7 @@ struct Plan {
 
 struct Dims {
     int D, L, heads, dh, F, Fn, S_last, W;   // W = width of state_value
+    int Wp;                                  // its row stride: W padded to a multiple of 16 so the value head runs on MFMA
     int h0l, h0r;                            // hidden sizes of the two pointer heads
     int maxdim;                              // widest per-sample activation
 };
@@ -33,9 +34,10 @@ Dims dims_of(const upamd_model_desc &d) {
     x.D = d.D; x.L = d.L; x.heads = d.heads; x.dh = d.D / d.heads; x.F = d.node_dim; x.Fn = d.numerical_dim;
     x.S_last = d.num_hidden[d.n_num - 1];
     x.W = 3 * d.D + x.S_last + 3;
+    x.Wp = (x.W + 15) / 16 * 16;
     x.h0l = d.land_hidden[0];
     x.h0r = d.road_hidden[0];
-    x.maxdim = std::max(x.W, std::max(x.Fn, d.D));
+    x.maxdim = std::max(x.Wp, std::max(x.Fn, d.D));
     for (int i = 0; i < d.n_num; ++i) x.maxdim = std::max(x.maxdim, d.num_hidden[i]);
     for (int i = 0; i < d.n_value; ++i) x.maxdim = std::max(x.maxdim, d.value_hidden[i]);
     return x;
@@ -84,7 +86,8 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     add("hbarV", B * D); add("hbarE", B * D);
     add("q0", B * D); add("q1", B * D); add("r", B * x.heads * D); add("alpha", (int64_t)x.heads * M);
     add("s", B * x.heads * D); add("o", B * D); add("att", B * D);
-    add("SV", B * x.W);
+    add("SV", B * x.Wp);
+    add("Vw0p", (int64_t)d.value_hidden[0] * x.Wp);     // first value-head weight, columns zero-padded to Wp
     for (int i = 0; i < d.n_value; ++i) add("V" + std::to_string(i + 1), B * d.value_hidden[i]);
     add("FE", NH * 2 * D); add("hidl", NH * x.h0l); add("z_he", NH); add("p_he", NH);
     add("XR", NR * D); add("hidr", NR * x.h0r); add("z_rn", NR); add("p_rn", NR);
@@ -179,18 +182,21 @@ struct Lin {
         return launch_smm(R, N, K, X, ldx, 1, Wm, N, 1, nullptr, Y, ldy, 0, 0, 1.f, st);
     }
     // dW[N,K] += dY[R,N]^T X[R,K];  db[N] += colsum(dY)
-    int tn_acc(const float *dY, int64_t ldy, int R, int N, const float *X, int64_t ldx, int K, float *dW, float *db) const {
+    // (keep < K: X's trailing columns are zero padding, dW is [N, keep])
+    int tn_acc(const float *dY, int64_t ldy, int R, int N, const float *X, int64_t ldx, int K, float *dW, float *db,
+               int keep = -1) const {
+        if (keep < 0) keep = K;
         GemmTN g{dY, N, ldy, X, K, ldx, R, true, slabs};
         if (R >= MIN_ROWS && gemm_tn_mfma_ok(g)) {
             int S = 1;
             CK(launch_gemm_tn_ex(g, &S, st, prof));
-            CK(launch_reduce_slabs(slabs, S, N, K, 0, K, dW, K, st));
+            CK(launch_reduce_slabs(slabs, S, N, K, 0, keep, dW, keep, st));
         } else if (R >= 512) {      // long reduction over rows, small output: split-K, fixed-order reduce
             int S = 1;
             CK(launch_smm_splitk(N, K, R, dY, 1, ldy, X, ldx, 1, slabs, &S, st));
-            CK(launch_reduce_slabs(slabs, S, N, K, 0, K, dW, K, st));
+            CK(launch_reduce_slabs(slabs, S, N, K, 0, keep, dW, keep, st));
         } else {
-            CK(launch_smm(N, K, R, dY, 1, ldy, X, ldx, 1, nullptr, dW, K, 1, 0, 1.f, st));
+            CK(launch_smm(N, keep, R, dY, 1, ldy, X, ldx, 1, nullptr, dW, keep, 1, 0, 1.f, st));
         }
         if (db) CK(launch_colsum_rm(dY, R, N, ldy, db, st));
         return 0;
@@ -296,7 +302,7 @@ extern "C" int upamd_ws_tensor(upamd_engine *eng, const upamd_minibatch *mb, con
     else if (n == "z_he" || n == "p_he" || n == "dz_he") { r = NH; c = 1; }
     else if (n == "z_rn" || n == "p_rn" || n == "dz_rn") { r = NR; c = 1; }
     else if (n == "alpha") { r = x.heads; c = M; }
-    else if (n == "SV") { r = B; c = x.W; }
+    else if (n == "SV") { r = B; c = x.Wp; }      // columns >= W are zero padding
     else if (n == "r" || n == "s" || n == "ds" || n == "dr") { r = B; c = (int64_t)x.heads * x.D; }
     else if (n == "lse" || n == "entk") { r = B; c = 1; }
     else if (n == "U0") { r = B; c = x.Fn; }
@@ -389,14 +395,15 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
                   x.dh, W("o") + h * x.dh, D, 0, 1.f));
     CK(lin.nt(W("o"), D, B, D, PR(P.outproj_w), D, PR(P.outproj_b), D, W("att"), D, 0, 1.f));
     // value head (value.py:15-39)
-    CK(launch_assemble_sv(pk, mb, D, x.S_last, W("U" + std::to_string(d.n_num)), W("hbarV"), W("hbarE"), W("att"), W("SV"), st));
+    CK(launch_assemble_sv(pk, mb, D, x.S_last, W("U" + std::to_string(d.n_num)), W("hbarV"), W("hbarE"), W("att"), W("SV"), x.Wp, st));
+    CK(launch_pad_cols(PR(P.value_w[0]), d.value_hidden[0], x.W, x.Wp, W("Vw0p"), st));
     {
         const float *prevp = W("SV");
-        int prev = x.W;
+        int prev = x.Wp;
         for (int i = 0; i < d.n_value; ++i) {
             float *out = (i == d.n_value - 1) ? value_dev : W("V" + std::to_string(i + 1));
-            CK(lin.nt(prevp, prev, B, prev, PR(P.value_w[i]), prev, PR(P.value_b[i]), d.value_hidden[i], out, d.value_hidden[i],
-                      i < d.n_value - 1, 1.f));
+            CK(lin.nt(prevp, prev, B, prev, i == 0 ? W("Vw0p") : PR(P.value_w[i]), prev, PR(P.value_b[i]), d.value_hidden[i], out,
+                      d.value_hidden[i], i < d.n_value - 1, 1.f));
             prevp = out;
             prev = d.value_hidden[i];
         }
@@ -457,26 +464,27 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         int64_t ldz = 1;
         for (int i = d.n_value - 1; i >= 0; --i) {
             const int N = d.value_hidden[i];
-            const int K = (i == 0) ? x.W : d.value_hidden[i - 1];
+            const int K = (i == 0) ? x.Wp : d.value_hidden[i - 1];
             const float *Xin = (i == 0) ? W("SV") : W("V" + std::to_string(i));
             if (i < d.n_value - 1) CK(launch_tanh_bwd(const_cast<float *>(dz), W("V" + std::to_string(i + 1)), (int64_t)B * N, st));
-            CK(lin.tn_acc(dz, ldz, B, N, Xin, K, K, GR(P.value_w[i]), GR(P.value_b[i])));
+            // first layer: SV rows are Wp wide (zero padded); only the W real columns of the gradient are kept
+            CK(lin.tn_acc(dz, ldz, B, N, Xin, K, K, GR(P.value_w[i]), GR(P.value_b[i]), i == 0 ? x.W : K));
             float *dnext = (dz == dzA) ? dzB : dzA;
-            CK(lin.nn(dz, ldz, B, N, PR(P.value_w[i]), K, dnext, K));
+            CK(lin.nn(dz, ldz, B, N, i == 0 ? W("Vw0p") : PR(P.value_w[i]), K, dnext, K));
             dz = dnext;
             ldz = K;
         }
-        if (dz != dzA) UPAMD_HIP(hipMemcpyAsync(dzA, dz, sizeof(float) * (size_t)B * x.W, hipMemcpyDeviceToDevice, st));
+        if (dz != dzA) UPAMD_HIP(hipMemcpyAsync(dzA, dz, sizeof(float) * (size_t)B * x.Wp, hipMemcpyDeviceToDevice, st));
     }
-    const float *dSV = dzA;                          // [B, W]
-    const float *dhbarV = dSV + x.S_last;            // column slices, ld = W
+    const float *dSV = dzA;                          // [B, W] with row stride Wp
+    const float *dhbarV = dSV + x.S_last;            // column slices, ld = Wp
     const float *dhbarE = dSV + x.S_last + D;
 
     // ---- numerical encoder backward
     {
         float *bufA = W("dnA"), *bufB = W("dnB");
         // compact the dUlast column slice of dSV into a dense [B, S_last] buffer
-        UPAMD_HIP(hipMemcpy2DAsync(bufA, sizeof(float) * x.S_last, dSV, sizeof(float) * x.W, sizeof(float) * x.S_last, B,
+        UPAMD_HIP(hipMemcpy2DAsync(bufA, sizeof(float) * x.S_last, dSV, sizeof(float) * x.Wp, sizeof(float) * x.S_last, B,
                                    hipMemcpyDeviceToDevice, st));
         float *dz = bufA;
         for (int i = d.n_num - 1; i >= 0; --i) {
@@ -493,7 +501,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     }
 
     // ---- attention, dense part (datt compacted so the MFMA path sees aligned rows)
-    UPAMD_HIP(hipMemcpy2DAsync(W("datt"), sizeof(float) * D, dSV + x.S_last + 2 * D, sizeof(float) * x.W, sizeof(float) * D, B,
+    UPAMD_HIP(hipMemcpy2DAsync(W("datt"), sizeof(float) * D, dSV + x.S_last + 2 * D, sizeof(float) * x.Wp, sizeof(float) * D, B,
                                hipMemcpyDeviceToDevice, st));
     const float *datt = W("datt");
     CK(lin.tn_acc(datt, D, B, D, W("o"), D, D, GR(P.outproj_w), GR(P.outproj_b)));
@@ -512,7 +520,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     }
     // ---- attention core: writes G^L (mean + attention terms) and dr
     float *G = W("G0"), *Gn = W("G1");
-    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("ds"), dhbarV, x.W, G, W("dr"), st));
+    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("ds"), dhbarV, x.Wp, G, W("dr"), st));
     for (int h = 0; h < x.heads; ++h) {
         // dq1[:,h-slice] = dr[:,h,:] Wkk[h-slice,:]^T
         CK(lin.nt(W("dr") + (int64_t)h * D, (int64_t)x.heads * D, B, D, W("Wkk") + (int64_t)h * x.dh * D, D, nullptr, x.dh,
@@ -575,7 +583,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     for (int l = x.L; l >= 1; --l) {
         const std::string sl = std::to_string(l), sp = std::to_string(l - 1);
         const bool last = (l == x.L);
-        CK(launch_edge_bwd(pk, mb, D, last, W("PQ" + sl), PR(P.edge_b[l - 1]), G, dhbarE, x.W,
+        CK(launch_edge_bwd(pk, mb, D, last, W("PQ" + sl), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp,
                            (last && mb.Nhe > 0) ? W("dMhe") : nullptr, W("dPQ"), W("dbias_part"), st, prof));
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
         UPAMD_HIP(hipMemsetAsync(W("cs1"), 0, sizeof(float) * (size_t)2 * D, st));

@@ -130,7 +130,7 @@ int launch_rowdot_bwd_pm(const float *X, int64_t rows, int cols, const float *w,
 // dz[i] *= 1 - y[i]^2 (row-major, same shape)
 int launch_tanh_bwd(float *dz, const float *y, int64_t n, hipStream_t st);
 int launch_assemble_sv(const PackedView &pk, const MbView &mb, int D, int S_last, const float *Ulast,
-                       const float *hbarV, const float *hbarE, const float *att, float *SV, hipStream_t st);
+                       const float *hbarV, const float *hbarE, const float *att, float *SV, int ld, hipStream_t st);
 int launch_prep_wcat(const float *W, int D, float *Wcat, float *WcatT, hipStream_t st);
 int launch_pad_cols(const float *W, int rows, int cols, int cols_pad, float *out, hipStream_t st);
 int launch_transpose(const float *W, int rows, int cols, float *out, hipStream_t st);
