@@ -27,7 +27,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 // ------------------------------------------------------------------------------------------ NT
-template <int BN, int WM, int WN, bool A_RM, bool C_RM, int PK>
+template <int BN, int WM, int WN, bool A_RM, bool C_RM, int PK, int KC = 0>      // KC != 0: K known at compile time
 __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K, int64_t lda,
                                                            const float *__restrict__ W, int N, int64_t ldw,
                                                            const float *__restrict__ bias,
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KS = (K >> 4) / PK;      // pipeline stages
+    const int KS = KC ? (KC >> 4) / PK : (K >> 4) / PK;      // pipeline stages
     float4 ra[PK][2], rb[PK][NB];
     auto load_tiles = [&](int ks) {
 #pragma unroll
@@ -218,10 +218,14 @@ bool gemm_nt_mfma_ok(const GemmNT &g) {
 }
 
 template <bool A_RM, bool C_RM, int PK>
-static void launch_nt_layout(const GemmNT &g, hipStream_t st) {
+static void launch_nt_layout(const GemmNT &g, hipStream_t st, bool k32 = false) {
     const int MT = (int)((g.M + 127) / 128);
     const int MT8 = (MT + 7) / 8 * 8;
-    if (g.N % 128 == 0) {
+    if (k32) {
+        const int NT = g.N / 128;
+        hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM, PK, 32>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K,
+                           g.lda, g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
+    } else if (g.N % 128 == 0) {
         const int NT = g.N / 128;
         hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM, PK>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
                            g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
@@ -244,7 +248,11 @@ int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
     const double flops = 2.0 * (double)g.M * g.K * g.N;
     const double bytes = 4.0 * ((double)g.M * g.K + (double)g.M * g.N * (g.R ? 2 : 1) + (double)g.N * g.K);
     const bool rm = g.a_rm || g.c_rm;
+    // K = 32 (the raw-feature GEMMs): its own instantiation with the two-panel K loop unrolled at compile time; it is
+    // bound by writing C (HBM), not by the MFMA pipe, and is accounted separately from the K >= 64 launches
+    const bool k32 = mfma && !rm && g.K == 32 && g.N % 128 == 0;
     const char *pname = !mfma ? "gemm_nt_generic"
+                        : k32 ? "gemm_nt_128_k32"
                               : (g.N % 128 == 0 ? (rm ? "gemm_nt_128_rm" : "gemm_nt_128")
                                                 : (g.N % 64 == 0 ? (rm ? "gemm_nt_64_rm" : "gemm_nt_64") : (rm ? "gemm_nt_32_rm" : "gemm_nt_32")));
     int began = prof_begin(prof, pname, st, flops, bytes);
@@ -253,6 +261,7 @@ int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
         if (g.a_rm && g.c_rm) launch_nt_layout<true, true, 1>(g, st);
         else if (g.a_rm) launch_nt_layout<true, false, 1>(g, st);
         else if (g.c_rm) launch_nt_layout<false, true, 1>(g, st);
+        else if (k32) launch_nt_layout<false, false, 1>(g, st, true);
         else launch_nt_layout<false, false, 1>(g, st);
     } else {
         const int64_t total = g.M * g.N;
