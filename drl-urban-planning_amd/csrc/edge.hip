@@ -115,24 +115,32 @@ __device__ __forceinline__ void stage_pq(float2 *PQl, const float *Pg, const flo
 // re-stages in linear form and walks with the exponentials inside the loop (same math, any magnitude).
 constexpr float EF_LIMIT = 56.f, EF_BIAS_LIMIT = 6.f;
 
+// writes the exp form of P/Q floats [4i, 4i+4) of the slice; returns the largest |C2 P|, |C2 Q| seen
+__device__ __forceinline__ float put_pq_exp(float2 *PQl, int i, const float4 &pp, const float4 &qq) {
+    const float ax = C2 * pp.x, ay = C2 * pp.y, az = C2 * pp.z, aw = C2 * pp.w;
+    const float bx = C2 * qq.x, by = C2 * qq.y, bz = C2 * qq.z, bw = C2 * qq.w;
+    float4 *d = reinterpret_cast<float4 *>(PQl + i * 4);
+    d[0] = make_float4(__builtin_amdgcn_exp2f(ax), __builtin_amdgcn_exp2f(bx), __builtin_amdgcn_exp2f(ay),
+                       __builtin_amdgcn_exp2f(by));
+    d[1] = make_float4(__builtin_amdgcn_exp2f(az), __builtin_amdgcn_exp2f(bz), __builtin_amdgcn_exp2f(aw),
+                       __builtin_amdgcn_exp2f(bw));
+    return fmaxf(fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fmaxf(fabsf(az), fabsf(aw))),
+                 fmaxf(fmaxf(fabsf(bx), fabsf(by)), fmaxf(fabsf(bz), fabsf(bw))));
+}
+
 __device__ __forceinline__ bool stage_pq_exp(float2 *PQl, const float *Pg, const float *Qg, int n) {
     const float4 *p4 = reinterpret_cast<const float4 *>(Pg);
     const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
     float mx = 0.f;
-    for (int i = threadIdx.x; i < n * 4; i += EDGE_THREADS) {
-        const float4 pp = p4[i], qq = q4[i];
-        const float ax = C2 * pp.x, ay = C2 * pp.y, az = C2 * pp.z, aw = C2 * pp.w;
-        const float bx = C2 * qq.x, by = C2 * qq.y, bz = C2 * qq.z, bw = C2 * qq.w;
-        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fmaxf(fabsf(az), fabsf(aw))),
-                             fmaxf(fmaxf(fabsf(bx), fabsf(by)), fmaxf(fabsf(bz), fabsf(bw)))));
-        float4 *d = reinterpret_cast<float4 *>(PQl + i * 4);
-        d[0] = make_float4(__builtin_amdgcn_exp2f(ax), __builtin_amdgcn_exp2f(bx), __builtin_amdgcn_exp2f(ay),
-                           __builtin_amdgcn_exp2f(by));
-        d[1] = make_float4(__builtin_amdgcn_exp2f(az), __builtin_amdgcn_exp2f(bz), __builtin_amdgcn_exp2f(aw),
-                           __builtin_amdgcn_exp2f(bw));
-    }
+    for (int i = threadIdx.x; i < n * 4; i += EDGE_THREADS) mx = fmaxf(mx, put_pq_exp(PQl, i, p4[i], q4[i]));
     return mx <= EF_LIMIT;
 }
+
+// Stage-in with ONE memory round trip: the workgroup-lifetime profile (s_memtime) showed the stage-in taking longer
+// than the walk itself (15.5 k vs 12.9 k cycles), because the staging loops were seven dependent global round
+// trips (P/Q twice, H twice, row pointers, neighbour ids, order/mask).  When the slice fits two trips per thread
+// (n <= 512 nodes, e <= 2048 edges) every load is issued into registers first and only then committed to LDS.
+__device__ __forceinline__ bool fits_batched(int n, int e) { return n * 4 <= 2 * EDGE_THREADS && e <= 2 * EDGE_THREADS; }
 
 __device__ __forceinline__ float rcp1p_mul(float a, float b) {      // 1 / (1 + a*b)
     return __builtin_amdgcn_rcpf(fmaf(a, b, 1.0f));
@@ -156,10 +164,9 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
                                                                 int aux_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
-    const int t = mb.idx[b];
-    const int32_t *m = META(t);
+    const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;      // one scalar load: meta row + minibatch offsets
     const int n = m[0], e = m[1];
-    const int64_t o = mb.node_off[b], M = mb.M;
+    const int64_t o = m[14], M = mb.M;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ca = 2 * (lane & 7), g = lane >> 3;      // this lane's two columns (ca, ca+1); node slot within the wave
     const EdgeLds L = carve(smem, n, e, STAGE, false);
@@ -170,20 +177,60 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
     float *Ho = Hout + ((int64_t)p * M + o) * 16;
     const float2 bc = make_float2(C2 * bias[p * 16 + ca], C2 * bias[p * 16 + ca + 1]);
     bool ok = false;
-    if (STAGE) {
-        ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
-        const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
-        for (int i = tid; i < n * 4; i += EDGE_THREADS) reinterpret_cast<float4 *>(L.X)[i] = h4[i];
-    }
     const int32_t *rpg = pk.rowptr + m[13];
-    for (int i = tid; i <= n; i += EDGE_THREADS) L.rp[i] = rpg[i];
     const uint32_t *nbg = reinterpret_cast<const uint32_t *>(pk.inc_nbr + 2 * (int64_t)m[10]);
-    for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
     const uint16_t *og = pk.order + m[9];
     const uint8_t *nmg = pk.nmask + m[9];
-    for (int i = tid; i < n; i += EDGE_THREADS) {
-        L.ord[i] = og[i];
-        L.nm[i] = nmg[i];
+    if (STAGE && fits_batched(n, e)) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(Pg), *q4 = reinterpret_cast<const float4 *>(Qg);
+        const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
+        float4 rP[2], rQ[2], rH[2];
+        uint32_t rNb[2] = {0u, 0u};
+        int rRp = 0;
+        uint32_t rOrd = 0, rNm = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = tid + r * EDGE_THREADS;
+            if (i < n * 4) {
+                rP[r] = p4[i];
+                rQ[r] = q4[i];
+                rH[r] = h4[i];
+            }
+            if (i < e) rNb[r] = nbg[i];
+        }
+        if (tid <= n) rRp = rpg[tid];
+        if (tid < n) {
+            rOrd = og[tid];
+            rNm = nmg[tid];
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = tid + r * EDGE_THREADS;
+            if (i < n * 4) {
+                mx = fmaxf(mx, put_pq_exp(L.PQ, i, rP[r], rQ[r]));
+                reinterpret_cast<float4 *>(L.X)[i] = rH[r];
+            }
+            if (i < e) reinterpret_cast<uint32_t *>(L.nb)[i] = rNb[r];
+        }
+        if (tid <= n) L.rp[tid] = rRp;
+        if (tid < n) {
+            L.ord[tid] = (uint16_t)rOrd;
+            L.nm[tid] = (uint8_t)rNm;
+        }
+        ok = mx <= EF_LIMIT && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+    } else {
+        if (STAGE) {
+            ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+            const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
+            for (int i = tid; i < n * 4; i += EDGE_THREADS) reinterpret_cast<float4 *>(L.X)[i] = h4[i];
+        }
+        for (int i = tid; i <= n; i += EDGE_THREADS) L.rp[i] = rpg[i];
+        for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
+        for (int i = tid; i < n; i += EDGE_THREADS) {
+            L.ord[i] = og[i];
+            L.nm[i] = nmg[i];
+        }
     }
     // last layer: the row's candidate edges (endpoints, live flag) next to the slice, so the pointer-head pass
     // below does not chase them through global memory
@@ -270,7 +317,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
         }
         if (LAST && FE && nh > 0) {
             // pointer-head inputs of this row's candidate edges (8 candidates per wave pass)
-            const int64_t NH = mb.Nhe, q0 = mb.he_off[b];
+            const int64_t NH = mb.Nhe, q0 = m[15];
             const float2 cc = *reinterpret_cast<const float2 *>(Ccur + (int64_t)b * (NP * 16) + p * 16 + ca);
             for (int q = 8 * w + g; q < nh; q += 8 * EDGE_WAVES) {
                 float2 mm = make_float2(0.f, 0.f);
@@ -370,10 +417,9 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
                                                                 float *__restrict__ dbias_part, int aux_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
-    const int t = mb.idx[b];
-    const int32_t *m = META(t);
+    const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;      // one scalar load: meta row + minibatch offsets
     const int n = m[0], e = m[1];
-    const int64_t o = mb.node_off[b], M = mb.M;
+    const int64_t o = m[14], M = mb.M;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ca = 2 * (lane & 7), g = lane >> 3;      // this lane's two columns (ca, ca+1); node slot within the wave
     const EdgeLds L = carve(smem, n, e, STAGE, true);
@@ -382,11 +428,59 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
     const float *Qg = PQ + ((int64_t)(2 * p + 1) * M + o) * 16;
     const float *Gg = G + ((int64_t)p * M + o) * 16;
     const int32_t *rpg = pk.rowptr + m[13];
-    for (int i = tid; i <= n; i += EDGE_THREADS) L.rp[i] = rpg[i];
     const uint32_t *nbg = reinterpret_cast<const uint32_t *>(pk.inc_nbr + 2 * (int64_t)m[10]);
-    for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
     const uint16_t *og = pk.order + m[9];
-    for (int i = tid; i < n; i += EDGE_THREADS) L.ord[i] = og[i];
+    const float2 bc = make_float2(C2 * bias[p * 16 + ca], C2 * bias[p * 16 + ca + 1]);
+    const bool batched = STAGE && fits_batched(n, e);
+    bool ok = false;
+    if (batched) {
+        // one memory round trip (see fits_batched): P/Q, G, the degrees of the G rows, the lists -- then commit
+        const float4 *p4 = reinterpret_cast<const float4 *>(Pg), *q4 = reinterpret_cast<const float4 *>(Qg);
+        const float4 *g4 = reinterpret_cast<const float4 *>(Gg);
+        float4 rP[2], rQ[2], rG[2];
+        int rD0[2] = {0, 0}, rD1[2] = {1, 1};
+        uint32_t rNb[2] = {0u, 0u};
+        int rRp = 0;
+        uint32_t rOrd = 0;
+        float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);       // the thread's four columns are the same on both trips
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = tid + r * EDGE_THREADS;
+            if (i < n * 4) {
+                rP[r] = p4[i];
+                rQ[r] = q4[i];
+                rG[r] = g4[i];
+                rD0[r] = rpg[i >> 2];
+                rD1[r] = rpg[(i >> 2) + 1];
+            }
+            if (i < e) rNb[r] = nbg[i];
+        }
+        if (tid <= n) rRp = rpg[tid];
+        if (tid < n) rOrd = og[tid];
+        if (LAST) {
+            const float4 dh = *reinterpret_cast<const float4 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + (tid & 3) * 4);
+            ex4 = make_float4(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e, 0.5f * dh.z / (float)e, 0.5f * dh.w / (float)e);
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = tid + r * EDGE_THREADS;
+            if (i < n * 4) {
+                mx = fmaxf(mx, put_pq_exp(L.PQ, i, rP[r], rQ[r]));
+                const float inv = __builtin_amdgcn_rcpf((float)(rD1[r] - rD0[r]) + 1e-6f);
+                reinterpret_cast<float4 *>(L.X)[i] = make_float4(fmaf(rG[r].x, inv, ex4.x), fmaf(rG[r].y, inv, ex4.y),
+                                                                 fmaf(rG[r].z, inv, ex4.z), fmaf(rG[r].w, inv, ex4.w));
+            }
+            if (i < e) reinterpret_cast<uint32_t *>(L.nb)[i] = rNb[r];
+        }
+        if (tid <= n) L.rp[tid] = rRp;
+        if (tid < n) L.ord[tid] = (uint16_t)rOrd;
+        ok = mx <= EF_LIMIT && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+    } else {
+        for (int i = tid; i <= n; i += EDGE_THREADS) L.rp[i] = rpg[i];
+        for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
+        for (int i = tid; i < n; i += EDGE_THREADS) L.ord[i] = og[i];
+    }
     // last layer: the per-node candidate-incidence pointers (aux_cap >= 0) and, when they fit, the lists themselves
     // are staged too -- otherwise every node pass would pay a global round trip just to learn it has no candidate
     const bool heads_on = LAST && dMhe != nullptr && m[2] > 0;
@@ -405,10 +499,9 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
             reinterpret_cast<uint32_t *>(a_hhe)[i] = reinterpret_cast<const uint32_t *>(hhe)[i];
         }
     }
-    const float2 bc = make_float2(C2 * bias[p * 16 + ca], C2 * bias[p * 16 + ca + 1]);
     bool ef = false;                       // LDS holds the exp form (workgroup-uniform), see stage_pq_exp
     if (STAGE) {
-        const bool ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+        if (!batched) ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
         ef = !__syncthreads_or(ok ? 0 : 1);
         if (!ef) {
             stage_pq(L.PQ, Pg, Qg, n);
@@ -422,7 +515,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
         const float2 dh = *reinterpret_cast<const float2 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + ca);
         extra = make_float2(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e);
     }
-    if (STAGE) {
+    if (STAGE && !batched) {
         float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);       // the thread's four columns are the same on every trip
         if (LAST) {
             const float4 dh = *reinterpret_cast<const float4 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + (tid & 3) * 4);
@@ -450,7 +543,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
         const float inv = __builtin_amdgcn_rcpf((float)(L.rp[u + 1] - L.rp[u]) + 1e-6f);
         return make_float2(fmaf(gg.x, inv, extra.x), fmaf(gg.y, inv, extra.y));
     };
-    const float *dMg = heads_on ? dMhe + ((int64_t)p * mb.Nhe + mb.he_off[b]) * 16 + ca : nullptr;
+    const float *dMg = heads_on ? dMhe + ((int64_t)p * mb.Nhe + m[15]) * 16 + ca : nullptr;
     float2 sumdP = make_float2(0.f, 0.f), sumdQ = make_float2(0.f, 0.f);
     auto walk = [&](auto efc) {
         constexpr bool EF = decltype(efc)::value;

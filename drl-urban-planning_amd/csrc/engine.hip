@@ -65,6 +65,7 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
         pl->len[name] = n;
         off = align_up(off + std::max<int64_t>(n, 1), 64);
     };
+    add("rows", B * UPAMD_META_STRIDE);     // int32 row descriptors (MbView::rows)
     add("We_pad", (int64_t)D * 32);
     for (int l = 0; l < x.L; ++l) {
         add("Wcat" + std::to_string(l), 2LL * D * D);
@@ -133,6 +134,7 @@ MbView make_mb(const upamd_minibatch &mb) {
     MbView v;
     v.B = mb.B; v.M = mb.n_nodes; v.Nhe = mb.n_he; v.Nrn = mb.n_rn; v.max_n = mb.max_n; v.max_inc = mb.max_inc;
     v.idx = mb.idx_dev; v.node_off = mb.node_off_dev; v.he_off = mb.he_off_dev; v.rn_off = mb.rn_off_dev;
+    v.rows = nullptr;
     return v;
 }
 
@@ -333,12 +335,15 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     const Dims x = dims_of(d);
     const int D = x.D, B = mbp->B;
     const PackedView pk = make_view(packed_dev, *layout);
-    const MbView mb = make_mb(*mbp);
+    MbView mb = make_mb(*mbp);
     float *ws = static_cast<float *>(ws_dev);
     auto W = [&](const std::string &n) { return ws + pl.off.at(n); };
     auto PR = [&](int idx) { return prm + P.off(idx); };
     Profiler *prof = &eng->prof;
     const Lin lin{st, prof, W("slabs"), W("wt")};
+    // row descriptors first: every per-graph kernel below (and the backward) reads them
+    CK(launch_gather_rows(pk, mb, reinterpret_cast<int32_t *>(W("rows")), st));
+    mb.rows = reinterpret_cast<const int32_t *>(W("rows"));
 
     // -- per-step weight preparation (tiny)
     CK(launch_pad_cols(PR(P.node_w), D, x.F, 32, W("We_pad"), st));
@@ -445,9 +450,10 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     const Dims x = dims_of(d);
     const int D = x.D, B = mbp->B;
     const PackedView pk = make_view(packed_dev, *layout);
-    const MbView mb = make_mb(*mbp);
+    MbView mb = make_mb(*mbp);
     float *ws = static_cast<float *>(ws_dev);
     auto W = [&](const std::string &n) { return ws + pl.off.at(n); };
+    mb.rows = reinterpret_cast<const int32_t *>(W("rows"));     // written by the forward of this minibatch
     auto PR = [&](int idx) { return prm + P.off(idx); };
     auto GR = [&](int idx) { return grads + P.off(idx); };
     Profiler *prof = &eng->prof;

@@ -37,6 +37,24 @@ __global__ __launch_bounds__(256) void gather_inputs_kernel(PackedView pk, MbVie
     if (threadIdx.x < UPAMD_NODE_PAD) curg[(int64_t)b * UPAMD_NODE_PAD + threadIdx.x] = pk.cur[(int64_t)t * UPAMD_NODE_PAD + threadIdx.x];
 }
 
+// row descriptors of the minibatch (MbView::rows)
+__global__ void gather_rows_kernel(PackedView pk, MbView mb, int32_t *__restrict__ rows) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= mb.B * UPAMD_META_STRIDE) return;
+    const int b = g / UPAMD_META_STRIDE, c = g % UPAMD_META_STRIDE;
+    int32_t v;
+    if (c == 14) v = mb.node_off[b];
+    else if (c == 15) v = mb.he_off[b];
+    else v = pk.meta[(int64_t)mb.idx[b] * UPAMD_META_STRIDE + c];
+    rows[g] = v;
+}
+int launch_gather_rows(const PackedView &pk, const MbView &mb, int32_t *rows, hipStream_t st) {
+    const int tot = mb.B * UPAMD_META_STRIDE;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, pk, mb, rows);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st) {
     hipLaunchKernelGGL(gather_inputs_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, Xp, U0, curg);
     UPAMD_HIP(hipGetLastError());

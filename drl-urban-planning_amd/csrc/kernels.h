@@ -34,6 +34,9 @@ struct MbView {       // one minibatch (device schedule arrays)
     int64_t M, Nhe, Nrn;
     int max_n, max_inc;
     const int32_t *idx, *node_off, *he_off, *rn_off;
+    // [B][16] row descriptors gathered once per forward: columns 0..13 = the state's meta row, 14 = node_off[b],
+    // 15 = he_off[b].  One scalar load per workgroup instead of the idx -> meta -> offsets chain.
+    const int32_t *rows;
 };
 
 struct KernelStat {
@@ -84,6 +87,7 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
 // ---- graph.hip -------------------------------------------------------------------------
 int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st);
 int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage);
+int launch_gather_rows(const PackedView &pk, const MbView &mb, int32_t *rows, hipStream_t st);
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
                     hipStream_t st, Profiler *prof);
