@@ -200,6 +200,8 @@ def main():
             if st['launches']:
                 kern[name] = st
     up.detach()
+    ctx.barrier()
+    ctx.close()
 
     if rank != 0:
         return

@@ -216,8 +216,7 @@ class PPOUpdater:
             for j in range(S):
                 main.wait_stream(self._streams[j])
             torch.add(self._sub_grads[0], self._sub_grads[1], out=self.grads)
-        if self.dist.world > 1:
-            self.dist.all_reduce_sum(self.grads)          # ONE collective per optimizer step
+        self.dist.all_reduce_sum(self.grads)              # ONE collective per optimizer step (no-op for one rank)
         if loss_out is not None:
             loss_out.copy_(self.grads[nflt:])
         if self.clip_pending:

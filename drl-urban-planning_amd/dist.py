@@ -16,14 +16,18 @@ import torch.distributed as dist
 class DistContext:
     """rank / world + the collectives the update needs.  world == 1 -> every call is a no-op."""
 
-    def __init__(self, rank=0, world=1, group=None):
+    def __init__(self, rank=0, world=1, group=None, active=None):
         self.rank, self.world, self.group = rank, world, group
+        # collectives are issued when world > 1; UPAMD_DIST_FORCE_INIT=1 also issues them for a single rank (lets the
+        # RCCL code path be exercised on a one-GPU box)
+        self.active = (world > 1) if active is None else active
 
     @classmethod
     def from_env(cls, backend=None, device=None):
         """Initialise from torchrun's environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
         world = int(os.environ.get('WORLD_SIZE', '1'))
-        if world == 1:
+        forced = world == 1 and os.environ.get('UPAMD_DIST_FORCE_INIT') == '1' and 'RANK' in os.environ
+        if world == 1 and not forced:
             return cls(0, 1)
         rank = int(os.environ['RANK'])
         if not dist.is_initialized():
@@ -34,24 +38,30 @@ class DistContext:
             if device is not None and backend == 'nccl':
                 kwargs['device_id'] = device
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
-        return cls(rank, world)
+        return cls(rank, world, active=True)
+
+    def close(self):
+        """Tear the process group down (end of the program)."""
+        if self.active and dist.is_initialized():
+            dist.destroy_process_group()
+        self.active = False
 
     def all_reduce_sum(self, tensor):
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
     def all_reduce_max(self, tensor):
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=self.group)
         return tensor
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             dist.barrier(group=self.group)
 
     def broadcast(self, tensor, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(tensor, src=src, group=self.group)
         return tensor
 
@@ -68,7 +78,7 @@ def shard_rows(rows, rank, world):
 def global_counts(ctx, lists, device):
     """Element-wise sum over ranks of several equal-length integer lists (per-minibatch row counts);
     one tiny all-reduce per epoch, not per step."""
-    if ctx.world == 1:
+    if not ctx.active:
         return [list(x) for x in lists]
     t = torch.tensor([list(x) for x in lists], dtype=torch.float64, device=device)
     ctx.all_reduce_sum(t)
