@@ -606,7 +606,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             UPAMD_HIP(hipMemsetAsync(W("Tn"), 0, sizeof(float) * (size_t)2 * D * 32, st));
             CK(launch_gemm_tn(W("dPQ"), 2 * D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
             CK(launch_reduce_slabs(W("slabs"), S, 2 * D, 32, 0, 32, W("Tn"), 32, st));
-            CK(launch_smm(2 * D, D, 32, W("Tn"), 32, 1, W("We_pad"), 1, 32, nullptr, W("dWc1"), D, 0, 0, 1.f, st));
+            CK(lin.nt(W("Tn"), 32, 2 * D, 32, W("We_pad"), 32, nullptr, D, W("dWc1"), D, 0, 1.f));       // Tn We^T
             CK(launch_smm(2 * D, D, 1, W("cs1"), 1, 1, PR(P.node_b), 1, 1, nullptr, W("dWc1"), D, 1, 0, 1.f, st));
             CK(launch_reduce_slabs(W("dWc1"), 1, 2 * D, D, 2, D, GR(P.edge_w[0]), 2 * D, st));
         }

@@ -500,13 +500,26 @@ int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, flo
     return launch_gemm_tn_ex(g, S_out, st, prof);
 }
 
-__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int S, int I, int J, int mode, int jkeep,
-                                    float *__restrict__ dst, int ldd, float *__restrict__ last_col_dst) {
-    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ij >= I * J) return;
-    const int i = ij / J, j = ij % J;
+// dst (+)= sum_s slabs[s][i][j] in a FIXED order: 16 slab groups (s = g, g+16, ...) are summed by 16 threads per
+// output element, then combined g = 0..15 -- deterministic, and 16x more parallel than one thread per element
+// (the small-output reductions have up to 384 slabs for only 8192 elements).
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restrict__ slabs, int S, int I, int J, int mode,
+                                                            int jkeep, float *__restrict__ dst, int ldd,
+                                                            float *__restrict__ last_col_dst) {
+    __shared__ float part[16][65];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int ij = blockIdx.x * 64 + e;
+    const bool in = ij < I * J;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += slabs[(int64_t)s * I * J + ij];
+    if (in)
+        for (int s = g; s < S; s += 16) acc += slabs[(int64_t)s * I * J + ij];
+    part[g][e] = acc;
+    __syncthreads();
+    if (g != 0 || !in) return;
+    acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += part[q][e];
+    const int i = ij / J, j = ij % J;
     if (mode == 0) {
         if (j < jkeep) dst[(int64_t)i * ldd + j] += acc;
         if (last_col_dst && j == J - 1) last_col_dst[i] += acc;      // the B operand's last column was all ones: a column sum
@@ -522,7 +535,7 @@ __global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int S, int 
 
 int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int jkeep, float *dst, int ldd,
                         hipStream_t st, float *last_col_dst) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, slabs, S, I, J, mode, jkeep, dst, ldd,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((I * J + 63) / 64), dim3(1024), 0, st, slabs, S, I, J, mode, jkeep, dst, ldd,
                        last_col_dst);
     UPAMD_HIP(hipGetLastError());
     return 0;
