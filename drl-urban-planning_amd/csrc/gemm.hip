@@ -217,19 +217,30 @@ bool gemm_nt_mfma_ok(const GemmNT &g) {
     return true;
 }
 
+// N-tile width of a launch.  Small-M problems (the per-sample [B, D] layers: 16 M-tiles) take a narrower tile so that
+// at least ~half the CUs get a workgroup.
+static int nt_tile(const GemmNT &g) {
+    constexpr int64_t MIN_WGS = 128;
+    const int64_t MT = (g.M + 127) / 128;
+    if (g.N % 128 == 0 && MT * (g.N / 128) >= MIN_WGS) return 128;
+    if (g.N % 64 == 0 && (g.N % 128 != 0 || MT * (g.N / 64) >= MIN_WGS)) return 64;
+    return 32;
+}
+
 template <bool A_RM, bool C_RM, int PK>
 static void launch_nt_layout(const GemmNT &g, hipStream_t st, bool k32 = false) {
+    const int BNsel = nt_tile(g);
     const int MT = (int)((g.M + 127) / 128);
     const int MT8 = (MT + 7) / 8 * 8;
     if (k32) {
         const int NT = g.N / 128;
         hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM, PK, 32>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K,
                            g.lda, g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
-    } else if (g.N % 128 == 0) {
+    } else if (BNsel == 128) {
         const int NT = g.N / 128;
         hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM, PK>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
                            g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
-    } else if (g.N % 64 == 0) {
+    } else if (BNsel == 64) {
         const int NT = g.N / 64;
         hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64, 32, A_RM, C_RM, PK>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
                            g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
@@ -250,11 +261,12 @@ int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
     const bool rm = g.a_rm || g.c_rm;
     // K = 32 (the raw-feature GEMMs): its own instantiation with the two-panel K loop unrolled at compile time; it is
     // bound by writing C (HBM), not by the MFMA pipe, and is accounted separately from the K >= 64 launches
-    const bool k32 = mfma && !rm && g.K == 32 && g.N % 128 == 0;
+    const int bn = mfma ? nt_tile(g) : 0;
+    const bool k32 = mfma && !rm && g.K == 32 && bn == 128;
     const char *pname = !mfma ? "gemm_nt_generic"
                         : k32 ? "gemm_nt_128_k32"
-                              : (g.N % 128 == 0 ? (rm ? "gemm_nt_128_rm" : "gemm_nt_128")
-                                                : (g.N % 64 == 0 ? (rm ? "gemm_nt_64_rm" : "gemm_nt_64") : (rm ? "gemm_nt_32_rm" : "gemm_nt_32")));
+                              : (bn == 128 ? (rm ? "gemm_nt_128_rm" : "gemm_nt_128")
+                                           : (bn == 64 ? (rm ? "gemm_nt_64_rm" : "gemm_nt_64") : (rm ? "gemm_nt_32_rm" : "gemm_nt_32")));
     int began = prof_begin(prof, pname, st, flops, bytes);
     if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
     if (mfma) {
