@@ -526,7 +526,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     }
     // ---- attention core: writes G^L (mean + attention terms) and dr
     float *G = W("G0"), *Gn = W("G1");
-    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("ds"), dhbarV, x.Wp, G, W("dr"), st));
+    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("s"), W("ds"), dhbarV, x.Wp, G, W("dr"), st));
     for (int h = 0; h < x.heads; ++h) {
         // dq1[:,h-slice] = dr[:,h,:] Wkk[h-slice,:]^T
         CK(lin.nt(W("dr") + (int64_t)h * D, (int64_t)x.heads * D, B, D, W("Wkk") + (int64_t)h * x.dh * D, D, nullptr, x.dh,

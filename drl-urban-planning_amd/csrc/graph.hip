@@ -161,8 +161,214 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(PackedView pk, MbView mb,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Single-pass variants (D = 16 * NP with NP a power of two <= 16; the kernels above stay as the generic path).
+// 16 lanes per node: lane c owns column c of every panel, i.e. NP values of the node's row in registers, so the
+// score (a 16-lane reduction) and the softmax-weighted sum use the row while it is in registers -- H^L is read
+// ONCE (online softmax: every one of the 16 node slots keeps a running max / normaliser / weighted sum, the slots
+// are merged in a fixed order at the end).  The two-pass kernels read it twice from HBM (2048 graphs x 277 KB do
+// not stay in L2).
+// ------------------------------------------------------------------------------------------
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }    // exp(-inf) = 0
+
+__device__ __forceinline__ float reduce16(float v) {      // sum over the 16 lanes of a node slot, result on all of them
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void attn_fwd16_kernel(PackedView pk, MbView mb, int heads, const float *__restrict__ HL,
+                                                         const float *__restrict__ r, float *__restrict__ alpha,
+                                                         float *__restrict__ s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int D = NP * 16;
+    float *sacc = reinterpret_cast<float *>(smem);         // [16 slots][D]
+    float *sm = sacc + 16 * D;                             // [16] running max
+    float *sl = sm + 16;                                   // [16] running normaliser
+    float *sc = sl + 16;                                   // [max_n] raw scores
+    const int b = blockIdx.x;
+    const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;
+    const int n = m[0];
+    const int64_t o = m[14], M = mb.M;
+    const float *Hg = HL + o * 16;
+    const uint8_t *nmask = pk.nmask + m[9];
+    const int c = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    for (int h = 0; h < heads; ++h) {
+        float vec[NP], acc[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            vec[p] = r[((int64_t)b * heads + h) * D + p * 16 + c];
+            acc[p] = 0.f;
+        }
+        float mrun = -INFINITY, lrun = 0.f;
+        for (int j = slot; j < n; j += 16) {
+            if (!nmask[j]) continue;
+            float hv[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) hv[p] = Hg[((int64_t)p * M + j) * 16 + c];
+            float dot = 0.f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dot = fmaf(hv[p], vec[p], dot);
+            dot = reduce16(dot);
+            if (c == 0) sc[j] = dot;
+            const float mnew = fmaxf(mrun, dot);
+            const float keep = fast_exp(mrun - mnew), w = fast_exp(dot - mnew);
+            lrun = fmaf(lrun, keep, w);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[p] = fmaf(acc[p], keep, w * hv[p]);
+            mrun = mnew;
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) sacc[slot * D + p * 16 + c] = acc[p];
+        if (c == 0) {
+            sm[slot] = mrun;
+            sl[slot] = lrun;
+        }
+        __syncthreads();
+        float mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mx = fmaxf(mx, sm[q]);
+        float L = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) L = fmaf(sl[q], fast_exp(sm[q] - mx), L);
+        const float invL = 1.f / L;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot = fmaf(sacc[q * D + d], fast_exp(sm[q] - mx), tot);
+            s[((int64_t)b * heads + h) * D + d] = tot * invL;
+        }
+        for (int j = threadIdx.x; j < n; j += 256) alpha[(int64_t)h * M + o + j] = nmask[j] ? fast_exp(sc[j] - mx) * invL : 0.f;
+        __syncthreads();
+    }
+}
+
+// backward, single pass over H^L:  with t_j = ds . h_j and T = sum_k alpha_k t_k,
+//   dscore_j = alpha_j (t_j - T),   dr = sum_j dscore_j h_j = (sum_j alpha_j t_j h_j) - T * s     (s = the forward output)
+// so the weighted sum is accumulated while t_j is computed; GL is then written without touching H^L again.
+template <int NP>
+__global__ __launch_bounds__(256) void attn_bwd16_kernel(PackedView pk, MbView mb, int heads, const float *__restrict__ HL,
+                                                         const float *__restrict__ r, const float *__restrict__ alpha,
+                                                         const float *__restrict__ s, const float *__restrict__ ds,
+                                                         const float *__restrict__ dhbarV, int ld_dhbarV,
+                                                         float *__restrict__ GL, float *__restrict__ dr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int D = NP * 16;
+    float *sacc = reinterpret_cast<float *>(smem);         // [16 slots][D]
+    float *sT = sacc + 16 * D;                             // [16]
+    float *dsl = sT + 16;                                  // [heads][D]
+    float *rl = dsl + heads * D;                           // [heads][D]
+    float *al = rl + heads * D;                            // [heads][max_n] alpha
+    float *dscl = al + heads * mb.max_n;                   // [heads][max_n] t_j, then dscore_j
+    const int b = blockIdx.x;
+    const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;
+    const int n = m[0];
+    const int64_t o = m[14], M = mb.M;
+    const float *Hg = HL + o * 16;
+    const uint8_t *nmask = pk.nmask + m[9];
+    const int c = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    for (int i = threadIdx.x; i < heads * D; i += 256) {
+        dsl[i] = ds[(int64_t)b * heads * D + i];
+        rl[i] = r[(int64_t)b * heads * D + i];
+    }
+    for (int h = 0; h < heads; ++h) {
+        float *a_h = al + h * mb.max_n, *d_h = dscl + h * mb.max_n;
+        float vec[NP], acc[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            vec[p] = ds[((int64_t)b * heads + h) * D + p * 16 + c];
+            acc[p] = 0.f;
+        }
+        float Tpart = 0.f;
+        for (int j = slot; j < n; j += 16) {
+            const float a = alpha[(int64_t)h * M + o + j];
+            float t = 0.f;
+            if (nmask[j]) {
+                float hv[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) hv[p] = Hg[((int64_t)p * M + j) * 16 + c];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) t = fmaf(hv[p], vec[p], t);
+                t = reduce16(t);
+                const float wgt = a * t;
+                Tpart += wgt;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[p] = fmaf(wgt, hv[p], acc[p]);
+            }
+            if (c == 0) {
+                a_h[j] = a;
+                d_h[j] = t;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) sacc[slot * D + p * 16 + c] = acc[p];
+        if (c == 0) sT[slot] = Tpart;
+        __syncthreads();
+        float T = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) T += sT[q];
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += sacc[q * D + d];
+            dr[((int64_t)b * heads + h) * D + d] = tot - T * s[((int64_t)b * heads + h) * D + d];
+        }
+        for (int j = threadIdx.x; j < n; j += 256) d_h[j] = a_h[j] * (d_h[j] - T);
+        __syncthreads();
+    }
+    const float inv_nm = 1.f / (float)m[6];
+    float dhv[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dhv[p] = dhbarV[(int64_t)b * ld_dhbarV + p * 16 + c] * inv_nm;
+    for (int j = slot; j < n; j += 16) {
+        const bool live = nmask[j] != 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int d = p * 16 + c;
+            float v = live ? dhv[p] : 0.f;
+            for (int h = 0; h < heads; ++h)
+                v += al[h * mb.max_n + j] * dsl[h * D + d] + dscl[h * mb.max_n + j] * rl[h * D + d];
+            GL[((int64_t)p * M + o + j) * 16 + c] = v;
+        }
+    }
+}
+
+template <int NP>
+static int launch_attn_fwd16(const PackedView &pk, const MbView &mb, int heads, const float *HL, const float *r, float *alpha,
+                             float *s, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(16 * NP * 16 + 32 + mb.max_n);
+    hipLaunchKernelGGL((attn_fwd16_kernel<NP>), dim3(mb.B), dim3(256), lds, st, pk, mb, heads, HL, r, alpha, s);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+template <int NP>
+static int launch_attn_bwd16(const PackedView &pk, const MbView &mb, int heads, const float *HL, const float *r,
+                             const float *alpha, const float *s, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL,
+                             float *dr, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(16 * NP * 16 + 16 + 2 * heads * NP * 16 + 2 * heads * mb.max_n);
+    if (lds > 64 * 1024) return -1;
+    hipLaunchKernelGGL((attn_bwd16_kernel<NP>), dim3(mb.B), dim3(256), lds, st, pk, mb, heads, HL, r, alpha, s, ds, dhbarV,
+                       ld_dhbarV, GL, dr);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_attn_fwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     float *alpha, float *s, hipStream_t st) {
+    if (mb.rows && (size_t)(16 * D + 32 + mb.max_n) * sizeof(float) <= 64 * 1024) {
+        switch (D / 16) {
+            case 1: return launch_attn_fwd16<1>(pk, mb, heads, HL, r, alpha, s, st);
+            case 2: return launch_attn_fwd16<2>(pk, mb, heads, HL, r, alpha, s, st);
+            case 4: return launch_attn_fwd16<4>(pk, mb, heads, HL, r, alpha, s, st);
+            case 8: return launch_attn_fwd16<8>(pk, mb, heads, HL, r, alpha, s, st);
+            case 16: return launch_attn_fwd16<16>(pk, mb, heads, HL, r, alpha, s, st);
+            default: break;
+        }
+    }
     const size_t lds = sizeof(float) * (size_t)(D + mb.max_n + 256 + 8);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(mb.B), dim3(256), lds, st, pk, mb, D / 16, heads, HL, r, alpha, s);
     UPAMD_HIP(hipGetLastError());
@@ -225,8 +431,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(PackedView pk, MbView mb,
 }
 
 int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
-                    const float *alpha, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL, float *dr,
-                    hipStream_t st) {
+                    const float *alpha, const float *s, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL,
+                    float *dr, hipStream_t st) {
+    if (mb.rows && s) {
+        int rc = -1;
+        switch (D / 16) {
+            case 1: rc = launch_attn_bwd16<1>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
+            case 2: rc = launch_attn_bwd16<2>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
+            case 4: rc = launch_attn_bwd16<4>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
+            case 8: rc = launch_attn_bwd16<8>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
+            case 16: rc = launch_attn_bwd16<16>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
+            default: break;
+        }
+        if (rc >= 0) return rc;      // -1: shape not covered, fall through to the two-pass kernel
+    }
     const size_t lds = sizeof(float) * (size_t)(2 * heads * D + 2 * heads * mb.max_n + 256 + 8);
     if (lds > (size_t)LDS_LIMIT) return fail(UPAMD_E_LIMIT, "attn_bwd: LDS need %zu too large", lds);
     if (lds > 64 * 1024)

@@ -97,7 +97,7 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
 int launch_attn_fwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     float *alpha, float *s, hipStream_t st);
 int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
-                    const float *alpha, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL, float *dr,
+                    const float *alpha, const float *s, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL, float *dr,
                     hipStream_t st);
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
                        const float *dFE, float *dMhe, float *dC_head, hipStream_t st);
