@@ -86,7 +86,7 @@ int launch_smm(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, co
 
 // split-K form: slabs[s][I][J] = partial products over K chunks (sum them with launch_reduce_slabs)
 int smm_splits(int K) {
-    int S = K / 64;
+    int S = K / 16;       // down to one 16-wide K step per workgroup: these products are latency-, not FLOP-bound
     if (S > 32) S = 32;
     if (S < 1) S = 1;
     return S;

@@ -51,6 +51,7 @@ int64_t slab_floats(const Dims &x, int64_t B, int64_t M, int64_t Nhe, int64_t Nr
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.h0r, Nrn) * x.D * x.h0r);            // road head
     s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.D, B) * x.D * x.D);                  // per-sample D x D layers
     s = std::max<int64_t>(s, (int64_t)smm_splits((int)B) * x.maxdim * x.maxdim);            // small per-sample layers (split-K)
+    s = std::max<int64_t>(s, (int64_t)smm_splits(2 * x.D) * x.D * 32);                       // node-encoder products over K = 2D
     return s;
 }
 
@@ -618,8 +619,11 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // Xp's column 31 is all ones (gather_inputs), so column 31 of G^1^T Xp is colsum(G^1): straight into dbe
     CK(launch_reduce_slabs(W("slabs"), S, D, 32, 0, x.F, GR(P.node_w), x.F, st, GR(P.node_b)));
     // "Tn" = dPQ_1^T Xp and "cs1" = colsum(dPQ_1) come from the l = 1 iteration of the loop above
-    CK(launch_smm(D, x.F, 2 * D, W("WcatT0"), 2 * D, 1, W("Tn"), 32, 1, nullptr, GR(P.node_w), x.F, 1, 0, 1.f, st));
-    CK(launch_smm(1, D, 2 * D, W("cs1"), 2 * D, 1, W("WcatT0"), 1, 2 * D, nullptr, GR(P.node_b), D, 1, 0, 1.f, st));
+    // (split-K: 4 workgroups looping over K = 2D would be pure latency)
+    CK(launch_smm_splitk(D, x.F, 2 * D, W("WcatT0"), 2 * D, 1, W("Tn"), 32, 1, W("slabs"), &S, st));
+    CK(launch_reduce_slabs(W("slabs"), S, D, x.F, 0, x.F, GR(P.node_w), x.F, st));
+    CK(launch_smm_splitk(1, D, 2 * D, W("cs1"), 2 * D, 1, W("WcatT0"), 1, 2 * D, W("slabs"), &S, st));
+    CK(launch_reduce_slabs(W("slabs"), S, 1, D, 0, D, GR(P.node_b), D, st));
     CK(lin.tn_acc(W("dC"), D, B, D, W("curg"), UPAMD_NODE_PAD, x.F, GR(P.node_w), GR(P.node_b)));
     return UPAMD_OK;
 }
