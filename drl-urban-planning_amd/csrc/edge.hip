@@ -184,35 +184,41 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
     if (STAGE && fits_batched(n, e)) {
         const float4 *p4 = reinterpret_cast<const float4 *>(Pg), *q4 = reinterpret_cast<const float4 *>(Qg);
         const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
-        float4 rP[2], rQ[2], rH[2];
-        uint32_t rNb[2] = {0u, 0u};
+        // (plain named registers on purpose: with small arrays the compiler parked part of them in scratch memory)
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int i0 = tid, i1 = tid + EDGE_THREADS;
+        const bool in0 = i0 < n * 4, in1 = i1 < n * 4;
+        float4 p0 = z4, q0 = z4, h0 = z4, p1 = z4, q1 = z4, h1 = z4;
+        uint32_t nb0 = 0u, nb1 = 0u, rOrd = 0u, rNm = 0u;
         int rRp = 0;
-        uint32_t rOrd = 0, rNm = 0;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int i = tid + r * EDGE_THREADS;
-            if (i < n * 4) {
-                rP[r] = p4[i];
-                rQ[r] = q4[i];
-                rH[r] = h4[i];
-            }
-            if (i < e) rNb[r] = nbg[i];
+        if (in0) {
+            p0 = p4[i0];
+            q0 = q4[i0];
+            h0 = h4[i0];
         }
+        if (in1) {
+            p1 = p4[i1];
+            q1 = q4[i1];
+            h1 = h4[i1];
+        }
+        if (i0 < e) nb0 = nbg[i0];
+        if (i1 < e) nb1 = nbg[i1];
         if (tid <= n) rRp = rpg[tid];
         if (tid < n) {
             rOrd = og[tid];
             rNm = nmg[tid];
         }
         float mx = 0.f;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int i = tid + r * EDGE_THREADS;
-            if (i < n * 4) {
-                mx = fmaxf(mx, put_pq_exp(L.PQ, i, rP[r], rQ[r]));
-                reinterpret_cast<float4 *>(L.X)[i] = rH[r];
-            }
-            if (i < e) reinterpret_cast<uint32_t *>(L.nb)[i] = rNb[r];
+        if (in0) {
+            mx = put_pq_exp(L.PQ, i0, p0, q0);
+            reinterpret_cast<float4 *>(L.X)[i0] = h0;
         }
+        if (in1) {
+            mx = fmaxf(mx, put_pq_exp(L.PQ, i1, p1, q1));
+            reinterpret_cast<float4 *>(L.X)[i1] = h1;
+        }
+        if (i0 < e) reinterpret_cast<uint32_t *>(L.nb)[i0] = nb0;
+        if (i1 < e) reinterpret_cast<uint32_t *>(L.nb)[i1] = nb1;
         if (tid <= n) L.rp[tid] = rRp;
         if (tid < n) {
             L.ord[tid] = (uint16_t)rOrd;
@@ -437,24 +443,30 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
         // one memory round trip (see fits_batched): P/Q, G, the degrees of the G rows, the lists -- then commit
         const float4 *p4 = reinterpret_cast<const float4 *>(Pg), *q4 = reinterpret_cast<const float4 *>(Qg);
         const float4 *g4 = reinterpret_cast<const float4 *>(Gg);
-        float4 rP[2], rQ[2], rG[2];
-        int rD0[2] = {0, 0}, rD1[2] = {1, 1};
-        uint32_t rNb[2] = {0u, 0u};
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int i0 = tid, i1 = tid + EDGE_THREADS;
+        const bool in0 = i0 < n * 4, in1 = i1 < n * 4;
+        float4 p0 = z4, q0 = z4, g0 = z4, p1 = z4, q1 = z4, g1 = z4;
+        int d00 = 0, d01 = 1, d10 = 0, d11 = 1;               // row pointers of the G rows (their degrees)
+        uint32_t nb0 = 0u, nb1 = 0u, rOrd = 0u;
         int rRp = 0;
-        uint32_t rOrd = 0;
-        float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);       // the thread's four columns are the same on both trips
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int i = tid + r * EDGE_THREADS;
-            if (i < n * 4) {
-                rP[r] = p4[i];
-                rQ[r] = q4[i];
-                rG[r] = g4[i];
-                rD0[r] = rpg[i >> 2];
-                rD1[r] = rpg[(i >> 2) + 1];
-            }
-            if (i < e) rNb[r] = nbg[i];
+        float4 ex4 = z4;                                      // the thread's four columns are the same on both trips
+        if (in0) {
+            p0 = p4[i0];
+            q0 = q4[i0];
+            g0 = g4[i0];
+            d00 = rpg[i0 >> 2];
+            d01 = rpg[(i0 >> 2) + 1];
         }
+        if (in1) {
+            p1 = p4[i1];
+            q1 = q4[i1];
+            g1 = g4[i1];
+            d10 = rpg[i1 >> 2];
+            d11 = rpg[(i1 >> 2) + 1];
+        }
+        if (i0 < e) nb0 = nbg[i0];
+        if (i1 < e) nb1 = nbg[i1];
         if (tid <= n) rRp = rpg[tid];
         if (tid < n) rOrd = og[tid];
         if (LAST) {
@@ -462,17 +474,20 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
             ex4 = make_float4(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e, 0.5f * dh.z / (float)e, 0.5f * dh.w / (float)e);
         }
         float mx = 0.f;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int i = tid + r * EDGE_THREADS;
-            if (i < n * 4) {
-                mx = fmaxf(mx, put_pq_exp(L.PQ, i, rP[r], rQ[r]));
-                const float inv = __builtin_amdgcn_rcpf((float)(rD1[r] - rD0[r]) + 1e-6f);
-                reinterpret_cast<float4 *>(L.X)[i] = make_float4(fmaf(rG[r].x, inv, ex4.x), fmaf(rG[r].y, inv, ex4.y),
-                                                                 fmaf(rG[r].z, inv, ex4.z), fmaf(rG[r].w, inv, ex4.w));
-            }
-            if (i < e) reinterpret_cast<uint32_t *>(L.nb)[i] = rNb[r];
+        if (in0) {
+            mx = put_pq_exp(L.PQ, i0, p0, q0);
+            const float inv = __builtin_amdgcn_rcpf((float)(d01 - d00) + 1e-6f);
+            reinterpret_cast<float4 *>(L.X)[i0] = make_float4(fmaf(g0.x, inv, ex4.x), fmaf(g0.y, inv, ex4.y),
+                                                              fmaf(g0.z, inv, ex4.z), fmaf(g0.w, inv, ex4.w));
         }
+        if (in1) {
+            mx = fmaxf(mx, put_pq_exp(L.PQ, i1, p1, q1));
+            const float inv = __builtin_amdgcn_rcpf((float)(d11 - d10) + 1e-6f);
+            reinterpret_cast<float4 *>(L.X)[i1] = make_float4(fmaf(g1.x, inv, ex4.x), fmaf(g1.y, inv, ex4.y),
+                                                              fmaf(g1.z, inv, ex4.z), fmaf(g1.w, inv, ex4.w));
+        }
+        if (i0 < e) reinterpret_cast<uint32_t *>(L.nb)[i0] = nb0;
+        if (i1 < e) reinterpret_cast<uint32_t *>(L.nb)[i1] = nb1;
         if (tid <= n) L.rp[tid] = rRp;
         if (tid < n) L.ord[tid] = (uint16_t)rOrd;
         ok = mx <= EF_LIMIT && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
