@@ -185,29 +185,15 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
         const float4 *p4 = reinterpret_cast<const float4 *>(Pg), *q4 = reinterpret_cast<const float4 *>(Qg);
         const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
         // (plain named registers on purpose: with small arrays the compiler parked part of them in scratch memory)
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const int i0 = tid, i1 = tid + EDGE_THREADS;
         const bool in0 = i0 < n * 4, in1 = i1 < n * 4;
-        float4 p0 = z4, q0 = z4, h0 = z4, p1 = z4, q1 = z4, h1 = z4;
-        uint32_t nb0 = 0u, nb1 = 0u, rOrd = 0u, rNm = 0u;
-        int rRp = 0;
-        if (in0) {
-            p0 = p4[i0];
-            q0 = q4[i0];
-            h0 = h4[i0];
-        }
-        if (in1) {
-            p1 = p4[i1];
-            q1 = q4[i1];
-            h1 = h4[i1];
-        }
-        if (i0 < e) nb0 = nbg[i0];
-        if (i1 < e) nb1 = nbg[i1];
-        if (tid <= n) rRp = rpg[tid];
-        if (tid < n) {
-            rOrd = og[tid];
-            rNm = nmg[tid];
-        }
+        // unconditional loads from clamped (always valid) indices: no divergent control flow between the loads, so
+        // they all issue back to back; out-of-range lanes simply do not commit
+        const int c0 = in0 ? i0 : 0, c1 = in1 ? i1 : 0;
+        const float4 p0 = p4[c0], q0 = q4[c0], h0 = h4[c0], p1 = p4[c1], q1 = q4[c1], h1 = h4[c1];
+        const uint32_t nb0 = nbg[i0 < e ? i0 : 0], nb1 = nbg[i1 < e ? i1 : 0];
+        const int rRp = rpg[tid <= n ? tid : 0];
+        const uint32_t rOrd = og[tid < n ? tid : 0], rNm = nmg[tid < n ? tid : 0];
         float mx = 0.f;
         if (in0) {
             mx = put_pq_exp(L.PQ, i0, p0, q0);
@@ -446,29 +432,15 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const int i0 = tid, i1 = tid + EDGE_THREADS;
         const bool in0 = i0 < n * 4, in1 = i1 < n * 4;
-        float4 p0 = z4, q0 = z4, g0 = z4, p1 = z4, q1 = z4, g1 = z4;
-        int d00 = 0, d01 = 1, d10 = 0, d11 = 1;               // row pointers of the G rows (their degrees)
-        uint32_t nb0 = 0u, nb1 = 0u, rOrd = 0u;
-        int rRp = 0;
+        // unconditional loads from clamped (always valid) indices, see edge_fwd_kernel
+        const int c0 = in0 ? i0 : 0, c1 = in1 ? i1 : 0;
+        const float4 p0 = p4[c0], q0 = q4[c0], g0 = g4[c0], p1 = p4[c1], q1 = q4[c1], g1 = g4[c1];
+        const int d00 = rpg[c0 >> 2], d01 = rpg[(c0 >> 2) + 1];     // row pointers of the G rows (their degrees)
+        const int d10 = rpg[c1 >> 2], d11 = rpg[(c1 >> 2) + 1];
+        const uint32_t nb0 = nbg[i0 < e ? i0 : 0], nb1 = nbg[i1 < e ? i1 : 0];
+        const int rRp = rpg[tid <= n ? tid : 0];
+        const uint32_t rOrd = og[tid < n ? tid : 0];
         float4 ex4 = z4;                                      // the thread's four columns are the same on both trips
-        if (in0) {
-            p0 = p4[i0];
-            q0 = q4[i0];
-            g0 = g4[i0];
-            d00 = rpg[i0 >> 2];
-            d01 = rpg[(i0 >> 2) + 1];
-        }
-        if (in1) {
-            p1 = p4[i1];
-            q1 = q4[i1];
-            g1 = g4[i1];
-            d10 = rpg[i1 >> 2];
-            d11 = rpg[(i1 >> 2) + 1];
-        }
-        if (i0 < e) nb0 = nbg[i0];
-        if (i1 < e) nb1 = nbg[i1];
-        if (tid <= n) rRp = rpg[tid];
-        if (tid < n) rOrd = og[tid];
         if (LAST) {
             const float4 dh = *reinterpret_cast<const float4 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + (tid & 3) * 4);
             ex4 = make_float4(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e, 0.5f * dh.z / (float)e, 0.5f * dh.w / (float)e);
