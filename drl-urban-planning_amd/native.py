@@ -106,6 +106,9 @@ def lib():
             raise RuntimeError('native library %s not found and building it failed (%s). Run `python -c "import '
                                '__graft_entry__ as g; g.build()"` (or `make -C %s`). The HIP path has no Python '
                                'fallback.' % (LIB_PATH, exc, CSRC))
+    # torch first: its wheel bundles its own HIP runtime; if libupamd.so were loaded before it, the process would end up
+    # with /opt/rocm's runtime for this library and torch's for the tensors ("no ROCm-capable device" at first launch)
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         try:
