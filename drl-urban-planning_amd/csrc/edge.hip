@@ -34,7 +34,7 @@ namespace upamd {
 // workgroup per CU instead of two (measured: the last-layer forward went from 1.62 ms back to 1.05 ms).
 constexpr int EDGE_THREADS = 1024;
 constexpr int EDGE_WAVES = EDGE_THREADS / 64;
-constexpr int64_t LDS_LIMIT = 160 * 1024;
+constexpr int64_t LDS_LIMIT = 160 * 1024 - 1024;      // dynamic LDS a launch may ask for (the kernels also own 256 static bytes)
 constexpr float C2 = 2.8853900817779268f;      // 2 * log2(e)
 
 __device__ __forceinline__ float rcp1p_exp2(float x) {      // 1 / (1 + 2^x)
@@ -61,7 +61,8 @@ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage) 
 // the candidate count (backward: the per-node candidate-incidence pointers), `per_cand` = bytes per candidate.
 static int aux_capacity(int64_t lds, int64_t fixed, int per_cand) {
     // never trade the second resident workgroup for it (some slack: the allocation granularity is not 1 byte)
-    const int64_t limit = lds <= LDS_LIMIT / 2 - 2048 ? LDS_LIMIT / 2 - 2048 : LDS_LIMIT;
+    const int64_t half = 80 * 1024 - 2048;
+    const int64_t limit = lds <= half ? half : LDS_LIMIT;
     if (lds + fixed > limit) return -1;                                          // not even the fixed part fits
     int64_t cap = (limit - lds - fixed) / per_cand / 8 * 8;
     if (cap > 4096) cap = 4096;

@@ -272,7 +272,10 @@ def _random_case(D, L, heads, S, land, road, value, T, max_nodes, max_edges, see
 
 
 @pytest.mark.parametrize('D,L,heads,n_range,T', [(256, 3, 1, (200, 345), 5), (128, 2, 4, (40, 90), 6),
-                                                    (64, 2, 2, (30, 60), 6)])
+                                                    (64, 2, 2, (30, 60), 6),
+                                                    # 520..700 nodes: staged in LDS (one workgroup per CU) but too
+                                                    # large for the single-round-trip stage-in -> the looped stage-in
+                                                    (64, 2, 2, (520, 700), 3)])
 def test_wide_model_matches_oracle(D, L, heads, n_range, T):
     """BASELINE cfg-2 dims (3 layers x 256) on HLG-shaped graphs: exercises the MFMA GEMM tiles."""
     cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
