@@ -35,15 +35,16 @@ namespace upamd {
 constexpr int EDGE_THREADS = 1024;
 constexpr int EDGE_WAVES = EDGE_THREADS / 64;
 constexpr int64_t LDS_LIMIT = 160 * 1024 - 1024;      // dynamic LDS a launch may ask for (the kernels also own 256 static bytes)
+constexpr int64_t LDS_HALF = 80 * 1024 - 2048;       // two workgroups per CU (with slack for the allocation granularity)
 constexpr float C2 = 2.8853900817779268f;      // 2 * log2(e)
 
 __device__ __forceinline__ float rcp1p_exp2(float x) {      // 1 / (1 + 2^x)
     return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x) + 1.0f);
 }
 
-static inline int64_t a16(int64_t x) { return (x + 15) / 16 * 16; }
+__host__ __device__ static inline int64_t a16(int64_t x) { return (x + 15) / 16 * 16; }
 
-int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage) {
+__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage) {
     (void)last;
     int64_t b = 0;
     if (stage) b += (int64_t)max_n * 192;                     // P/Q interleaved (128 B/node) + H or dS (64 B/node)
@@ -61,8 +62,7 @@ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage) 
 // the candidate count (backward: the per-node candidate-incidence pointers), `per_cand` = bytes per candidate.
 static int aux_capacity(int64_t lds, int64_t fixed, int per_cand) {
     // never trade the second resident workgroup for it (some slack: the allocation granularity is not 1 byte)
-    const int64_t half = 80 * 1024 - 2048;
-    const int64_t limit = lds <= half ? half : LDS_LIMIT;
+    const int64_t limit = lds <= LDS_HALF ? LDS_HALF : LDS_LIMIT;
     if (lds + fixed > limit) return -1;                                          // not even the fixed part fits
     int64_t cap = (limit - lds - fixed) / per_cand / 8 * 8;
     if (cap > 4096) cap = 4096;
@@ -162,11 +162,17 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
                                                                 const float *__restrict__ Hin, float *__restrict__ Hout,
                                                                 float *__restrict__ hbarV, float *__restrict__ hbarE,
                                                                 const float *__restrict__ Ccur, float *__restrict__ FE,
-                                                                int aux_cap) {
+                                                                int aux_cap, int fit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;      // one scalar load: meta row + minibatch offsets
     const int n = m[0], e = m[1];
+    // size classes (see launch_edge_fwd): fit > 0 -> only graphs whose staged slice needs <= fit bytes of LDS,
+    // fit < 0 -> only the larger ones
+    if (fit != 0) {
+        const int64_t need = edge_lds_bytes(n, 2 * e, false, LAST, true);
+        if (fit > 0 ? need > fit : need <= -fit) return;
+    }
     const int64_t o = m[14], M = mb.M;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ca = 2 * (lane & 7), g = lane >> 3;      // this lane's two columns (ca, ca+1); node slot within the wave
@@ -360,36 +366,54 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
                     hipStream_t st, Profiler *prof) {
     const int NP = D / 16;
-    bool stage = true;
-    int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, true);
-    if (lds > LDS_LIMIT) {
-        stage = false;
-        lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, false);
-        if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_fwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
-    }
-    int aux_cap = 0;
-    if (last && FE) {
-        aux_cap = std::max(aux_capacity(lds, 0, 5), 0);       // u16 src + u16 dst + u8 live per candidate
-        lds += a16((int64_t)aux_cap * 5);
-    }
     const int began = prof_begin(prof, "edge_fwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
+    // one launch of a given (stage, lds, fit) configuration
+    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit) -> int {
 #define UPAMD_EF(L_, S_)                                                                                              \
     do {                                                                                                              \
         if (lds > 64 * 1024)                                                                                          \
             UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_>),                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
         hipLaunchKernelGGL((edge_fwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, Hout,  \
-                           hbarV, hbarE, Ccur, FE, aux_cap);                                                          \
+                           hbarV, hbarE, Ccur, FE, aux_cap, fit);                                                     \
     } while (0)
-    if (last && stage) UPAMD_EF(true, true);
-    else if (last) UPAMD_EF(true, false);
-    else if (stage) UPAMD_EF(false, true);
-    else UPAMD_EF(false, false);
+        if (last && stage) UPAMD_EF(true, true);
+        else if (last) UPAMD_EF(true, false);
+        else if (stage) UPAMD_EF(false, true);
+        else UPAMD_EF(false, false);
 #undef UPAMD_EF
+        UPAMD_HIP(hipGetLastError());
+        return 0;
+    };
+    const int64_t lds_max = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, true);
+    int rc = 0;
+    if (lds_max <= LDS_HALF) {
+        // every graph of the minibatch fits two workgroups per CU: one launch (+ the row's candidate lists on the last layer)
+        int64_t lds = lds_max;
+        int aux_cap = 0;
+        if (last && FE) {
+            aux_cap = std::max(aux_capacity(lds, 0, 5), 0);       // u16 src + u16 dst + u8 live per candidate
+            lds += a16((int64_t)aux_cap * 5);
+        }
+        rc = go(true, lds, aux_cap, 0);
+    } else {
+        // a few large graphs must not cost every workgroup its neighbour on the CU: the graphs that fit in half the
+        // LDS run in a two-per-CU launch, the rest in a second launch (staged with up to the whole LDS, or un-staged);
+        // a workgroup of the wrong class exits at once
+        rc = go(true, LDS_HALF, 0, (int)LDS_HALF);
+        if (rc == 0) {
+            if (lds_max <= LDS_LIMIT) {
+                rc = go(true, lds_max, 0, -(int)LDS_HALF);
+            } else {
+                const int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, false);
+                if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_fwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
+                rc = go(false, lds, 0, -(int)LDS_HALF);
+            }
+        }
+    }
     prof_end(prof, "edge_fwd", st, began);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -407,11 +431,15 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
                                                                 const float *__restrict__ G,
                                                                 const float *__restrict__ dhbarE, int ld_dhbarE,
                                                                 const float *__restrict__ dMhe, float *__restrict__ dPQ,
-                                                                float *__restrict__ dbias_part, int aux_cap) {
+                                                                float *__restrict__ dbias_part, int aux_cap, int fit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;      // one scalar load: meta row + minibatch offsets
     const int n = m[0], e = m[1];
+    if (fit != 0) {                                    // size classes, see launch_edge_fwd
+        const int64_t need = edge_lds_bytes(n, 2 * e, true, LAST, true);
+        if (fit > 0 ? need > fit : need <= -fit) return;
+    }
     const int64_t o = m[14], M = mb.M;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ca = 2 * (lane & 7), g = lane >> 3;      // this lane's two columns (ca, ca+1); node slot within the wave
@@ -621,37 +649,50 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
                     float *dbias_part, hipStream_t st, Profiler *prof) {
     const int NP = D / 16;
-    bool stage = true;
-    int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, true);
-    if (lds > LDS_LIMIT) {
-        stage = false;
-        lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, false);
-        if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_bwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
-    }
-    int aux_cap = -1;
-    if (last && dMhe) {
-        const int64_t fixed = a16(((int64_t)mb.max_n + 1) * 4);
-        aux_cap = aux_capacity(lds, fixed, 8);               // two u16 lists with two entries per candidate
-        if (aux_cap >= 0) lds += fixed + a16((int64_t)aux_cap * 8);
-    }
     const int began = prof_begin(prof, "edge_bwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
+    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit) -> int {
 #define UPAMD_EB(L_, S_)                                                                                              \
     do {                                                                                                              \
         if (lds > 64 * 1024)                                                                                          \
             UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_>),                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
         hipLaunchKernelGGL((edge_bwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G, dhbarE,  \
-                           ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap);                                                \
+                           ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit);                                           \
     } while (0)
-    if (last && stage) UPAMD_EB(true, true);
-    else if (last) UPAMD_EB(true, false);
-    else if (stage) UPAMD_EB(false, true);
-    else UPAMD_EB(false, false);
+        if (last && stage) UPAMD_EB(true, true);
+        else if (last) UPAMD_EB(true, false);
+        else if (stage) UPAMD_EB(false, true);
+        else UPAMD_EB(false, false);
 #undef UPAMD_EB
+        UPAMD_HIP(hipGetLastError());
+        return 0;
+    };
+    const int64_t lds_max = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, true);
+    int rc = 0;
+    if (lds_max <= LDS_HALF) {
+        int64_t lds = lds_max;
+        int aux_cap = -1;
+        if (last && dMhe) {
+            const int64_t fixed = a16(((int64_t)mb.max_n + 1) * 4);
+            aux_cap = aux_capacity(lds, fixed, 8);               // two u16 lists with two entries per candidate
+            if (aux_cap >= 0) lds += fixed + a16((int64_t)aux_cap * 8);
+        }
+        rc = go(true, lds, aux_cap, 0);
+    } else {                                                      // size classes, see launch_edge_fwd
+        rc = go(true, LDS_HALF, -1, (int)LDS_HALF);
+        if (rc == 0) {
+            if (lds_max <= LDS_LIMIT) {
+                rc = go(true, lds_max, -1, -(int)LDS_HALF);
+            } else {
+                const int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, false);
+                if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_bwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
+                rc = go(false, lds, -1, -(int)LDS_HALF);
+            }
+        }
+    }
     prof_end(prof, "edge_bwd", st, began);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
+    return rc;
 }
 
 }  // namespace upamd

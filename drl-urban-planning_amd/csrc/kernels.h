@@ -86,7 +86,7 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
 
 // ---- graph.hip -------------------------------------------------------------------------
 int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st);
-int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage);
+__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage);
 int launch_gather_rows(const PackedView &pk, const MbView &mb, int32_t *rows, hipStream_t st);
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
