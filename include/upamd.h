@@ -22,6 +22,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the entry points declared here are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define UPAMD_ABI_VERSION 1
 
@@ -227,6 +231,9 @@ int upamd_profile_read(upamd_engine *eng, const char *name, int64_t *launches, d
                        double *total_flops, double *total_bytes);
 int upamd_profile_reset(upamd_engine *eng);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
