@@ -7,6 +7,8 @@ urban_planning/models/state_encoder.py:163-177).  Input format = the wire format
 ``ObservationExtractor.get_obs`` (urban_planning/envs/observation_extractor.py:207-228).
 """
 import ctypes as C
+import importlib.util
+import os
 
 import numpy as np
 import torch
@@ -40,6 +42,26 @@ class PackedReplay:
         return raw[off:off + count * np.dtype(dtype).itemsize].view(dtype)
 
 
+_host_mod = False      # False = not looked up yet, None = unavailable
+
+
+def _host_helper():
+    """The optional CPython helper csrc/_upamd_host.so (pointer-table extraction in C); None when it is not built."""
+    global _host_mod
+    if _host_mod is False:
+        _host_mod = None
+        path = os.path.join(native.CSRC, '_upamd_host.so')
+        if os.path.exists(path):
+            try:
+                spec = importlib.util.spec_from_file_location('_upamd_host', path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _host_mod = mod
+            except Exception:           # glue only: the Python loop below does the same job
+                _host_mod = None
+    return _host_mod
+
+
 def _as_array(x, dtype):
     if isinstance(x, torch.Tensor):
         x = x.detach().cpu().numpy()
@@ -60,7 +82,13 @@ def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     pad_n = np.empty(T, dtype=np.int32)
     pad_e = np.empty(T, dtype=np.int32)
     keep = []
-    for t, s in enumerate(states):
+    first_slow = 0
+    helper = _host_helper()
+    if helper is not None:
+        # fast path: every state whose fields already are C-contiguous arrays of the wire dtypes is handled in C
+        bad = helper.addr_table(states, ptrs, pad_n, pad_e, int(node_dim))
+        first_slow = T if bad < 0 else 0          # anything unusual: redo the whole table the slow, validating way
+    for t, s in enumerate(states if first_slow < T else ()):
         if len(s) != 9:
             raise ValueError('state %d has %d fields, expected 9' % (t, len(s)))
         for f in range(9):

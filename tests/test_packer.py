@@ -88,3 +88,49 @@ def test_action_outside_candidates_maps_to_minus_one():
     replay.actions[4, 0] = bad
     pk = packer.pack_replay(replay.states, replay.actions, synth.NODE_DIM, synth.NUMERICAL_DIM, pin=False)
     assert pk.meta[4, 5] == -1
+
+
+def _sections(pk, Fn):
+    """Every section of a pack as arrays (the alignment gaps between sections are not written by the packer)."""
+    L, T = pk.layout, pk.T
+    N, E, H, R = int(L.total_nodes), int(L.total_edges), int(L.total_he), int(L.total_rn)
+    spec = [('meta', np.int32, T * native.META_STRIDE), ('x', np.float32, N * native.NODE_PAD), ('nmask', np.uint8, N),
+            ('rowptr', np.int32, N + T), ('inc_nbr', np.uint16, 2 * E), ('he_src', np.uint16, H), ('he_dst', np.uint16, H),
+            ('he_live', np.uint8, H), ('rn_node', np.uint16, R), ('numerical', np.float32, T * Fn),
+            ('cur', np.float32, T * native.NODE_PAD), ('order', np.uint16, N), ('hinc_ptr', np.int32, N + T),
+            ('hinc_nbr', np.uint16, 2 * H), ('hinc_he', np.uint16, 2 * H)]
+    return {name: pk.section(name, dt, cnt).copy() for name, dt, cnt in spec}
+
+
+def _same_pack(a, b, Fn):
+    sa, sb = _sections(a, Fn), _sections(b, Fn)
+    return all(np.array_equal(sa[k], sb[k]) for k in sa) and np.array_equal(a.meta, b.meta)
+
+
+def test_host_helper_matches_python_path():
+    """csrc/_upamd_host.so (pointer tables extracted in C) must give byte-identical packs to the Python loop, and
+    step aside for inputs it does not recognise (tensors, wrong dtypes) instead of guessing."""
+    import torch
+    if packer._host_helper() is None:
+        pytest.skip('_upamd_host.so not built')
+    rep = synth.make_replay(24, 'hlg', max_nodes=60, max_edges=200, seed=5, n_range=(20, 50))
+    fast = packer.pack_replay(rep.states, rep.actions, 23, rep.states[0][0].shape[-1], pin=False)
+    saved = packer._host_mod
+    try:
+        packer._host_mod = None
+        slow = packer.pack_replay(rep.states, rep.actions, 23, rep.states[0][0].shape[-1], pin=False)
+    finally:
+        packer._host_mod = saved
+    Fn = rep.states[0][0].shape[-1]
+    assert _same_pack(fast, slow, Fn)
+    # states given as torch tensors / float64 arrays: the helper reports them, the validating Python path converts
+    odd = [list(s) for s in rep.states]
+    odd[3] = [torch.from_numpy(a) for a in odd[3]]
+    odd[7][1] = odd[7][1].astype(np.float64)
+    conv = packer.pack_replay(odd, rep.actions, 23, rep.states[0][0].shape[-1], pin=False)
+    assert _same_pack(conv, slow, Fn)
+    # and a malformed state is still rejected
+    broken = [list(s) for s in rep.states]
+    broken[2] = broken[2][:8]
+    with pytest.raises(ValueError):
+        packer.pack_replay(broken, rep.actions, 23, rep.states[0][0].shape[-1], pin=False)
