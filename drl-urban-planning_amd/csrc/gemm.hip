@@ -28,7 +28,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 // ------------------------------------------------------------------------------------------ NT
 template <int BN, int WM, int WN, bool A_RM, bool C_RM, int PK, int KC = 0>      // KC != 0: K known at compile time
-__global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K, int64_t lda,
+__global__ __launch_bounds__(256, 4) void gemm_nt_mfma_kernel(const float *__restrict__ A, int64_t M, int K, int64_t lda,
                                                            const float *__restrict__ W, int N, int64_t ldw,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ R, float *__restrict__ C,
