@@ -39,6 +39,8 @@ WORKLOADS = {
     'hlg_ref': dict(community='hlg', D=16, L=2, B=256, T=8192, unique=1024, max_nodes=1000, max_edges=3000),
     # BASELINE.json configs[2]
     'dhm_d256': dict(community='dhm', D=256, L=3, B=4096, T=32768, unique=1024, max_nodes=1000, max_edges=3000),
+    # BASELINE.json configs[4], per-GPU share: heterogeneous HLG + DHM graphs in one minibatch (2048 rows per GPU)
+    'mixed_d256': dict(community='mixed', D=256, L=3, B=2048, T=16384, unique=1024, max_nodes=1000, max_edges=3000),
 }
 
 
