@@ -194,7 +194,7 @@ struct Lin {
             int S = 1;
             CK(launch_gemm_tn_ex(g, &S, st, prof));
             CK(launch_reduce_slabs(slabs, S, N, K, 0, keep, dW, keep, st));
-        } else if (R >= 512) {      // long reduction over rows, small output: split-K, fixed-order reduce
+        } else if (R >= 64) {       // reduction over rows, small output: split-K, fixed-order reduce
             int S = 1;
             CK(launch_smm_splitk(N, K, R, dY, 1, ldy, X, ldx, 1, slabs, &S, st));
             CK(launch_reduce_slabs(slabs, S, N, K, 0, keep, dW, keep, st));
