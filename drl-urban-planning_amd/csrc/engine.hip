@@ -74,10 +74,10 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     }
     add("Wkk", (int64_t)D * D); add("Wvv", (int64_t)D * D); add("bvv", D);
     add("W1f", 2LL * D * x.h0l); add("W1fT", 2LL * D * x.h0l); add("Wbd", (int64_t)D * x.h0l); add("R1T", (int64_t)D * x.h0r);
-    add("constb", B * x.h0l); add("dconst", B * x.h0l); add("dW1f", 2LL * D * x.h0l); add("dWbd", (int64_t)D * x.h0l);
+    add("constb", B * x.h0l); add("dconst", B * x.h0l);
     add("wt", (int64_t)x.maxdim * x.maxdim);          // transposed-weight scratch of the per-sample layers
     add("W1c", 2LL * D * 32); add("b1c", 2LL * D);    // first GCN layer collapsed onto the raw node features
-    add("Tn", 2LL * D * 32); add("cs1", 2LL * D); add("dWc1", 2LL * D * D);   // backward of that collapse
+    add("dWc1", 2LL * D * D);                         // backward of that collapse
     add("Xp", 2 * M * 16);
     add("U0", B * x.Fn);
     for (int i = 0; i < d.n_num; ++i) add("U" + std::to_string(i + 1), B * d.num_hidden[i]);
@@ -99,7 +99,11 @@ void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
     add("datt", B * D);
     add("do", B * D); add("ds", B * x.heads * D); add("dr", B * x.heads * D);
     add("dq1", B * D); add("dq0", B * D); add("dC", B * D); add("dC_head", B * D);
+    // accumulate-into scratch of the backward, one contiguous block zeroed by a single memset ("zero_end" marks its end)
     add("dWkk", (int64_t)D * D); add("dWvv", (int64_t)D * D); add("dbvv", D);
+    add("dW1f", 2LL * D * x.h0l); add("dWbd", (int64_t)D * x.h0l); add("Tn", 2LL * D * 32);
+    for (int l = 1; l <= x.L; ++l) add("cs" + std::to_string(l), 2LL * D);     // column sums of dP | dQ per layer
+    add("zero_end", 1);
     add("dz_he", NH); add("dz_rn", NR); add("dprel", NH * x.h0l); add("dFE", NH * 2 * D); add("dMhe", NH * D);
     add("dprer", NR * x.h0r); add("dXR", NR * D);
     add("G0", M * D); add("G1", M * D); add("dPQ", M * 2 * D); add("dbias_part", B * 2 * D);
@@ -464,6 +468,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     float *gWin = GR(P.inproj_w), *gbin = GR(P.inproj_b);
     const float *HL = W("H" + std::to_string(x.L));
 
+    UPAMD_HIP(hipMemsetAsync(W("dWkk"), 0, sizeof(float) * (size_t)(W("zero_end") - W("dWkk")), st));      // every accumulate-into scratch
     // ---- value head
     float *dzA = W("dzA"), *dzB = W("dzB");
     {
@@ -513,9 +518,6 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     const float *datt = W("datt");
     CK(lin.tn_acc(datt, D, B, D, W("o"), D, D, GR(P.outproj_w), GR(P.outproj_b)));
     CK(lin.nn(datt, D, B, D, PR(P.outproj_w), D, W("do"), D));
-    UPAMD_HIP(hipMemsetAsync(W("dWvv"), 0, sizeof(float) * (size_t)D * D, st));
-    UPAMD_HIP(hipMemsetAsync(W("dWkk"), 0, sizeof(float) * (size_t)D * D, st));
-    UPAMD_HIP(hipMemsetAsync(W("dbvv"), 0, sizeof(float) * (size_t)D, st));
     CK(launch_colsum_rm(W("do"), B, D, D, W("dbvv"), st));
     for (int h = 0; h < x.heads; ++h) {
         // dWvv[h-slice,:] += do[:,h-slice]^T s[:,h,:]
@@ -560,8 +562,6 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_rowdot_bwd_pm(W("hidl"), mb.Nhe, x.h0l, PR(P.land_w[1]), W("dz_he"), W("dprel"), st));
         CK(launch_colsum_pm(W("dprel"), mb.Nhe, x.h0l, nullptr, W("cs_part"), GR(P.land_b0), st));
         // dW1f = dpre^T FE, mapped back onto [Wa|Wb|Wc|Wd] together with dWbd = dconst^T C
-        UPAMD_HIP(hipMemsetAsync(W("dW1f"), 0, sizeof(float) * (size_t)2 * D * x.h0l, st));
-        UPAMD_HIP(hipMemsetAsync(W("dWbd"), 0, sizeof(float) * (size_t)D * x.h0l, st));
         CK(launch_gemm_tn(W("FE"), 2 * D, W("dprel"), x.h0l, mb.Nhe, W("slabs"), &S, st, prof));
         CK(launch_reduce_slabs(W("slabs"), S, 2 * D, x.h0l, 1, x.h0l, W("dW1f"), 2 * D, st));
         CK(launch_he_segsum(pk, mb, x.h0l, W("dprel"), W("dconst"), st));
@@ -593,9 +593,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_edge_bwd(pk, mb, D, last, W("PQ" + sl), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp,
                            (last && mb.Nhe > 0) ? W("dMhe") : nullptr, W("dPQ"), W("dbias_part"), st, prof));
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
-        UPAMD_HIP(hipMemsetAsync(W("cs1"), 0, sizeof(float) * (size_t)2 * D, st));
-        CK(launch_reduce_rows_add(W("dbias_part"), B, 2 * D, W("cs1"), st));
-        CK(launch_add_p_panels(GR(P.edge_b[l - 1]), W("cs1"), D, st));
+        CK(launch_reduce_rows_add(W("dbias_part"), B, 2 * D, W("cs" + sl), st));
+        CK(launch_add_p_panels(GR(P.edge_b[l - 1]), W("cs" + sl), D, st));
         if (l > 1) {
             CK(launch_gemm_tn(W("dPQ"), 2 * D, W("H" + sp), D, mb.M, W("slabs"), &S, st, prof));
             CK(launch_reduce_slabs(W("slabs"), S, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D, st));
@@ -604,7 +603,6 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         } else {
             // layer 1: H_0 = Xp We^T + be, so dWcat_1 = dPQ_1^T H_0 = (dPQ_1^T Xp) We^T + colsum(dPQ_1) (x) be --
             // two J = 32 reductions over the nodes instead of a full-size weight-gradient GEMM
-            UPAMD_HIP(hipMemsetAsync(W("Tn"), 0, sizeof(float) * (size_t)2 * D * 32, st));
             CK(launch_gemm_tn(W("dPQ"), 2 * D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
             CK(launch_reduce_slabs(W("slabs"), S, 2 * D, 32, 0, 32, W("Tn"), 32, st));
             CK(lin.nt(W("Tn"), 32, 2 * D, 32, W("We_pad"), 32, nullptr, D, W("dWc1"), D, 0, 1.f));       // Tn We^T
