@@ -181,11 +181,9 @@ struct Lin {
     }
     // Y[R,N] = X[R,K] Wm[K,N]   (Wm row-major dense, ld = N)
     int nn(const float *X, int64_t ldx, int R, int K, const float *Wm, int N, float *Y, int64_t ldy) const {
-        GemmNT g{X, R, K, ldx, true, wt, N, K, nullptr, nullptr, Y, ldy, true, 0, 1.f};
-        if (R >= MIN_ROWS && gemm_nt_mfma_ok(g)) {
-            CK(launch_transpose(Wm, K, N, wt, st));
-            return launch_gemm_nt_ex(g, st, prof);
-        }
+        GemmNT g{X, R, K, ldx, true, Wm, N, N, nullptr, nullptr, Y, ldy, true, 0, 1.f};
+        g.w_kn = true;                       // the kernel reads the [K][N] weight as it is
+        if (R >= MIN_ROWS && gemm_nt_mfma_ok(g)) return launch_gemm_nt_ex(g, st, prof);
         return launch_smm(R, N, K, X, ldx, 1, Wm, N, 1, nullptr, Y, ldy, 0, 0, 1.f, st);
     }
     // dW[N,K] += dY[R,N]^T X[R,K];  db[N] += colsum(dY)

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_mfma_kernel(const float *__res
                                                            const float *__restrict__ W, int N, int64_t ldw,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ R, float *__restrict__ C,
-                                                           int64_t ldc, int act_tanh, float alpha, int MT, int NT) {
+                                                           int64_t ldc, int act_tanh, float alpha, int MT, int NT,
+                                                           int w_kn) {
     constexpr int BM = 128, LD = 17;
     constexpr int WAVES_N = BN / WN;
     constexpr int TI = WM / 32, TJ = WN / 32;
@@ -78,7 +79,12 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_mfma_kernel(const float *__res
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
-                if (e < BN * 4) rb[pp][q] = *reinterpret_cast<const float4 *>(W + (int64_t)(n0 + row) * ldw + kp * 16 + c4);
+                if (e < BN * 4) {
+                    // [N][K] weights: 4 consecutive k of row n;  [K][N] weights: 4 consecutive n of row k
+                    const float *src = w_kn ? W + (int64_t)(kp * 16 + e / (BN / 4)) * ldw + n0 + (e % (BN / 4)) * 4
+                                            : W + (int64_t)(n0 + row) * ldw + kp * 16 + c4;
+                    rb[pp][q] = *reinterpret_cast<const float4 *>(src);
+                }
             }
         }
     };
@@ -95,8 +101,13 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_mfma_kernel(const float *__res
             for (int q = 0; q < NB; ++q) {
                 const int e = tid + 256 * q, row = e >> 2, c4 = (e & 3) * 4;
                 if (e < BN * 4) {
-                    float *d = &Bs[buf][pp][row * LD + c4];
-                    d[0] = rb[pp][q].x; d[1] = rb[pp][q].y; d[2] = rb[pp][q].z; d[3] = rb[pp][q].w;
+                    if (w_kn) {
+                        float *d = &Bs[buf][pp][(e % (BN / 4)) * 4 * LD + e / (BN / 4)];
+                        d[0] = rb[pp][q].x; d[LD] = rb[pp][q].y; d[2 * LD] = rb[pp][q].z; d[3 * LD] = rb[pp][q].w;
+                    } else {
+                        float *d = &Bs[buf][pp][row * LD + c4];
+                        d[0] = rb[pp][q].x; d[1] = rb[pp][q].y; d[2] = rb[pp][q].z; d[3] = rb[pp][q].w;
+                    }
                 }
             }
         }
@@ -235,19 +246,19 @@ static void launch_nt_layout(const GemmNT &g, hipStream_t st, bool k32 = false) 
     if (k32) {
         const int NT = g.N / 128;
         hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM, PK, 32>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K,
-                           g.lda, g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
+                           g.lda, g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT, g.w_kn ? 1 : 0);
     } else if (BNsel == 128) {
         const int NT = g.N / 128;
         hipLaunchKernelGGL((gemm_nt_mfma_kernel<128, 64, 64, A_RM, C_RM, PK>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
-                           g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
+                           g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT, g.w_kn ? 1 : 0);
     } else if (BNsel == 64) {
         const int NT = g.N / 64;
         hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64, 32, A_RM, C_RM, PK>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
-                           g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
+                           g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT, g.w_kn ? 1 : 0);
     } else {
         const int NT = g.N / 32;
         hipLaunchKernelGGL((gemm_nt_mfma_kernel<32, 32, 32, A_RM, C_RM, PK>), dim3(MT8 * NT), dim3(256), 0, st, g.A, g.M, g.K, g.lda,
-                           g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT);
+                           g.W, g.N, g.ldw, g.bias, g.R, g.C, g.ldc, g.act_tanh, g.alpha, MT, NT, g.w_kn ? 1 : 0);
     }
 }
 

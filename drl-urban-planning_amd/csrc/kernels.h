@@ -64,6 +64,7 @@ struct GemmNT {
     const float *bias; const float *R;
     float *C; int64_t ldc; bool c_rm;
     int act_tanh; float alpha;
+    bool w_kn = false;          // W is given as [K][N] (row stride ldw) instead of [N][K]: C = A W, no transpose needed
 };
 bool gemm_nt_mfma_ok(const GemmNT &g);
 int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof);
