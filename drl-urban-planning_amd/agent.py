@@ -116,6 +116,32 @@ class PPOUpdater:
         """Write the flat parameters back into the nn.Module parameters."""
         self.engine.unflatten(self.flat, self._named)
 
+    # ------------------------------------------------------------------ optimizer checkpoint (SURVEY section 8f row 3)
+    def state_dict(self):
+        """Optimizer state the reference's checkpoint omits (urban_planning_agent.py:172-194 saves only the networks):
+        Adam moments per named parameter (CPU tensors), the per-group step counts, the loss-curve position and whether
+        the first-step clipping quirk is still pending.  `load_state_dict` restores it, so a resumed run continues the
+        same trajectory instead of restarting Adam."""
+        out = {'group_steps': list(self.group_steps), 'loss_iter': int(self.loss_iter),
+               'clip_pending': bool(self.clip_pending), 'exp_avg': {}, 'exp_avg_sq': {}}
+        if self.m is not None:
+            eng = self.engine if self.engine is not None else self.backend.engine(self._device())
+            for name, off, rows, cols, _ in eng.table:
+                shape = tuple(self.backend.named_params()[name].shape)
+                out['exp_avg'][name] = self.m[off:off + rows * cols].detach().cpu().clone().view(shape)
+                out['exp_avg_sq'][name] = self.v[off:off + rows * cols].detach().cpu().clone().view(shape)
+        return out
+
+    def load_state_dict(self, state):
+        self.group_steps = [int(x) for x in state['group_steps']]
+        self.loss_iter = int(state['loss_iter'])
+        self.clip_pending = bool(state['clip_pending'])
+        if state['exp_avg']:
+            eng = self.attach()
+            for name, off, rows, cols, _ in eng.table:
+                self.m[off:off + rows * cols].copy_(state['exp_avg'][name].reshape(-1))
+                self.v[off:off + rows * cols].copy_(state['exp_avg_sq'][name].reshape(-1))
+
     @staticmethod
     def _to_f32(x, device):
         return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device)
