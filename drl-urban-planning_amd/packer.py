@@ -70,6 +70,98 @@ def _as_array(x, dtype):
     return x
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Compact wire record of one state (SURVEY.md section 8f row 1).  The reference's rollout workers push the padded
+# 9-field tuple (~148 KB at 1000 / 3000 pads) through a multiprocessing queue (khrylib/rl/agents/agent.py:92-97);
+# the record keeps the same nine arrays but only up to the last non-empty node / edge row (~54 KB for an HLG state),
+# in one contiguous uint8 buffer that can live in shared memory.  It is lossless: every dropped row is all-zero /
+# all-False, `expand_state(record, padded=True)` gives back the exact padded tuple, and without `padded` it returns
+# zero-copy views that `pack_replay` consumes directly (the engine never looks at pad rows).
+_REC_MAGIC = 0x31535055          # 'UPS1'
+_REC_HEADER = np.dtype([('magic', '<u4'), ('node_dim', '<u4'), ('numerical_len', '<u4'), ('cur_len', '<u4'),
+                        ('stage_len', '<u4'), ('pad_n', '<u4'), ('pad_e', '<u4'), ('n_rows', '<u4'), ('e_rows', '<u4'),
+                        ('edge_fill', '<i4')])       # index value of the dropped edge rows (the extractor pads with N-1)
+
+
+def _align8(x):
+    return (x + 7) & ~7
+
+
+def _record_sections(h):
+    """[(field index, dtype, shape, byte offset)] of a record with header values h, and its total size."""
+    F, nr, er = int(h['node_dim']), int(h['n_rows']), int(h['e_rows'])
+    spec = [(0, np.float32, (int(h['numerical_len']),)), (1, np.float32, (nr, F)), (2, np.int64, (er, 2)),
+            (3, np.float32, (int(h['cur_len']),)), (4, np.bool_, (nr,)), (5, np.bool_, (er,)), (6, np.bool_, (er,)),
+            (7, np.bool_, (nr,)), (8, np.float32, (int(h['stage_len']),))]
+    out, off = [], _align8(_REC_HEADER.itemsize)
+    for f, dt, shape in spec:
+        out.append((f, dt, shape, off))
+        off = _align8(off + int(np.prod(shape)) * np.dtype(dt).itemsize)
+    return out, off
+
+
+def compact_state(state):
+    """9-field padded state (observation_extractor.py:207-228) -> compact uint8 record (see above)."""
+    if len(state) != 9:
+        raise ValueError('state has %d fields, expected 9' % len(state))
+    a = [_as_array(state[f], _FIELD_DTYPES[f]) for f in range(9)]
+    nf, ei = a[1], a[2]
+    if nf.ndim != 2 or ei.ndim != 2 or ei.shape[1] != 2:
+        raise ValueError('node features must be [N, F] and edge index [E, 2]')
+    if not (len(a[4]) == len(a[7]) == nf.shape[0] and len(a[5]) == len(a[6]) == ei.shape[0]):
+        raise ValueError('mask lengths do not match the padded node / edge counts')
+    used_n = np.flatnonzero(a[4] | a[7] | (nf != 0).any(axis=1))
+    # padded edge rows repeat one index value (observation_extractor.py pads the edge list with max_num_nodes - 1):
+    # trailing rows that are unmasked and hold exactly that value are dropped and re-created on expansion
+    fill = int(ei[-1, 0]) if ei.shape[0] and ei[-1, 0] == ei[-1, 1] and abs(int(ei[-1, 0])) < 2 ** 31 else 0
+    used_e = np.flatnonzero(a[5] | a[6] | (ei != fill).any(axis=1))
+    h = np.zeros((), dtype=_REC_HEADER)
+    h['magic'], h['node_dim'], h['numerical_len'] = _REC_MAGIC, nf.shape[1], a[0].size
+    h['cur_len'], h['stage_len'] = a[3].size, a[8].size
+    h['pad_n'], h['pad_e'], h['edge_fill'] = nf.shape[0], ei.shape[0], fill
+    h['n_rows'] = int(used_n[-1]) + 1 if used_n.size else 0
+    h['e_rows'] = int(used_e[-1]) + 1 if used_e.size else 0
+    sections, total = _record_sections(h)
+    rec = np.zeros(total, dtype=np.uint8)
+    rec[:_REC_HEADER.itemsize] = np.frombuffer(h.tobytes(), dtype=np.uint8)
+    for f, dt, shape, off in sections:
+        n = int(np.prod(shape))
+        src = a[f].reshape(-1) if f in (0, 3, 8) else a[f][:shape[0]].reshape(-1)
+        rec[off:off + n * np.dtype(dt).itemsize] = src[:n].view(np.uint8) if n else src[:0].view(np.uint8)
+    return rec
+
+
+def is_record(obj):
+    return isinstance(obj, np.ndarray) and obj.dtype == np.uint8 and obj.ndim == 1 and obj.size >= _REC_HEADER.itemsize \
+        and int(obj[:4].view('<u4')[0]) == _REC_MAGIC
+
+
+def expand_state(record, padded=False):
+    """Record -> list of the 9 arrays.  padded=False: zero-copy views with the trimmed row counts (what pack_replay
+    needs); padded=True: fresh arrays of the original pad sizes, equal to the state the record was made from."""
+    if not is_record(record):
+        raise ValueError('not a compact state record')
+    h = record[:_REC_HEADER.itemsize].view(_REC_HEADER)[0]
+    sections, total = _record_sections(h)
+    if record.size < total:
+        raise ValueError('truncated state record (%d < %d bytes)' % (record.size, total))
+    out = []
+    for f, dt, shape, off in sections:
+        n = int(np.prod(shape))
+        v = record[off:off + n * np.dtype(dt).itemsize].view(dt).reshape(shape)
+        if padded and f in (1, 2, 4, 5, 6, 7):
+            rows = int(h['pad_n']) if f in (1, 4, 7) else int(h['pad_e'])
+            full = np.zeros((rows,) + tuple(shape[1:]), dtype=dt)
+            if f == 2:
+                full[:] = int(h['edge_fill'])
+            full[:shape[0]] = v
+            v = full
+        elif padded:
+            v = v.copy()
+        out.append(v)
+    return out
+
+
 def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None, reuse=None):
     """states: list[T] of list[9] arrays (or tensors); actions: f32[T,2] (padded-slot indices).
     ``reuse``: optional dict owned by the caller; its pinned staging buffer is recycled across iterations
@@ -77,6 +169,8 @@ def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     T = len(states)
     if T == 0:
         raise ValueError('empty replay')
+    if any(is_record(s) for s in states):           # compact wire records: zero-copy views, trimmed pads
+        states = [expand_state(s) if is_record(s) else s for s in states]
     L = native.lib()
     ptrs = np.empty((9, T), dtype=np.uint64)
     pad_n = np.empty(T, dtype=np.int32)

@@ -134,3 +134,31 @@ def test_host_helper_matches_python_path():
     broken[2] = broken[2][:8]
     with pytest.raises(ValueError):
         packer.pack_replay(broken, rep.actions, 23, rep.states[0][0].shape[-1], pin=False)
+
+
+def test_compact_wire_record_is_lossless_and_packs_identically():
+    """the compact record of a state (trailing empty node / edge rows dropped) expands back to
+    the exact padded tuple, and a replay given as records packs to the same graph data as the padded states."""
+    rep = synth.make_replay(20, 'mixed', max_nodes=120, max_edges=400, seed=9, road_fraction=0.3, n_range=(20, 60))
+    quirky = cases.quirky_replay(6, 28, 60, seed=4, road_fraction=0.5, n_lo=10, full_row=True)
+    for states in (rep.states, quirky.states):
+        recs = [packer.compact_state(s) for s in states]
+        for s, rec in zip(states, recs):
+            assert packer.is_record(rec) and rec.dtype == np.uint8 and rec.ndim == 1
+            back = packer.expand_state(rec, padded=True)
+            assert all(np.array_equal(a, b) and np.asarray(a).dtype == b.dtype and np.asarray(a).shape == b.shape
+                       for a, b in zip(s, back))
+    recs = [packer.compact_state(s) for s in rep.states]
+    assert sum(r.size for r in recs) < 0.6 * sum(sum(np.asarray(a).nbytes for a in s) for s in rep.states)
+    Fn = rep.states[0][0].shape[-1]
+    a = packer.pack_replay(rep.states, rep.actions, 23, Fn, pin=False)
+    mixed = [recs[i] if i % 2 else rep.states[i] for i in range(len(recs))]        # records and padded states together
+    b = packer.pack_replay(mixed, rep.actions, 23, Fn, pin=False)
+    ma, mb = a.meta.copy(), b.meta.copy()
+    ma[:, packer.M_PADN:packer.M_PADE + 1] = 0                                      # the records carry trimmed pads
+    mb[:, packer.M_PADN:packer.M_PADE + 1] = 0
+    assert np.array_equal(ma, mb)
+    sa, sb = _sections(a, Fn), _sections(b, Fn)
+    assert all(np.array_equal(sa[k], sb[k]) for k in sa if k != 'meta')
+    with pytest.raises(ValueError):
+        packer.expand_state(recs[0][:100])
