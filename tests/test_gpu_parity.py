@@ -541,3 +541,21 @@ def test_native_failure_modes():
                                C.c_int64(1024), C.c_void_p(v.data_ptr()), C.c_void_p(v.data_ptr()),
                                C.c_void_p(v.data_ptr()), 0, None)
     assert rc == -4 and b'workspace too small' in eng.lib.upamd_last_error()
+
+
+@pytest.mark.parametrize('seed', list(range(10)))
+def test_random_small_configurations(seed):
+    """Fuzz over model shapes and graph sizes (tiny graphs below one 8-node chunk, one-layer models, several heads,
+    road-only and land-only minibatches): forward values, losses and every gradient against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([16, 32, 64]))
+    heads = int(rng.choice([h for h in (1, 2, 4) if D % h == 0]))
+    L = int(rng.integers(1, 4))
+    lo = int(rng.choice([3, 6, 12, 30]))
+    n_range = (lo, lo + int(rng.integers(0, 40)))
+    T = int(rng.integers(2, 7))
+    road_fraction = float(rng.choice([0.0, 0.3, 1.0]))
+    cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 3,
+                                   int(5.55 * n_range[1]) + 12, seed=50 + seed, road_fraction=road_fraction,
+                                   n_range=n_range)
+    _check_against_oracle(cfg, sd, replay, heads, T)
