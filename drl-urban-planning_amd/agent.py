@@ -19,15 +19,25 @@ What differs by design: the shared encoder is evaluated once per step (same grad
 replay is packed and uploaded once per iteration; the four loss scalars stay on the GPU until the
 iteration ends (no host sync inside the minibatch loop); optimizer state lives in flat device
 buffers owned by the updater (the reference never checkpoints optimizer state either).
+
+Data parallelism (the reference has none): see ``dist.py``.  ``mini_batch_size`` keeps
+the reference's meaning in ``dp_mode='global'`` -- the GLOBAL minibatch, of which every rank processes
+``mini_batch_size / world`` rows -- and is the per-rank minibatch in ``dp_mode='local'``.
+
+``zero_grad`` semantics: the goldens (and this implementation) follow torch >= 2.0, where ``zero_grad()`` sets the
+gradients of a head that saw no row to ``None`` and Adam skips that head.  The reference pins torch <= 1.13, whose
+``zero_grad()`` zero-fills: there, a head without rows still takes an Adam step with g = 0 once it has had a
+gradient (step count + moment decay + a momentum move).  ``legacy_zero_grad=True`` reproduces that.
 """
 import math
+import os
 import time
 
 import numpy as np
 import torch
 
 from . import packer
-from .dist import DistContext, global_counts
+from .dist import DistContext, batch_fingerprint, global_counts, order_fingerprint, split_minibatch
 from .models import backend_of
 
 
@@ -55,7 +65,7 @@ class PPOUpdater:
     def __init__(self, policy_net, value_net, lr=4e-4, eps=1e-5, weight_decay=0.0, betas=(0.9, 0.999), gamma=1.0,
                  tau=0.0, clip_epsilon=0.2, value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4,
                  mini_batch_size=256, batch_stage=False, max_grad_norm=1.0, dist_ctx=None, pack_threads=0,
-                 sub_batches=1):
+                 sub_batches=1, dp_mode='auto', dp_balance='edges', legacy_zero_grad=False):
         self.policy_net, self.value_net = policy_net, value_net
         self.backend = backend_of(policy_net)
         self.lr, self.eps, self.weight_decay, self.betas = lr, eps, weight_decay, betas
@@ -66,6 +76,12 @@ class PPOUpdater:
         self.batch_stage = batch_stage
         self.max_grad_norm = max_grad_norm
         self.dist = dist_ctx or DistContext()
+        if dp_mode not in ('auto', 'global', 'local'):
+            raise ValueError("dp_mode must be 'auto', 'global' or 'local'")
+        self.dp_mode, self.dp_balance = dp_mode, dp_balance
+        self._mode = 'single'                 # resolved per update_params: 'single' | 'global' | 'local'
+        self.legacy_zero_grad = bool(legacy_zero_grad)
+        self._group_seen = [False, False, False]
         self.pack_threads = pack_threads
         # sub_batches = 2: the two halves of every minibatch run on two HIP streams so the MFMA-bound GEMMs of
         # one half overlap the VALU-bound message passing of the other; their gradients are summed afterwards
@@ -103,14 +119,43 @@ class PPOUpdater:
         self.engine = engine
         self._named = self.backend.named_params()
         engine.flatten(self._named, out=self.flat)
-        B = self.mini_batch_size
-        if getattr(self, '_rowbuf_B', None) != B:
-            self._rows = [torch.empty(B, device=dev) for _ in range(6)]   # value, logp, ent, dvalue, dlogp, dent
-            self._rowbuf_B = B
         if self.sub_batches > 1 and getattr(self, '_streams', None) is None:
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.sub_batches)]
             self._sub_grads = [torch.zeros_like(self.grads) for _ in range(self.sub_batches)]
         return engine
+
+    def _ensure_rowbufs(self, rows):
+        if getattr(self, '_rowbuf_B', None) != rows:
+            dev = self.engine.device
+            self._rows = [torch.empty(rows, device=dev) for _ in range(6)]   # value, logp, ent, dvalue, dlogp, dent
+            self._rowbuf_B = rows
+
+    # ------------------------------------------------------------------ data-parallel mode
+    def _resolve_mode(self, batch):
+        """'single' (no collectives) | 'global' (same batch everywhere, slices of one global permutation) |
+        'local' (own shard per rank).  'auto' picks 'global' exactly when every rank was handed the same batch."""
+        d = self.dist
+        if not d.active:
+            return 'single'
+        if d.world == 1 or self.dp_mode == 'local':
+            return 'local'
+        same = d.same_everywhere(batch_fingerprint(batch), self.engine.device)
+        if self.dp_mode == 'global' and not same:
+            raise RuntimeError("dp_mode='global' needs the same replay batch on every rank (sample once and "
+                               "dist.broadcast_batch it, or use dp_mode='local' for per-rank shards)")
+        return 'global' if same else 'local'
+
+    def local_rows(self):
+        """Rows THIS rank processes per optimizer step."""
+        if self._mode == 'global':
+            if self.mini_batch_size % self.dist.world:
+                raise ValueError('mini_batch_size %d is not divisible by %d ranks' % (self.mini_batch_size, self.dist.world))
+            return self.mini_batch_size // self.dist.world
+        return self.mini_batch_size
+
+    def global_rows(self):
+        """Rows of one GLOBAL minibatch (what one optimizer step consumes over all ranks)."""
+        return self.mini_batch_size if self._mode != 'local' else self.mini_batch_size * self.dist.world
 
     def detach(self):
         """Write the flat parameters back into the nn.Module parameters."""
@@ -123,7 +168,8 @@ class PPOUpdater:
         the first-step clipping quirk is still pending.  `load_state_dict` restores it, so a resumed run continues the
         same trajectory instead of restarting Adam."""
         out = {'group_steps': list(self.group_steps), 'loss_iter': int(self.loss_iter),
-               'clip_pending': bool(self.clip_pending), 'exp_avg': {}, 'exp_avg_sq': {}}
+               'clip_pending': bool(self.clip_pending), 'group_seen': list(self._group_seen), 'exp_avg': {},
+               'exp_avg_sq': {}}
         if self.m is not None:
             eng = self.engine if self.engine is not None else self.backend.engine(self._device())
             for name, off, rows, cols, _ in eng.table:
@@ -136,6 +182,7 @@ class PPOUpdater:
         self.group_steps = [int(x) for x in state['group_steps']]
         self.loss_iter = int(state['loss_iter'])
         self.clip_pending = bool(state['clip_pending'])
+        self._group_seen = [bool(x) for x in state.get('group_seen', [n > 0 for n in self.group_steps])]
         if state['exp_avg']:
             eng = self.attach()
             for name, off, rows, cols, _ in eng.table:
@@ -151,6 +198,11 @@ class PPOUpdater:
         """Pack + upload the replay, value / old-log-prob pre-pass (:256-264, :283-292), GAE (:267)."""
         engine, dev = self.engine, self.engine.device
         agent = self.policy_net.agent
+        self._mode = self._resolve_mode(batch)
+        R = self.local_rows()
+        if self.sub_batches > 1 and R % self.sub_batches:
+            raise ValueError('sub_batches must divide the %d rows a rank processes per step' % R)
+        self._ensure_rowbufs(R)
         T = len(batch.states)
         if not hasattr(self, '_pack_cache'):
             self._pack_cache = {}
@@ -162,16 +214,24 @@ class PPOUpdater:
         masks = self._to_f32(batch.masks, dev)
         exps_np = np.asarray(batch.exps, dtype=np.float32)
         exps = torch.from_numpy(exps_np).to(dev)
-        values = torch.empty(T, device=dev)
-        logp = torch.empty(T, device=dev)
+        shared = self._mode == 'global'
+        # 'global': every rank holds all T rows, so the no-grad sweep is shared out chunk by chunk and the two
+        # T-float results are summed over the ranks (rows a rank did not compute are zero)
+        values = torch.zeros(T, device=dev) if shared else torch.empty(T, device=dev)
+        logp = torch.zeros(T, device=dev) if shared else torch.empty(T, device=dev)
         ent = torch.empty(T, device=dev)
-        chunk = self.mini_batch_size
+        chunk = R
         row_lists = [np.arange(i, min(i + chunk, T)) for i in range(0, T, chunk)]
         sched = packer.Schedule(packed, row_lists, dev)
         for k, rows in enumerate(row_lists):
+            if shared and k % self.dist.world != self.dist.rank:
+                continue
             mb, _ = sched.minibatch(k)
             lo, hi = int(rows[0]), int(rows[-1]) + 1
             engine.forward(packed, mb, self.flat, values[lo:hi], logp[lo:hi], ent[lo:hi], keep=False)
+        if shared:
+            self.dist.all_reduce_sum(values)
+            self.dist.all_reduce_sum(logp)
         adv = torch.empty(T, device=dev)
         ret = torch.empty(T, device=dev)
         engine.gae(rewards, masks, values, self.gamma, self.tau, adv, ret)
@@ -179,34 +239,51 @@ class PPOUpdater:
 
     def make_epoch(self, it):
         """Next epoch's schedule: numpy-global-RNG shuffle composed onto the running order (:306-319)."""
-        T, B, dev = it.T, self.mini_batch_size, self.engine.device
+        T, dev, d = it.T, self.engine.device, self.dist
         perm = np.arange(T)
         np.random.shuffle(perm)
         it.order = it.order[perm]
-        stage_np = it.packed.meta[:, packer.M_STAGE]
+        meta = it.packed.meta
+        stage_np = meta[:, packer.M_STAGE]
         if self.batch_stage:
             st = stage_np[it.order]
             it.order = np.concatenate([it.order[st == 0], it.order[st == 1]])
-        nb = int(math.floor(T / B))
-        row_lists = [it.order[i * B:(i + 1) * B] for i in range(nb)]
-        if self.sub_batches > 1:      # schedule items 2k, 2k+1 = the two halves of minibatch k
-            h = B // self.sub_batches
-            sched = packer.Schedule(it.packed, [r[j * h:(j + 1) * h] for r in row_lists for j in range(self.sub_batches)], dev)
+        count = lambda rows: [len(rows), int((it.exps_np[rows] != 0).sum()), int((stage_np[rows] == 0).sum()),
+                              int((stage_np[rows] == 1).sum())]
+        if self._mode == 'global':
+            if not d.same_everywhere([order_fingerprint(it.order)], dev):
+                raise RuntimeError("dp_mode='global': the ranks drew different permutations -- seed numpy's global RNG "
+                                   'identically on every rank (np.random.seed) before update_params')
+            B = self.mini_batch_size
+            nb = int(math.floor(T / B))
+            glob = [it.order[i * B:(i + 1) * B] for i in range(nb)]
+            row_lists = [split_minibatch(g, meta[g, packer.M_E], d.rank, d.world, self.dp_balance) for g in glob]
+            counts = [list(c) for c in zip(*[count(g) for g in glob])] if nb else [[], [], [], []]
         else:
-            sched = packer.Schedule(it.packed, row_lists, dev)
-        # per-minibatch global counts (rows, rows with exps != 0, land-use rows, road rows): known on the
-        # host, exchanged with ONE tiny all-reduce per epoch when data-parallel
-        counts = [[B] * nb, [int((it.exps_np[r] != 0).sum()) for r in row_lists],
-                  [int((stage_np[r] == 0).sum()) for r in row_lists], [int((stage_np[r] == 1).sum()) for r in row_lists]]
-        rows_glob, ind_glob, land_glob, road_glob = global_counts(self.dist, counts, dev)
-        order_dev = torch.from_numpy(np.ascontiguousarray(it.order[:nb * B])).to(dev)
+            B = self.mini_batch_size
+            nb = d.agree_min(int(math.floor(T / B)), dev)       # ranks may hold different numbers of rows
+            row_lists = [it.order[i * B:(i + 1) * B] for i in range(nb)]
+            # per-minibatch global counts (rows, rows with exps != 0, land-use rows, road rows): known on the
+            # host, exchanged with ONE tiny all-reduce per epoch when data-parallel
+            local = [list(c) for c in zip(*[count(r) for r in row_lists])] if nb else [[], [], [], []]
+            counts = global_counts(d, local, dev) if nb else local
+        rows_glob, ind_glob, land_glob, road_glob = counts
+        S = self.sub_batches
+        if S > 1:      # schedule items S*k + j = the j-th part of this rank's rows of minibatch k
+            h = self.local_rows() // S
+            sched = packer.Schedule(it.packed, [r[j * h:(j + 1) * h] for r in row_lists for j in range(S)], dev)
+        else:
+            sched = packer.Schedule(it.packed, row_lists, dev) if nb else None
+        flat_rows = np.concatenate(row_lists) if nb else np.zeros(0, dtype=np.int64)
+        order_dev = torch.from_numpy(np.ascontiguousarray(flat_rows)).to(dev)
         return Epoch(sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob)
 
     # ------------------------------------------------------------------ one optimizer step
     def step(self, it, ep, k, loss_out=None):
         """forward + loss + backward (+ all-reduce) + first-step clip + Adam on minibatch k of the epoch.
         Everything is enqueued on the current stream; nothing synchronises with the host."""
-        engine, B = self.engine, self.mini_batch_size
+        engine, B = self.engine, self.local_rows()
+        dev = engine.device
         value_b, logp_b, ent_b, dvalue, dlogp, dent = self._rows
         nflt = engine.n_floats
         inv_rows = 1.0 / ep.rows_glob[k]
@@ -222,7 +299,7 @@ class PPOUpdater:
             engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
         else:
             S, h = self.sub_batches, B // self.sub_batches
-            main = torch.cuda.current_stream()
+            main = torch.cuda.current_stream(dev)
             ready = main.record_event()
             for j in range(S):
                 st = self._streams[j]
@@ -248,9 +325,12 @@ class PPOUpdater:
         if self.clip_pending:
             engine.clip_first_step(self.grads, self.max_grad_norm, self.scratch)
             self.clip_pending = False
-        active = (True, ep.land_glob[k] > 0, ep.road_glob[k] > 0)
+        has_rows = (True, ep.land_glob[k] > 0, ep.road_glob[k] > 0)
         for g in range(3):
-            if active[g]:
+            # torch >= 2.0: a head without rows has grad None and Adam skips it; legacy_zero_grad (torch <= 1.13): once
+            # a head has had a gradient it keeps stepping with g = 0
+            if has_rows[g] or (self.legacy_zero_grad and self._group_seen[g]):
+                self._group_seen[g] = True
                 self.group_steps[g] += 1
                 engine.adam_step(g, self.flat, self.grads, self.m, self.v, self.group_steps[g], self.lr,
                                  self.betas[0], self.betas[1], self.eps, self.weight_decay)
@@ -264,8 +344,8 @@ class PPOUpdater:
         self.value_net.train(True)
         it = self.prepare(batch)
         t_loop = time.time()
-        nb = int(math.floor(it.T / self.mini_batch_size))
-        steps_total = self.num_optim_epoch * nb if max_steps is None else min(max_steps, self.num_optim_epoch * nb)
+        cap = self.num_optim_epoch * int(math.floor(it.T / self.mini_batch_size))      # upper bound on the steps
+        steps_total = cap if max_steps is None else min(max_steps, cap)
         loss_log = torch.zeros(max(steps_total, 1), 4, device=dev)
         step = 0
         epoch_ranges = []
@@ -305,7 +385,7 @@ class PPOUpdater:
         self.loss_iter += step
         self.last_losses = losses
         self.last_timing = dict(prepare=t_loop - t0, loop=t_end - t_loop, total=t_end - t0, steps=step,
-                                rows_per_step=self.mini_batch_size * self.dist.world)
+                                rows_per_step=self.global_rows(), dp_mode=self._mode)
         return t_end - t0
 
 
@@ -323,12 +403,18 @@ class HipUpdateMixin:
         up = getattr(self, '_upamd_updater', None)
         if up is None:
             pg = self.optimizer.param_groups[0]
+            dev = next(self.policy_net.parameters()).device
+            # under torchrun (WORLD_SIZE > 1) the update is data-parallel: one process per GPU, gradients all-reduced
+            # over RCCL; UPAMD_DP_MODE = auto | global | local (dist.py), UPAMD_DIST_BACKEND overrides the backend
+            ctx = getattr(self, 'dist_ctx', None) or DistContext.from_env(device=dev if dev.type == 'cuda' else None)
+            specs = getattr(getattr(self, 'cfg', None), 'agent_specs', None) or {}
             up = PPOUpdater(self.policy_net, self.value_net, lr=pg['lr'], eps=pg['eps'],
                             weight_decay=pg['weight_decay'], betas=tuple(pg['betas']), gamma=self.gamma, tau=self.tau,
                             clip_epsilon=self.clip_epsilon, value_pred_coef=self.value_pred_coef,
                             entropy_coef=self.entropy_coef, num_optim_epoch=self.opt_num_epochs,
-                            mini_batch_size=self.mini_batch_size,
-                            batch_stage=bool(self.cfg.agent_specs.get('batch_stage', False)))
+                            mini_batch_size=self.mini_batch_size, batch_stage=bool(specs.get('batch_stage', False)),
+                            dist_ctx=ctx, dp_mode=os.environ.get('UPAMD_DP_MODE', 'auto'),
+                            legacy_zero_grad=os.environ.get('UPAMD_LEGACY_ZERO_GRAD', '0') == '1')
             up.loss_iter = self.loss_iter
             self._upamd_updater = up
         return up

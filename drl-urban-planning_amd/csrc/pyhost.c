@@ -5,7 +5,7 @@
  * walks the list through the buffer protocol in C instead.  It is glue, not part of the hot path: packer.py falls
  * back to the Python loop when the module is missing, and the C ABI of libupamd.so does not depend on it.
  *
- *   addr_table(states, ptrs: uint64[9, T], pad_n: int32[T], pad_e: int32[T], node_dim) -> int
+ *   addr_table(states, ptrs: uint64[9, T], pad_n: int32[T], pad_e: int32[T], node_dim, numerical_dim) -> int
  *
  * fills the tables for every state whose 9 fields are C-contiguous buffers of the wire dtypes
  * (urban_planning/envs/observation_extractor.py:207-228: f32, f32, i64, f32, bool x4, f32) and returns -1; at the
@@ -29,9 +29,9 @@ static int format_ok(const char *fmt, int field) {
 
 static PyObject *addr_table(PyObject *self, PyObject *args) {
     PyObject *states, *ptrs_o, *padn_o, *pade_o;
-    int node_dim;
+    int node_dim, numerical_dim;
     (void)self;
-    if (!PyArg_ParseTuple(args, "OOOOi", &states, &ptrs_o, &padn_o, &pade_o, &node_dim)) return NULL;
+    if (!PyArg_ParseTuple(args, "OOOOii", &states, &ptrs_o, &padn_o, &pade_o, &node_dim, &numerical_dim)) return NULL;
     PyObject *seq = PySequence_Fast(states, "states must be a sequence");
     if (!seq) return NULL;
     const Py_ssize_t T = PySequence_Fast_GET_SIZE(seq);
@@ -65,6 +65,11 @@ static PyObject *addr_table(PyObject *self, PyObject *args) {
                 const Py_ssize_t rows = v.shape[0];
                 if (f == 1) { n_rows = rows; ok = v.ndim == 2 && v.shape[1] == node_dim; }
                 else if (f == 2) { e_rows = rows; ok = v.ndim == 2 && v.shape[1] == 2; }
+                /* the C packer copies numerical_dim / node_dim / 3 floats out of these three: a short array would be
+                 * an out-of-bounds host read, so anything else goes to the validating slow path (which raises) */
+                else if (f == 0) ok = v.len / v.itemsize == numerical_dim;
+                else if (f == 3) ok = v.len / v.itemsize == node_dim;
+                else if (f == 8) ok = v.len / v.itemsize == 3;
                 else if (f == 4 || f == 7) ok = rows == n_rows;
                 else if (f == 5 || f == 6) ok = rows == e_rows;
             }

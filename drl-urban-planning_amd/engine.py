@@ -14,8 +14,9 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device):
+    """The caller's current HIP stream ON THE ENGINE'S DEVICE (not on the process's current device)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class NativeEngine:
@@ -33,6 +34,14 @@ class NativeEngine:
         self.table, self.n_floats, self.groups = native.param_table(desc)
         self.index = {name: (off, rows, cols, grp) for name, off, rows, cols, grp in self.table}
         self.ws_slots = {}        # scratch workspaces; slot > 0 = concurrent sub-batches on side streams
+
+    def _st(self):
+        return _stream(self.device)
+
+    def _on_device(self):
+        """Native launches go to the device that is current in the calling thread (the library never calls
+        hipSetDevice): make the engine's device current around every call."""
+        return torch.cuda.device(self.device)
 
     def __del__(self):
         try:
@@ -65,48 +74,70 @@ class NativeEngine:
                 else flat[off:off + rows] for name, off, rows, cols, _ in self.table}
 
     # ---- workspace
+    # The engine keeps every activation the backward needs in ONE caller-owned workspace buffer.  Two kinds:
+    #   * slots (``slot=k``): engine-owned, reused by every call on that slot -- the PPO update loop (forward and
+    #     backward of the same minibatch are always adjacent there) and no-grad forwards;
+    #   * private (``ws=<tensor from alloc_workspace>``): owned by ONE forward/backward pair of the autograd surface
+    #     (models._Runner), so interleaved forwards can never clobber activations a pending backward still needs.
     @property
     def ws(self):
         return self.ws_slots.get(0)
 
-    def ensure_workspace(self, mb, slot=0):
+    def workspace_bytes(self, mb):
         need = C.c_int64()
         native.check(self.lib.upamd_workspace_bytes(self.handle, C.byref(mb), 1, C.byref(need)), 'upamd_workspace_bytes')
+        return int(need.value)
+
+    def alloc_workspace(self, mb):
+        """A private workspace for one forward/backward pair (exact size + alignment slack)."""
+        return torch.empty(self.workspace_bytes(mb) + 512, dtype=torch.uint8, device=self.device)
+
+    def ensure_workspace(self, mb, slot=0):
+        need = self.workspace_bytes(mb)
         ws = self.ws_slots.get(slot)
-        if ws is None or ws.numel() < need.value:
+        if ws is None or ws.numel() < need + 256:
             self.ws_slots[slot] = None
-            ws = torch.empty(int(need.value * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+            ws = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=self.device)
             self.ws_slots[slot] = ws
         return ws
 
-    def _ws_args(self, slot=0):
-        ws = self.ws_slots[slot]
+    def _ws_args(self, slot=0, ws=None):
+        ws = self.ws_slots[slot] if ws is None else ws
         base = ws.data_ptr()
         aligned = (base + 255) // 256 * 256
         return C.c_void_p(aligned), C.c_int64(ws.numel() - (aligned - base)), aligned - base
 
     # ---- forward / backward
-    def forward(self, packed, mb, flat_params, value, logp, ent, keep=True, slot=0):
-        self.ensure_workspace(mb, slot)
-        wsp, wsb, _ = self._ws_args(slot)
-        native.check(self.lib.upamd_forward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
-                                            _ptr(flat_params), wsp, wsb, _ptr(value), _ptr(logp), _ptr(ent),
-                                            1 if keep else 0, _stream()), 'upamd_forward')
+    def forward(self, packed, mb, flat_params, value, logp, ent, keep=True, slot=0, ws=None):
+        """keep=False: a no-grad forward; it runs in the scratch slot 'nograd' unless a workspace is named, so it never
+        overwrites activations that a backward on slot 0 (or on a private workspace) still needs."""
+        if ws is None:
+            if not keep and slot == 0:
+                slot = 'nograd'
+            self.ensure_workspace(mb, slot)
+        wsp, wsb, _ = self._ws_args(slot, ws)
+        with self._on_device():
+            native.check(self.lib.upamd_forward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
+                                                _ptr(flat_params), wsp, wsb, _ptr(value), _ptr(logp), _ptr(ent),
+                                                1 if keep else 0, self._st()), 'upamd_forward')
+        self.last_forward_slot = slot if ws is None else None
 
-    def backward(self, packed, mb, flat_params, dvalue, dlogp, dent, grads, slot=0):
-        wsp, wsb, _ = self._ws_args(slot)
-        native.check(self.lib.upamd_backward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
-                                             _ptr(flat_params), wsp, wsb, _ptr(dvalue), _ptr(dlogp), _ptr(dent),
-                                             _ptr(grads), _stream()), 'upamd_backward')
+    def backward(self, packed, mb, flat_params, dvalue, dlogp, dent, grads, slot=0, ws=None):
+        wsp, wsb, _ = self._ws_args(slot, ws)
+        with self._on_device():
+            native.check(self.lib.upamd_backward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
+                                                 _ptr(flat_params), wsp, wsb, _ptr(dvalue), _ptr(dlogp), _ptr(dent),
+                                                 _ptr(grads), self._st()), 'upamd_backward')
 
-    def ws_tensor(self, mb, name):
-        """Row-major copy of a named intermediate (parity tests)."""
+    def ws_tensor(self, mb, name, slot=0, ws=None):
+        """Row-major copy of a named intermediate of the last forward on that workspace (parity tests, action heads)."""
         off, rows, cols, kind = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         native.check(self.lib.upamd_ws_tensor(self.handle, C.byref(mb), name.encode(), C.byref(off), C.byref(rows),
                                               C.byref(cols), C.byref(kind)), 'upamd_ws_tensor')
-        _, _, shift = self._ws_args()
+        _, _, shift = self._ws_args(slot, ws)
+        buf = self.ws_slots[slot] if ws is None else ws
         n = rows.value * cols.value
-        raw = self.ws[shift + off.value: shift + off.value + 4 * n].view(torch.float32)
+        raw = buf[shift + off.value: shift + off.value + 4 * n].view(torch.float32)
         if kind.value == 1:
             return raw.view(cols.value // 16, rows.value, 16).permute(1, 0, 2).reshape(rows.value, cols.value).clone()
         return raw.view(rows.value, cols.value).clone()
@@ -114,23 +145,28 @@ class NativeEngine:
     # ---- PPO math
     def ppo_loss(self, B, value, logp, ent, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind, dvalue,
                  dlogp, dent, losses):
-        native.check(self.lib.upamd_ppo_loss(B, _ptr(value), _ptr(logp), _ptr(ent), _ptr(adv), _ptr(ret), _ptr(old_logp),
-                                             _ptr(exps), clip_eps, cv, ce, inv_rows, inv_ind, _ptr(dvalue), _ptr(dlogp),
-                                             _ptr(dent), _ptr(losses), _stream()), 'upamd_ppo_loss')
+        with self._on_device():
+            native.check(self.lib.upamd_ppo_loss(B, _ptr(value), _ptr(logp), _ptr(ent), _ptr(adv), _ptr(ret),
+                                                 _ptr(old_logp), _ptr(exps), clip_eps, cv, ce, inv_rows, inv_ind,
+                                                 _ptr(dvalue), _ptr(dlogp), _ptr(dent), _ptr(losses), self._st()),
+                         'upamd_ppo_loss')
 
     def gae(self, rewards, masks, values, gamma, tau, adv, ret):
-        native.check(self.lib.upamd_gae(rewards.numel(), _ptr(rewards), _ptr(masks), _ptr(values), float(gamma),
-                                        float(tau), _ptr(adv), _ptr(ret), _stream()), 'upamd_gae')
+        with self._on_device():
+            native.check(self.lib.upamd_gae(rewards.numel(), _ptr(rewards), _ptr(masks), _ptr(values), float(gamma),
+                                            float(tau), _ptr(adv), _ptr(ret), self._st()), 'upamd_gae')
 
     def clip_first_step(self, grads, max_norm, scratch):
-        native.check(self.lib.upamd_clip_first_step(C.byref(self.desc), _ptr(grads), float(max_norm), _ptr(scratch),
-                                                    _stream()), 'upamd_clip_first_step')
+        with self._on_device():
+            native.check(self.lib.upamd_clip_first_step(C.byref(self.desc), _ptr(grads), float(max_norm), _ptr(scratch),
+                                                        self._st()), 'upamd_clip_first_step')
 
     def adam_step(self, group, params, grads, m, v, step, lr, beta1, beta2, eps, weight_decay):
         b, e = self.groups[group]
-        native.check(self.lib.upamd_adam_step(b, e, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), int(step), float(lr),
-                                              float(beta1), float(beta2), float(eps), float(weight_decay), _stream()),
-                     'upamd_adam_step')
+        with self._on_device():
+            native.check(self.lib.upamd_adam_step(b, e, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), int(step),
+                                                  float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                                  self._st()), 'upamd_adam_step')
 
     # ---- profiling
     def profile(self, on):

@@ -139,27 +139,47 @@ class _HipNetwork(torch.autograd.Function):
 
 
 class _Runner:
-    """One packed batch bound to an engine (forward keeps the activations for backward)."""
+    """One packed batch bound to an engine.  A runner that will be differentiated owns a PRIVATE workspace: the
+    activations of its forward stay intact until its own backward has run, whatever else is evaluated in between
+    (``value_net(x1)``, then ``get_log_prob_entropy(x2, a)``, then ``loss.backward()`` -- or a no-grad
+    ``select_action`` between a forward and its backward).  No-grad runners use the engine's scratch slot."""
 
-    def __init__(self, engine, packed, sched):
+    def __init__(self, engine, packed, sched, need_grad):
         self.engine, self.packed, self.sched = engine, packed, sched
         self.mb, self.item = sched.minibatch(0)
+        self.need_grad = need_grad
+        self.ws = engine.alloc_workspace(self.mb) if need_grad else None
+        self.slot = 0 if need_grad else 'nograd'
+        self.backward_done = False
 
     def run_forward(self, flat_params):
         B, dev = self.mb.B, self.engine.device
         value = torch.empty(B, device=dev)
         logp = torch.empty(B, device=dev)
         ent = torch.empty(B, device=dev)
-        self.engine.forward(self.packed, self.mb, flat_params.contiguous(), value, logp, ent, keep=True)
+        self.engine.forward(self.packed, self.mb, flat_params.contiguous(), value, logp, ent, keep=self.need_grad,
+                            ws=self.ws)
         return value, logp, ent
 
+    def tensor(self, name):
+        """Named intermediate of this runner's forward (candidate logits for the action heads)."""
+        return self.engine.ws_tensor(self.mb, name, slot=self.slot, ws=self.ws)
+
     def run_backward(self, flat_params, dvalue, dlogp, dent):
+        if self.ws is None:
+            raise RuntimeError('backward through a forward that ran without gradient tracking (its activations were '
+                               'not kept)')
+        if self.backward_done:
+            raise RuntimeError('this forward has already been differentiated once; the native backward consumes the '
+                               'kept activations (retain_graph is not supported on the HIP path)')
         B, dev = self.mb.B, self.engine.device
         z = torch.zeros(B, device=dev)
         grads = torch.zeros_like(flat_params)
         self.engine.backward(self.packed, self.mb, flat_params.contiguous(),
                              z if dvalue is None else dvalue.contiguous(), z if dlogp is None else dlogp.contiguous(),
-                             z if dent is None else dent.contiguous(), grads)
+                             z if dent is None else dent.contiguous(), grads, ws=self.ws)
+        self.backward_done = True
+        self.ws = None                 # released (stream-ordered: the caching allocator reuses it after the backward)
         return grads
 
 
@@ -212,7 +232,8 @@ class _HipBackend:
         """x: list[B] of list[9] tensors on any device.  Returns (value, logp, ent) f32[B] on the GPU."""
         device = next(self.shared_net.parameters()).device
         engine = self.engine(device)
-        states = [[f.detach().cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in s] for s in x]
+        states = [s if packer.is_record(s) else
+                  [f.detach().cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in s] for s in x]
         B = len(states)
         if action is None:
             act = np.zeros((B, 2), dtype=np.float32)
@@ -221,10 +242,52 @@ class _HipBackend:
         pk = packer.pack_replay(states, act, self.shared_net.agent.node_dim,
                                 self.shared_net.agent.numerical_feature_size).to(device)
         sched = packer.Schedule(pk, [np.arange(B)], device)
-        runner = _Runner(engine, pk, sched)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.named_params().values())
+        runner = _Runner(engine, pk, sched, need_grad)
         flat = self.flat_params_autograd(engine)
         value, logp, ent = _HipNetwork.apply(flat, runner)
         return value, logp, ent, runner
+
+    def pointer_logits(self, x):
+        """The two pointer heads of a batch as the reference lays them out (policy.py:45-65): logits over the PADDED
+        edge / node slots of the rows in that stage, masked slots = the pad constant.  Forward only (the differentiable
+        route to log-prob / entropy is ``get_log_prob_entropy``).  Returns (land_logits | None, road_logits | None,
+        stage f32[B, 3]) on the networks' device."""
+        device = next(self.shared_net.parameters()).device
+        with torch.no_grad():
+            _, _, _, runner = self.run(x, None)
+            pk, mb, meta = runner.packed, runner.mb, runner.packed.meta
+            B = mb.B
+            stage_id = meta[:B, packer.M_STAGE]
+            out = []
+            for sid, zname, cnt_col, slot_name, slot_dt, pad_col, total in (
+                    (0, 'z_he', packer.M_NH, 'he_slot', np.int32, packer.M_PADE, int(pk.layout.total_he)),
+                    (1, 'z_rn', packer.M_NR, 'rn_node', np.uint16, packer.M_PADN, int(pk.layout.total_rn))):
+                rows = np.flatnonzero(stage_id == sid)
+                if rows.size == 0:
+                    out.append(None)
+                    continue
+                width = meta[rows, pad_col]
+                if (width != width[0]).any():
+                    raise ValueError('forward(): the rows of one stage must share their pad size to form one '
+                                     'Categorical (got %s); use select_action / get_log_prob_entropy for ragged '
+                                     'batches' % sorted(set(width.tolist())))
+                logits = torch.full((rows.size, int(width[0])), _PAD_LOGIT, dtype=torch.float32, device=device)
+                cnt = meta[:B, cnt_col].astype(np.int64)
+                off = np.concatenate([[0], np.cumsum(cnt)])           # candidate offsets in minibatch (= pack) order
+                if cnt[rows].sum() > 0:
+                    slots = pk.section(slot_name, slot_dt, max(total, 1)).astype(np.int64)
+                    src = np.concatenate([np.arange(off[b], off[b + 1]) for b in rows])
+                    dst_row = np.repeat(np.arange(rows.size), cnt[rows])
+                    z = runner.tensor(zname).reshape(-1)
+                    logits[torch.from_numpy(dst_row).to(device), torch.from_numpy(slots[src]).to(device)] = \
+                        z[torch.from_numpy(src).to(device)]
+                out.append(logits)
+            stage = np.zeros((B, 3), dtype=np.float32)
+            for b, s in enumerate(x):
+                st = packer.expand_state(s)[8] if packer.is_record(s) else s[8]
+                stage[b] = st.detach().cpu().numpy() if isinstance(st, torch.Tensor) else np.asarray(st)
+        return out[0], out[1], torch.from_numpy(stage).to(device)
 
 
 def _on_gpu(module):
@@ -250,12 +313,15 @@ class UrbanPlanningPolicy(nn.Module):
         return _mlp(input_size, hidden, prefix=name + '_linear_', act_prefix=name + '_tanh_', bias_after_first=False,
                     last_act=False, flatten_last_if_one=True, last_flatten_prefix=name + '_flatten_')
 
-    # ---- CPU (rollout) path
     def forward(self, x):
+        """(land_use_dist | None, road_dist | None, stage) exactly as policy.py:45-65: ``Categorical`` objects over
+        the padded edge / node slots of the rows in each stage.  On the GPU the logits come from the HIP forward
+        (no gradient flows through this route; ``get_log_prob_entropy`` is the differentiable one)."""
         if _on_gpu(self):
-            raise RuntimeError('UrbanPlanningPolicy.forward() returns Categorical objects over padded rows and is '
-                               'only available on the CPU rollout path; on the GPU call select_action / '
-                               'get_log_prob_entropy (HIP path).')
+            land, road, stage = self._backend[0].pointer_logits(x)
+            land_dist = None if land is None else torch.distributions.Categorical(logits=land)
+            road_dist = None if road is None else torch.distributions.Categorical(logits=road)
+            return land_dist, road_dist, stage
         s_land, s_road, _, land_mask, road_mask, stage = self.shared_net(x)
         land_dist = road_dist = None
         is_land, is_road = stage[:, 0].bool(), stage[:, 1].bool()
@@ -270,8 +336,8 @@ class UrbanPlanningPolicy(nn.Module):
         return land_dist, road_dist, stage
 
     def select_action(self, x, mean_action=False):
-        if _on_gpu(self):
-            return self._select_action_gpu(x, mean_action)
+        """policy.py:67-85 on either device: ``Categorical.sample`` (torch's generator of that device) or arg-max,
+        written into column 0 / 1 of the rows in the land-use / road stage."""
         land_dist, road_dist, stage = self.forward(x)
         action = torch.zeros(stage.shape[0], 2, dtype=self.agent.dtype, device=stage.device)
         for col, dist in ((0, land_dist), (1, road_dist)):
@@ -279,29 +345,6 @@ class UrbanPlanningPolicy(nn.Module):
                 a = dist.probs.argmax(dim=1) if mean_action else dist.sample()
                 action[stage[:, col].bool(), col] = a.to(self.agent.dtype)
         return action
-
-    def _select_action_gpu(self, x, mean_action):
-        backend = self._backend[0]
-        with torch.no_grad():
-            _, _, _, runner = backend.run(x, None)
-            eng, mb, meta = runner.engine, runner.mb, runner.packed.meta
-            p_he = eng.ws_tensor(mb, 'p_he').reshape(-1).cpu()
-            p_rn = eng.ws_tensor(mb, 'p_rn').reshape(-1).cpu()
-            he_slot = runner.packed.section('he_slot', np.int32, max(int(runner.packed.layout.total_he), 1))
-            rn_node = runner.packed.section('rn_node', np.uint16, max(int(runner.packed.layout.total_rn), 1))
-        B = mb.B
-        action = torch.zeros(B, 2, dtype=self.agent.dtype)
-        for b in range(B):
-            st, cnt_h, cnt_r = int(meta[b, 4]), int(meta[b, 2]), int(meta[b, 3])
-            if st == 0 and cnt_h > 0:
-                p = p_he[int(meta[b, 11]):int(meta[b, 11]) + cnt_h]
-                k = int(p.argmax()) if mean_action else int(torch.multinomial(p, 1))
-                action[b, 0] = float(he_slot[int(meta[b, 11]) + k])
-            elif st == 1 and cnt_r > 0:
-                p = p_rn[int(meta[b, 12]):int(meta[b, 12]) + cnt_r]
-                k = int(p.argmax()) if mean_action else int(torch.multinomial(p, 1))
-                action[b, 1] = float(rn_node[int(meta[b, 12]) + k])
-        return action.to(next(self.parameters()).device)
 
     def get_log_prob_entropy(self, x, action):
         if _on_gpu(self):

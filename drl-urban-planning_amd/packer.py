@@ -180,17 +180,22 @@ def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     helper = _host_helper()
     if helper is not None:
         # fast path: every state whose fields already are C-contiguous arrays of the wire dtypes is handled in C
-        bad = helper.addr_table(states, ptrs, pad_n, pad_e, int(node_dim))
+        try:
+            bad = helper.addr_table(states, ptrs, pad_n, pad_e, int(node_dim), int(numerical_dim))
+        except TypeError:                         # a stale _upamd_host.so with the older signature: glue only, skip it
+            bad = 0
         first_slow = T if bad < 0 else 0          # anything unusual: redo the whole table the slow, validating way
     for t, s in enumerate(states if first_slow < T else ()):
         if len(s) != 9:
             raise ValueError('state %d has %d fields, expected 9' % (t, len(s)))
+        sizes = [0] * 9
         for f in range(9):
             a = s[f]
             if not (isinstance(a, np.ndarray) and a.dtype == _FIELD_DTYPES[f] and a.flags['C_CONTIGUOUS']):
                 a = _as_array(a, _FIELD_DTYPES[f])
                 keep.append(a)
             ptrs[f, t] = a.__array_interface__['data'][0]
+            sizes[f] = a.size
         nf, ei = s[1], s[2]
         pad_n[t] = nf.shape[0]
         pad_e[t] = ei.shape[0]
@@ -198,6 +203,10 @@ def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
             raise ValueError('state %d: node feature width %d != node_dim %d' % (t, nf.shape[-1], node_dim))
         if len(s[4]) != pad_n[t] or len(s[7]) != pad_n[t] or len(s[5]) != pad_e[t] or len(s[6]) != pad_e[t]:
             raise ValueError('state %d: mask lengths do not match the padded node/edge counts' % t)
+        # the C packer copies exactly numerical_dim / node_dim / 3 floats out of these three fields
+        if sizes[0] != numerical_dim or sizes[3] != node_dim or sizes[8] != 3:
+            raise ValueError('state %d: numerical / current-node / stage fields have %d / %d / %d entries, expected '
+                             '%d / %d / 3' % (t, sizes[0], sizes[3], sizes[8], numerical_dim, node_dim))
     actions = _as_array(np.asarray(actions).reshape(T, 2), np.float32)
     meta = np.zeros((T, native.META_STRIDE), dtype=np.int32)
     layout = native.PackLayout()

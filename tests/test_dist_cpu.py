@@ -95,3 +95,66 @@ def test_shard_rows_and_single_rank_counts():
     with pytest.raises(ValueError):
         shard_rows(list(range(7)), 0, 2)
     assert global_counts(DistContext(), [[3, 4], [1, 2]], 'cpu') == [[3, 4], [1, 2]]
+
+
+def test_split_minibatch_is_a_partition_and_balances_edge_counts():
+    """Every rank takes B / G rows of the global minibatch; the union is the minibatch; with balance='edges' the ranks'
+    edge totals differ by far less than with contiguous slices on a mixed (bimodal) minibatch."""
+    from drl_urban_planning_amd.dist import split_minibatch
+    rng = np.random.default_rng(0)
+    B, G = 2048, 8
+    rows = rng.permutation(50000)[:B]
+    e = np.where(rng.random(B) < 0.5, rng.integers(1150, 1920, B), rng.integers(1320, 2216, B))     # HLG / DHM mix
+    for balance in ('none', 'edges'):
+        parts = [split_minibatch(rows, e, r, G, balance) for r in range(G)]
+        assert all(p.size == B // G for p in parts)
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.sort(rows))
+        pos = {int(v): i for i, v in enumerate(rows)}
+        for p in parts:            # rows keep the order they have in the global minibatch
+            assert all(pos[int(a)] < pos[int(b)] for a, b in zip(p[:-1], p[1:]))
+    lookup = dict(zip(rows.tolist(), e.tolist()))
+    tot = lambda bal: np.array([sum(lookup[int(v)] for v in split_minibatch(rows, e, r, G, bal)) for r in range(G)])
+    spread_none, spread_edges = np.ptp(tot('none')) / tot('none').mean(), np.ptp(tot('edges')) / tot('edges').mean()
+    assert spread_edges < 0.002 and spread_edges < spread_none / 5, (spread_none, spread_edges)
+    assert np.array_equal(split_minibatch(rows, e, 0, 1), rows)
+    with pytest.raises(ValueError):
+        split_minibatch(rows[:7], e[:7], 0, 2)
+
+
+def _agree_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from drl_urban_planning_amd import packer, synth
+    from drl_urban_planning_amd.dist import DistContext, batch_fingerprint, broadcast_batch, order_fingerprint
+    ctx = DistContext.from_env(backend='gloo')
+    assert ctx.backend == 'gloo'
+    assert ctx.agree_min(5 + rank) == 5
+    assert ctx.same_everywhere([3, 2 ** 40 + 1]) and not ctx.same_everywhere([rank])
+    np.random.seed(123)
+    perm = np.random.permutation(1000)
+    assert ctx.same_everywhere([order_fingerprint(perm)])
+    np.random.seed(123 + rank)
+    assert not ctx.same_everywhere([order_fingerprint(np.random.permutation(1000))])
+    # rank 0's batch reaches rank 1 as compact records and packs to the same bytes
+    rep = synth.make_replay(6, 'hlg', max_nodes=60, max_edges=200, seed=5, n_range=(20, 50)) if rank == 0 else None
+    got = broadcast_batch(ctx, rep, src=0)
+    ref = synth.make_replay(6, 'hlg', max_nodes=60, max_edges=200, seed=5, n_range=(20, 50))
+    assert batch_fingerprint(got) == batch_fingerprint(ref)
+    if rank == 1:
+        assert all(packer.is_record(s) for s in got.states)
+        for s, r in zip(got.states, ref.states):
+            for a, b in zip(packer.expand_state(s, padded=True), r):
+                assert np.array_equal(a, b)
+        pk = packer.pack_replay(got.states, got.actions, 23, 52, pin=False)
+        pk0 = packer.pack_replay(ref.states, ref.actions, 23, 52, pin=False)
+        # same live content; the pad-size columns differ (records are trimmed to the last used row)
+        cols = [c for c in range(13) if c not in (packer.M_PADN, packer.M_PADE)]
+        assert np.array_equal(pk.meta[:, cols], pk0.meta[:, cols])
+        np.save(os.path.join(out_dir, 'ok.npy'), np.ones(1))
+    ctx.barrier()
+    ctx.close()
+
+
+def test_two_rank_agreements_and_batch_broadcast(tmp_path):
+    port = _free_port()
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), 'ok.npy'))

@@ -81,6 +81,16 @@ def test_packer_rejects_bad_input():
         packer.pack_replay(replay.states, replay.actions, synth.NODE_DIM, synth.NUMERICAL_DIM, pin=False)
 
 
+@pytest.mark.parametrize('field,new_len', [(0, 40), (3, 20), (8, 2)])
+def test_packer_rejects_short_fixed_width_fields(field, new_len):
+    """numerical / current-node / stage are copied with fixed widths by the C packer: a shorter array (config / state
+    mismatch) must raise instead of reading past the buffer -- on the C fast path and on the Python path alike."""
+    replay = cases.quirky_replay(4, 20, 40, seed=1, full_row=False)
+    replay.states[2][field] = np.ascontiguousarray(replay.states[2][field][:new_len])
+    with pytest.raises(ValueError, match='state 2'):
+        packer.pack_replay(replay.states, replay.actions, synth.NODE_DIM, synth.NUMERICAL_DIM, pin=False)
+
+
 def test_action_outside_candidates_maps_to_minus_one():
     replay = cases.quirky_replay(6, 20, 40, seed=2, road_fraction=0.0, full_row=False)
     s = replay.states[4]
