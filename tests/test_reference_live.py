@@ -1,0 +1,78 @@
+"""The oracle against the LIVE reference (build container only: skipped wherever /root/reference is absent, e.g. on
+the GPU box).  Two things are pinned here that the committed golden vectors cannot pin:
+
+* the oracle's ``update_params`` reproduces the reference's on a freshly generated replay (not only on the three
+  golden cases), loss by loss;
+* ``bench.py``'s ``cpu_baseline`` times the ORACLE (``kind: "port"``) because the reference cannot travel to the GPU
+  box -- so the port must cost what the reference costs: the wall time of the oracle's update loop has to be within
+  10 % of ``UrbanPlanningAgent.update_params`` (urban_planning_agent.py:248-361) on the same replay, thread count and
+  minibatch schedule.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import ref_import
+from oracle import sgnn_oracle as orc
+
+pytestmark = pytest.mark.skipif(not ref_import.available(), reason='/root/reference is not present')
+
+SPEC = dict(D=32, L=2, heads=1, max_nodes=300, max_edges=900)
+
+
+def _pair(seed=0):
+    """The real reference agent and an oracle updater on identical weights."""
+    ref = ref_import.load_reference()
+    cfg = ref_import.DuckCfg(**SPEC)
+    torch.manual_seed(seed)
+    policy_net, value_net = ref.create_sgnn_model(cfg, ref_import.DuckAgent())
+    ag = ref_import.make_reference_agent(ref, cfg, policy_net, value_net, num_optim_epoch=2, mini_batch_size=32)
+    sd = {k: v.detach().clone() for k, v in ag.actor_critic_net.state_dict().items()}
+    ou = orc.OracleUpdater(helpers.oracle_params(sd), num_optim_epoch=2, mini_batch_size=32, num_heads=SPEC['heads'])
+    return ag, ou
+
+
+def _replay(T=96):
+    from drl_urban_planning_amd import synth
+    return synth.make_replay(T, 'hlg', max_nodes=SPEC['max_nodes'], max_edges=SPEC['max_edges'], seed=13,
+                             road_fraction=0.25, n_range=(120, 280))
+
+
+def test_oracle_update_matches_the_live_reference_on_a_fresh_replay():
+    ag, ou = _pair()
+    replay = _replay()
+    np.random.seed(5)
+    ag.update_params(replay, 0)
+    np.random.seed(5)
+    ou.update_params(replay)
+    ref_losses = np.array([v for (tag, v, s) in ag.tb_logger.scalars if tag == 'loss/loss'])
+    np.testing.assert_allclose(np.array(ou.loss_log)[:, 0], ref_losses, rtol=2e-5, atol=1e-6)
+    flat = orc.split_actor_critic_state_dict(ag.actor_critic_net.state_dict())
+    for k, p in ou.P.items():
+        np.testing.assert_allclose(p.detach().numpy(), flat[k].numpy(), rtol=1e-5, atol=2e-6, err_msg=k)
+
+
+def test_oracle_step_time_is_the_reference_step_time():
+    """min-of-3 wall time of a whole update_params (6 optimizer steps of 32 padded rows + the two no-grad sweeps),
+    interleaved reference / oracle so that machine noise hits both alike."""
+    torch.set_num_threads(min(4, torch.get_num_threads()))
+    replay = _replay()
+    t_ref, t_orc = [], []
+    for rep in range(4):
+        ag, ou = _pair()
+        np.random.seed(5)
+        t0 = time.perf_counter()
+        ag.update_params(replay, 0)
+        t1 = time.perf_counter()
+        np.random.seed(5)
+        ou.update_params(replay)
+        t2 = time.perf_counter()
+        if rep:                               # the first round warms allocators / thread pools
+            t_ref.append(t1 - t0)
+            t_orc.append(t2 - t1)
+    ratio = min(t_orc) / min(t_ref)
+    assert 0.90 <= ratio <= 1.10, 'oracle %.3f s vs reference %.3f s per update_params (ratio %.3f)' % (
+        min(t_orc), min(t_ref), ratio)
