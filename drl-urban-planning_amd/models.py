@@ -166,12 +166,12 @@ class _Runner:
         return self.engine.ws_tensor(self.mb, name, slot=self.slot, ws=self.ws)
 
     def run_backward(self, flat_params, dvalue, dlogp, dent):
-        if self.ws is None:
-            raise RuntimeError('backward through a forward that ran without gradient tracking (its activations were '
-                               'not kept)')
         if self.backward_done:
             raise RuntimeError('this forward has already been differentiated once; the native backward consumes the '
                                'kept activations (retain_graph is not supported on the HIP path)')
+        if self.ws is None:
+            raise RuntimeError('backward through a forward that ran without gradient tracking (its activations were '
+                               'not kept)')
         B, dev = self.mb.B, self.engine.device
         z = torch.zeros(B, device=dev)
         grads = torch.zeros_like(flat_params)
