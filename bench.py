@@ -215,6 +215,9 @@ def main():
     t_gen = time.time() - t_gen
     np.random.seed(seed_np)
     engine = up.attach()
+    if os.environ.get('UPAMD_GEMM_NT_DMA') is not None:          # kernel-lab A/B switch (default: the library's own choice)
+        from drl_urban_planning_amd import native
+        native.check(native.lib().upamd_tune(b'gemm_nt_dma', int(os.environ['UPAMD_GEMM_NT_DMA'])))
     t_prep = time.time()
     it = up.prepare(replay)
     torch.cuda.synchronize(dev)

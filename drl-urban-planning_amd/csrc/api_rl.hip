@@ -1,4 +1,6 @@
 // C-ABI entry points of the PPO minibatch math (loss, GAE, first-step clip, Adam).
+#include <cstring>
+
 #include "kernels.h"
 
 using namespace upamd;
@@ -67,6 +69,35 @@ extern "C" int upamd_gemm_nt(const float *A_dev, int64_t M, int32_t K, int64_t l
     if (!A_dev || !W_dev || !C_dev || M <= 0 || K <= 0 || N <= 0) return fail(UPAMD_E_INVALID, "upamd_gemm_nt: bad argument");
     GemmNT g{A_dev, M, K, lda, a_row_major != 0, W_dev, N, ldw, bias_dev, R_dev, C_dev, ldc, c_row_major != 0, act_tanh, alpha};
     return launch_gemm_nt_ex(g, static_cast<hipStream_t>(stream), nullptr);
+}
+
+// lab hook: one wave samples (shader clock, 100 MHz wall clock) pairs while other streams run kernels; the ratio of the
+// differences is the effective shader clock under that load
+__global__ void clock_probe_kernel(long long *out, int samples, int gap_ticks) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < samples; ++i) {
+        const long long w0 = wall_clock64();
+        out[2 * i] = clock64();
+        out[2 * i + 1] = w0;
+        while (wall_clock64() - w0 < gap_ticks) __builtin_amdgcn_s_sleep(16);
+    }
+}
+
+extern "C" int upamd_clock_probe(void *out_dev, int32_t samples, int32_t gap_ticks, void *stream) {
+    if (!out_dev || samples <= 0) return fail(UPAMD_E_INVALID, "upamd_clock_probe: bad argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<long long *>(out_dev), samples, gap_ticks);
+    UPAMD_HIP(hipGetLastError());
+    return UPAMD_OK;
+}
+
+extern "C" int upamd_tune(const char *name, int32_t value) {
+    if (!name) return fail(UPAMD_E_INVALID, "upamd_tune: name is null");
+    if (!strcmp(name, "gemm_nt_dma")) { set_gemm_nt_dma_variant(value); return UPAMD_OK; }
+    if (!strcmp(name, "gemm_lds_pad")) { set_gemm_lds_pad(value); return UPAMD_OK; }
+    if (!strcmp(name, "gemm_stagger_mode")) { set_gemm_stagger(value, -1); return UPAMD_OK; }
+    if (!strcmp(name, "gemm_stagger_cycles")) { set_gemm_stagger(-1, value); return UPAMD_OK; }
+    return fail(UPAMD_E_INVALID, "upamd_tune: unknown knob '%s'", name);
 }
 
 extern "C" int64_t upamd_gemm_tn_scratch_floats(int32_t I, int32_t J, int64_t M) {

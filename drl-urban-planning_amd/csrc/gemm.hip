@@ -19,6 +19,7 @@
 namespace upamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fast_tanh(float x) {
     // tanh(x) = 1 - 2 / (exp(2x) + 1); v_exp_f32 + v_rcp_f32, abs error ~1e-7, saturates cleanly
@@ -179,6 +180,361 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_mfma_kernel(const float *__res
     }
 }
 
+// ------------------------------------------------------------------------------------------ NT, LDS-DMA staging
+// Same tile decomposition (128 x 128 per workgroup, 64 x 64 per wave, 32x32x2 fp32 MFMA) with the operands staged by
+// the LDS-DMA path (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging VGPRs, no ds_write pass) and read
+// back with ds_read_b128:
+//   * LDS image of one 16-wide K panel of an operand = 128 rows x 4 chunks of 16 B, slot (row, c') holds the row's
+//     logical chunk c = c' ^ ((row >> 2) & 3).  The DMA destination is lane-linear, so the XOR swizzle is applied to the
+//     per-lane SOURCE address (still whole 64-byte row segments per 4 lanes: coalescing is unchanged); a 16-lane
+//     ds_read_b128 group then covers all 64 banks exactly once (rows r..r+3 x 4 row-quads) -- conflict-free.
+//   * a lane reads chunk c = 2g + (lane >> 5) of its row: k = 8g + 4 (lane >> 5) + t, t = 0..3.  MFMA step (g, t)
+//     therefore contracts k = 8g + t (lanes 0-31) and k = 8g + 4 + t (lanes 32-63): any assignment of k to steps is
+//     valid as long as A and B use the same one.  One 16-byte read feeds four MFMA steps of a fragment.
+//   * two LDS stages of BKP panels each, one raw s_barrier per chunk; chunk ks + 1 is issued behind the first panel's
+//     fragment reads of chunk ks (hipcc drains all LDS-DMA before a ds_read that follows one, so deeper rings buy
+//     nothing from HIP source) and lands while chunk ks's 32 * BKP MFMAs run.
+// Only the panel-major A / C, row-major [N][K] weight form (the dominant launches); everything else keeps the
+// register-staged kernel above.
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// Every workgroup of a launch starts at the same instant and the tiles cost the same, so without help the co-resident
+// workgroups of a CU (and of the whole chip) run in lockstep: all of them stream their prologue, then all compute, then
+// all write their C tiles at once -- the HBM-bound epilogue (N = 512: 1.2 GB per launch) is then NOT overlapped with
+// anyone's MFMAs (measured: main loop ~150 TFLOP/s, whole launch ~120).  Delaying the workgroups of the FIRST
+// residency round by (phase / 4) of a tile time de-synchronises them for the rest of the launch: later workgroups start
+// whenever a slot frees up, i.e. already staggered.
+//   mode 1: phase = (block >> 8) & 3 (round-robin placement over 256 CUs), 2: (block >> 3) & 3 (consecutive blocks of an XCD
+//   fill a CU), 3: the wave's hardware slot id (co-resident waves of a SIMD have distinct slots).
+__device__ __forceinline__ void first_wave_stagger(int mode, int cycles) {
+    if (mode == 0) return;
+    int phase;
+    if (mode == 3) {
+        phase = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3;      // HW_REG_HW_ID.WAVE_ID[1:0]
+    } else {
+        if (blockIdx.x >= 1024) return;
+        phase = (mode == 1 ? (blockIdx.x >> 8) : (blockIdx.x >> 3)) & 3;
+    }
+    if (phase == 0) return;
+    const long long t0 = __builtin_readcyclecounter();
+    const long long wait = (long long)phase * cycles;
+    while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BKP, int NSTAGE, int MINW, int MODE = 0>
+__global__ __launch_bounds__(256, MINW) void gemm_nt_dma_kernel(const float *__restrict__ A, int64_t M, int K,
+                                                                const float *__restrict__ W, int N, int64_t ldw,
+                                                                const float *__restrict__ bias,
+                                                                const float *__restrict__ R, float *__restrict__ C,
+                                                                int act_tanh, float alpha, int MT, int NT, int stagger_mode,
+                                                                int stagger_cycles) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int PANEL = 128 * 16;                 // floats of one operand panel (8 KB)
+    constexpr int STAGE = 2 * BKP * PANEL;          // A panels then B panels
+    constexpr int G = 4 * BKP;                      // LDS-DMA instructions per wave and chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // the ONLY LDS object of this kernel
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int mt = (slot / NT) * 8 + xcd, nt = slot % NT;
+    if (mt >= MT) return;
+    first_wave_stagger(stagger_mode & 7, stagger_cycles);
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-lane DMA sources: this wave fills LDS slots [(2w + j) * 64, +64) of every panel, slot q = 4 row + c'
+    const float *asrc[2], *bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (2 * w + j) * 64 + lane, row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+        int64_t gm = m0 + row;
+        if (gm >= M) gm = M - 1;                    // rows past the end: valid address, result never stored
+        asrc[j] = A + gm * 16 + c * 4;
+        bsrc[j] = W + (int64_t)(n0 + row) * ldw + c * 4;
+    }
+    const int64_t a_panel = M * 16;
+    auto issue = [&](int kc, int s) {
+#pragma unroll
+        for (int pp = 0; pp < BKP; ++pp) {
+            const int kp = kc * BKP + pp;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float *la = smem + s * STAGE + pp * PANEL + (2 * w + j) * 256;
+                float *lb = smem + s * STAGE + (BKP + pp) * PANEL + (2 * w + j) * 256;
+                __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + kp * a_panel), (lptr_t)la, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[j] + kp * 16), (lptr_t)lb, 16, 0, 0);
+            }
+        }
+    };
+    // fragment offsets (floats) inside a panel: row * 16 + 4 * ((2g + lhi) ^ ((row >> 2) & 3))
+    int aoff[2][2], boff[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int sw = ((2 * g + lhi) ^ ((l31 >> 2) & 3)) * 4;
+            aoff[i][g] = (wr * 64 + i * 32 + l31) * 16 + sw;
+            boff[i][g] = (wc * 64 + i * 32 + l31) * 16 + sw;
+        }
+
+    const int KS = (K >> 4) / BKP;
+    auto frags = [&](const float *sa, const float *sb, float4 (&a)[2][2], float4 (&b)[2][2]) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[g][i] = *reinterpret_cast<const float4 *>(sa + aoff[i][g]);
+                b[g][i] = *reinterpret_cast<const float4 *>(sb + boff[i][g]);
+            }
+    };
+    auto mfmas = [&](const float4 (&a)[2][2], const float4 (&b)[2][2]) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float av[2] = {t == 0 ? a[g][0].x : t == 1 ? a[g][0].y : t == 2 ? a[g][0].z : a[g][0].w,
+                                     t == 0 ? a[g][1].x : t == 1 ? a[g][1].y : t == 2 ? a[g][1].z : a[g][1].w};
+                const float bv[2] = {t == 0 ? b[g][0].x : t == 1 ? b[g][0].y : t == 2 ? b[g][0].z : b[g][0].w,
+                                     t == 0 ? b[g][1].x : t == 1 ? b[g][1].y : t == 2 ? b[g][1].z : b[g][1].w};
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0);
+            }
+    };
+    if (MODE == 0) {
+        issue(0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+            wait_vmcnt<0>();                            // this wave's part of chunk ks has landed
+            __builtin_amdgcn_s_barrier();               // ... and everyone's; all reads of chunk ks-1 are done
+            const float *st = smem + (ks & 1) * STAGE;
+            // The compiler drains every LDS-DMA (vmcnt(0)) before any ds_read that follows one, so the next chunk is issued
+            // BEHIND the first panel's fragment reads: its flight then overlaps this chunk's MFMAs instead of stalling them.
+            float4 a[2][2], b[2][2];
+            frags(st, st + BKP * PANEL, a, b);
+            if (ks + 1 < KS) issue(ks + 1, (ks + 1) & 1);
+            mfmas(a, b);
+#pragma unroll
+            for (int pp = 1; pp < BKP; ++pp) {
+                frags(st + pp * PANEL, st + (BKP + pp) * PANEL, a, b);
+                mfmas(a, b);
+            }
+        }
+    } else {
+        // Software-pipelined form (BKP == 1).  A wave's own non-MFMA work -- the wait for the next chunk, the barrier, the
+        // fragment reads, the DMA issue -- is placed BETWEEN the two 16-MFMA halves of the current chunk, where it issues
+        // while the matrix pipe is still executing the MFMAs ahead of it; the fragments of chunk k+1 are in registers before
+        // chunk k's last MFMA retires, so the wave's MFMA stream never pauses at a chunk boundary.  (All co-resident waves
+        // of a SIMD advance in lockstep, so a pause in one is a pause in all: the un-pipelined loop leaves the pipe idle
+        // ~20 % of the time at full clock.)
+        static_assert(MODE == 0 || BKP == 1, "the pipelined loop handles one panel per chunk");
+        float4 a0[2], b0[2], a1[2], b1[2];          // fragment sets of the two k-groups (g = 0, 1)
+        auto read_g = [&](const float *st, int g, float4 (&a)[2], float4 (&b)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4 *>(st + aoff[i][g]);
+                b[i] = *reinterpret_cast<const float4 *>(st + PANEL + boff[i][g]);
+            }
+        };
+        auto mfma_g = [&](const float4 (&a)[2], const float4 (&b)[2]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float av[2] = {t == 0 ? a[0].x : t == 1 ? a[0].y : t == 2 ? a[0].z : a[0].w,
+                                     t == 0 ? a[1].x : t == 1 ? a[1].y : t == 2 ? a[1].z : a[1].w};
+                const float bv[2] = {t == 0 ? b[0].x : t == 1 ? b[0].y : t == 2 ? b[0].z : b[0].w,
+                                     t == 0 ? b[1].x : t == 1 ? b[1].y : t == 2 ? b[1].z : b[1].w};
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0);
+            }
+        };
+        if (MODE <= 2) {
+            issue(0, 0);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            read_g(smem, 0, a0, b0);
+            read_g(smem, 1, a1, b1);
+            if (KS > 1) issue(1, 1);
+            for (int ks = 0; ks < KS; ++ks) {
+                const bool more = ks + 1 < KS;
+                const float *nxt = smem + ((ks + 1) & 1) * STAGE;
+                __builtin_amdgcn_sched_barrier(0);
+                if (MODE == 2) __builtin_amdgcn_s_setprio(2);
+                mfma_g(a0, b0);
+                if (MODE == 2) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    // chunk ks+1 was issued one half-iteration ago at least; every wave's reads of chunk ks are complete
+                    // (lgkmcnt(0)) before anyone's DMA of chunk ks+2 may overwrite that stage
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    read_g(nxt, 0, a0, b0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (MODE == 2) __builtin_amdgcn_s_setprio(2);
+                mfma_g(a1, b1);
+                if (MODE == 2) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    read_g(nxt, 1, a1, b1);
+                    if (ks + 2 < KS) issue(ks + 2, ks & 1);
+                }
+            }
+        } else {
+            // MODE 3: the fragment reads are inline asm, so hipcc neither drains the LDS-DMA queue in front of them nor
+            // waits lgkmcnt(0) at the loop header; every wait below is counted by hand (in-order LGKM counter: the four
+            // reads of the g = 1 set are always the youngest outstanding).
+            f32x4 xa0[2], xb0[2], xa1[2], xb1[2];
+            const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+            unsigned oa[2][2], ob[2][2];            // byte addresses inside stage 0
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    oa[i][g] = lds0 + 4u * (unsigned)aoff[i][g];
+                    ob[i][g] = lds0 + 4u * (unsigned)(PANEL + boff[i][g]);
+                }
+            auto rd = [&](f32x4 &dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
+            auto read_set = [&](unsigned stage_bytes, int g, f32x4 (&a)[2], f32x4 (&b)[2]) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    rd(a[i], oa[i][g] + stage_bytes);
+                    rd(b[i], ob[i][g] + stage_bytes);
+                }
+            };
+            auto mfma_x = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][t], a[i][t], acc[i][j], 0, 0, 0);
+            };
+            issue(0, 0);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            read_set(0, 0, xa0, xb0);
+            read_set(0, 1, xa1, xb1);
+            if (KS > 1) issue(1, 1);
+            for (int ks = 0; ks < KS; ++ks) {
+                const bool more = ks + 1 < KS;
+                const unsigned nxt = ((ks + 1) & 1) * (unsigned)(STAGE * 4);
+                // g = 0 set ready (the g = 1 set, 4 younger reads, may still be in flight)
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xa0[0]), "+v"(xa0[1]), "+v"(xb0[0]), "+v"(xb0[1])::"memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (MODE == 4) __builtin_amdgcn_s_setprio(2);
+                mfma_x(xa0, xb0);
+                if (MODE == 4) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                // g = 1 set ready = every read of this chunk's stage done; next chunk landed (this wave's part)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xa1[0]), "+v"(xa1[1]), "+v"(xb1[0]), "+v"(xb1[1])::"memory");
+                if (more) {
+                    __builtin_amdgcn_s_barrier();
+                    read_set(nxt, 0, xa0, xb0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (MODE == 4) __builtin_amdgcn_s_setprio(2);
+                mfma_x(xa1, xb1);
+                if (MODE == 4) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    read_set(nxt, 1, xa1, xb1);
+                    if (ks + 2 < KS) issue(ks + 2, ks & 1);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (keeps the counter argument of lgkmcnt(4) simple)
+                }
+            }
+        }
+    }
+
+    if (stagger_mode & 8) {     // lab only: keep the accumulators alive but write one value per lane (no C traffic)
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) C[0] = sacc;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t gm = m0 + wr * 64 + i * 32 + l31;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gn = n0 + wc * 64 + j * 32 + 8 * q + 4 * lhi;      // 4 consecutive columns gn..gn+3
+                const int64_t o = ((int64_t)(gn >> 4) * M + gm) * 16 + (gn & 15);
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * q + t] + (bias ? bias[gn + t] : 0.f);
+                if (R) {
+                    const float4 r4 = *reinterpret_cast<const float4 *>(R + o);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (act_tanh) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = fast_tanh(v[t]);
+                }
+                *reinterpret_cast<float4 *>(C + o) = make_float4(v[0] * alpha, v[1] * alpha, v[2] * alpha, v[3] * alpha);
+            }
+    }
+}
+
+// which LDS-DMA configuration a plain panel-major launch uses (0 = the register-staged kernel); set through
+// upamd_tune("gemm_nt_dma", v) by the kernel lab / tests
+// defaults = the best configuration of the kernel lab (tools/gemm_lab*.py, profiles/r02_gemm_lab.md): LDS-DMA staging,
+// three workgroups per CU (12 KB of LDS padding), first-residency-round stagger
+static int g_nt_dma_variant = 1, g_stagger_mode = 1, g_stagger_cycles = 37000, g_lds_pad = 12 * 1024;
+void set_gemm_lds_pad(int bytes) { g_lds_pad = bytes; }
+void set_gemm_nt_dma_variant(int v) { g_nt_dma_variant = v; }
+void set_gemm_stagger(int mode, int cycles) {
+    if (mode >= 0) g_stagger_mode = mode;
+    if (cycles >= 0) g_stagger_cycles = cycles;
+}
+
+template <int BKP, int NSTAGE, int MINW, int MODE = 0>
+static int launch_nt_dma(const GemmNT &g, hipStream_t st) {
+    const int MT = (int)((g.M + 127) / 128), MT8 = (MT + 7) / 8 * 8, NT = g.N / 128;
+    const size_t lds = sizeof(float) * (size_t)NSTAGE * 2 * BKP * 128 * 16 + (size_t)g_lds_pad;     // pad: lab knob limiting WGs per CU
+    auto kern = gemm_nt_dma_kernel<BKP, NSTAGE, MINW, MODE>;
+    if (lds > 64 * 1024) {
+        UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(MT8 * NT), dim3(256), lds, st, g.A, g.M, g.K, g.W, g.N, g.ldw, g.bias, g.R, g.C,
+                       g.act_tanh, g.alpha, MT, NT, g_stagger_mode, g_stagger_cycles);
+    return 0;
+}
+
+static bool nt_dma_ok(const GemmNT &g, int bkp) {
+    return !g.a_rm && !g.c_rm && !g.w_kn && g.N % 128 == 0 && g.K % (16 * bkp) == 0 && g.K >= 64 && g.ldw % 4 == 0 &&
+           reinterpret_cast<uintptr_t>(g.A) % 16 == 0 && reinterpret_cast<uintptr_t>(g.W) % 16 == 0;
+}
+
 // generic fallback (panel-major, any N % 16 == 0): one thread per output element
 __global__ void gemm_nt_generic_kernel(const float *__restrict__ A, int64_t M, int K, const float *__restrict__ W,
                                        int N, int64_t ldw, const float *__restrict__ bias, const float *__restrict__ R,
@@ -280,7 +636,21 @@ int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
                                            : (bn == 64 ? (rm ? "gemm_nt_64_rm" : "gemm_nt_64") : (rm ? "gemm_nt_32_rm" : "gemm_nt_32")));
     int began = prof_begin(prof, pname, st, flops, bytes);
     if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
-    if (mfma) {
+    const int dv = (mfma && !k32 && bn == 128) ? g_nt_dma_variant : 0;
+    int dma_rc = 1;                             // 1 = not taken
+    switch (dv) {
+        case 1: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4>(g, st); break;
+        case 2: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4, 1>(g, st); break;
+        case 3: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4, 2>(g, st); break;
+        case 4: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4, 3>(g, st); break;
+        case 5: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4, 4>(g, st); break;
+        case 6: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 2, 4>(g, st); break;
+        default: break;
+    }
+    if (dma_rc < 0) return dma_rc;
+    if (dma_rc == 0) {
+    }
+    else if (mfma) {
         if (g.a_rm && g.c_rm) launch_nt_layout<true, true, 1>(g, st);
         else if (g.a_rm) launch_nt_layout<true, false, 1>(g, st);
         else if (g.c_rm) launch_nt_layout<false, true, 1>(g, st);

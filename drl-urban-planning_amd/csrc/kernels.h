@@ -67,6 +67,9 @@ struct GemmNT {
     bool w_kn = false;          // W is given as [K][N] (row stride ldw) instead of [N][K]: C = A W, no transpose needed
 };
 bool gemm_nt_mfma_ok(const GemmNT &g);
+void set_gemm_nt_dma_variant(int v);
+void set_gemm_stagger(int mode, int cycles);
+void set_gemm_lds_pad(int bytes);   // first-residency-round stagger of the GEMM workgroups (-1 = keep)       // kernel-lab knob: LDS-DMA configuration of the plain panel-major launches
 int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof);
 struct GemmTN {
     const float *A; int I; int64_t lda;

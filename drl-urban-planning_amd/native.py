@@ -73,6 +73,8 @@ SYMBOLS = {
                                 C.c_int32, C.c_int32, C.c_float, _P]),
     'upamd_gemm_tn_scratch_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     'upamd_gemm_tn': (C.c_int, [_P, C.c_int32, C.c_int64, _P, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P]),
+    'upamd_tune': (C.c_int, [C.c_char_p, C.c_int32]),
+    'upamd_clock_probe': (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     'upamd_profile_enable': (C.c_int, [_P, C.c_int32]),
     'upamd_profile_read': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]),

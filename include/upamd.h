@@ -221,6 +221,13 @@ int64_t upamd_gemm_tn_scratch_floats(int32_t I, int32_t J, int64_t M);
 int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev, int32_t J, int64_t ldb, int64_t M,
                   int32_t row_major, float *scratch_dev, float *out_dev, void *stream);
 
+/* Kernel-lab knob (tools/gemm_lab.py, tests): selects a kernel configuration by name; no reference counterpart.
+ *   "gemm_nt_dma": 0 = register-staged gemm_nt, k > 0 = LDS-DMA configuration k of the plain panel-major launches */
+int upamd_tune(const char *name, int32_t value);
+/* Lab hook: one wave writes `samples` pairs (shader-clock counter, 100 MHz wall-clock counter) into out_dev (int64[2 * samples]),
+ * `gap_ticks` wall-clock ticks apart; launched on a side stream it measures the effective shader clock under load. */
+int upamd_clock_probe(void *out_dev, int32_t samples, int32_t gap_ticks, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing of the dominant kernels (HIP events on the launch stream), for bench.py.
  * ------------------------------------------------------------------------------------------ */
