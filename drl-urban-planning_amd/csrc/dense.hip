@@ -158,6 +158,17 @@ __global__ __launch_bounds__(256) void colsum_pm_kernel(const float *__restrict_
 int launch_reduce_rows_add(const float *part, int nrows, int cols, float *dst, hipStream_t st) {
     return launch_colsum_rm(part, nrows, cols, cols, dst, st);
 }
+// partial sums only: part[blk][cols]; the caller reduces the *nblk rows (a RedJob of the step's final reduction)
+int launch_colsum_pm_part(const float *X, int64_t rows, int cols, const float *w, float *part, int *nblk_out, hipStream_t st) {
+    *nblk_out = 0;
+    if (rows <= 0 || cols <= 0) return 0;
+    const int nblk = colsum_pm_blocks(rows);
+    *nblk_out = nblk;
+    hipLaunchKernelGGL(colsum_pm_kernel, dim3(nblk, cols / 16), dim3(256), 0, st, X, rows, cols, w, part);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_colsum_pm(const float *X, int64_t rows, int cols, const float *w, float *part, float *dst, hipStream_t st) {
     if (rows <= 0 || cols <= 0) return 0;
     const int nblk = colsum_pm_blocks(rows);

@@ -1,8 +1,12 @@
 // Engine: sequences the kernels of one minibatch forward / backward on a stream.
 // The order of operations mirrors tests/csr_model.py (the executable spec) step by step.
+//
+// Launch budget (round 2): the per-sample chains, the parameter preparation and every small reduction are fused
+// (chain.hip), so a training step is ~45 launches instead of ~165: what remains is one launch per big GEMM / message-
+// passing pass plus a handful of grouped kernels.
 #include <cmath>
 #include <cstring>
-#include <map>
+#include <vector>
 
 #include "kernels.h"
 
@@ -16,17 +20,45 @@ struct upamd_engine {
 
 namespace {
 
+constexpr int MAXL = 16;
+
+// workspace slots (float offsets computed by make_plan); "+l" / "+i" ranges are indexed by layer / MLP depth
+enum Slot : int {
+    S_ROWS = 0, S_WE_PAD, S_WKK, S_WKKT, S_WVV, S_WVVT, S_BVV, S_W1F, S_W1FT, S_WBD, S_WBDT, S_R1T, S_W1C, S_B1C, S_WET, S_WQT, S_WIQT,
+    S_WOT, S_XP, S_CURG, S_C, S_HBARV, S_HBARE, S_Q0, S_Q1, S_R, S_ALPHA, S_S, S_O, S_ATT, S_SV, S_CONSTB, S_FE, S_HIDL, S_Z_HE, S_P_HE,
+    S_XR, S_HIDR, S_Z_RN, S_P_RN, S_LSE, S_ENTK,
+    // backward
+    S_DSV, S_DATT, S_DO, S_DS, S_DR, S_DQ1, S_DQ0, S_DC, S_DC_HEAD, S_DCONST, S_DWKK, S_DWVV, S_DBVV, S_DW1F, S_DWBD, S_TN, S_DWC1,
+    S_DZ_HE, S_DZ_RN, S_DPREL, S_DFE, S_DMHE, S_DPRER, S_DXR, S_G0, S_G1, S_DPQ, S_SLAB_SMALL, S_SLAB_XP1, S_SLAB_XP2, S_SLAB_FE,
+    S_SLAB_XR, S_CSP0, S_CSP1, S_CSP2, S_CSP3,
+    S_WCAT,                               // + l (0 .. L-1)
+    S_WCATT = S_WCAT + MAXL,              // + l
+    S_H = S_WCATT + MAXL,                 // + l (0 .. L)
+    S_PQ = S_H + MAXL + 1,                // + l (1 .. L)
+    S_CS = S_PQ + MAXL + 1,               // + l (1 .. L): column sums of dP | dQ
+    S_DBIAS = S_CS + MAXL + 1,            // + l (1 .. L): per-graph partial sums of dP | dQ
+    S_SLAB_W = S_DBIAS + MAXL + 1,        // + l (2 .. L): split-K slabs of the layer's weight gradient
+    S_WNT = S_SLAB_W + MAXL + 1,          // + i: transposed numerical-encoder weights
+    S_WVT = S_WNT + UPAMD_MAX_MLP,        // + i: transposed value-head weights
+    S_U = S_WVT + UPAMD_MAX_MLP,          // + i (0 .. n_num)
+    S_V = S_U + UPAMD_MAX_MLP + 1,        // + i (1 .. n_value - 1)
+    S_DAV = S_V + UPAMD_MAX_MLP + 1,      // + i
+    S_DAN = S_DAV + UPAMD_MAX_MLP,        // + i
+    S_COUNT = S_DAN + UPAMD_MAX_MLP
+};
+
 struct Plan {
-    std::map<std::string, int64_t> off;     // float offsets
-    std::map<std::string, int64_t> len;
-    int64_t total = 0;                      // floats
+    int64_t off[S_COUNT];
+    int64_t len[S_COUNT];
+    int64_t total = 0;                    // floats
+    int64_t small_slab_floats = 0;
 };
 
 struct Dims {
     int D, L, heads, dh, F, Fn, S_last, W;   // W = width of state_value
-    int Wp;                                  // its row stride: W padded to a multiple of 16 so the value head runs on MFMA
+    int Wp;                                  // its row stride in the workspace: W padded to a multiple of 16
     int h0l, h0r;                            // hidden sizes of the two pointer heads
-    int maxdim;                              // widest per-sample activation
+    int maxnum, maxval, maxdim;
 };
 
 Dims dims_of(const upamd_model_desc &d) {
@@ -37,79 +69,98 @@ Dims dims_of(const upamd_model_desc &d) {
     x.Wp = (x.W + 15) / 16 * 16;
     x.h0l = d.land_hidden[0];
     x.h0r = d.road_hidden[0];
-    x.maxdim = std::max(x.Wp, std::max(x.Fn, d.D));
-    for (int i = 0; i < d.n_num; ++i) x.maxdim = std::max(x.maxdim, d.num_hidden[i]);
-    for (int i = 0; i < d.n_value; ++i) x.maxdim = std::max(x.maxdim, d.value_hidden[i]);
+    x.maxnum = x.Fn;
+    for (int i = 0; i < d.n_num; ++i) x.maxnum = std::max(x.maxnum, d.num_hidden[i]);
+    x.maxval = 1;
+    for (int i = 0; i < d.n_value; ++i) x.maxval = std::max(x.maxval, d.value_hidden[i]);
+    x.maxdim = std::max(std::max(x.maxnum, x.maxval), d.D);
     return x;
 }
 
-int64_t slab_floats(const Dims &x, int64_t B, int64_t M, int64_t Nhe, int64_t Nrn) {
-    int64_t s = 0;
-    s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, x.D, M) * 2 * x.D * x.D);          // GCN weight grads
-    s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, 32, M) * 2 * x.D * 32);            // node encoder (G^1 and dPQ_1 parts)
-    s = std::max<int64_t>(s, (int64_t)tn_splits(2 * x.D, x.h0l, Nhe) * 2 * x.D * x.h0l);    // land head
-    s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.h0r, Nrn) * x.D * x.h0r);            // road head
-    s = std::max<int64_t>(s, (int64_t)tn_splits(x.D, x.D, B) * x.D * x.D);                  // per-sample D x D layers
-    s = std::max<int64_t>(s, (int64_t)smm_splits((int)B) * x.maxdim * x.maxdim);            // small per-sample layers (split-K)
-    s = std::max<int64_t>(s, (int64_t)smm_splits(2 * x.D) * x.D * 32);                       // node-encoder products over K = 2D
-    return s;
+ChainDims chain_dims(const upamd_model_desc &d, const Dims &x, int B) {
+    ChainDims c;
+    memset(&c, 0, sizeof(c));
+    c.B = B; c.D = x.D; c.heads = x.heads; c.dh = x.dh; c.F = x.F; c.Fn = x.Fn;
+    c.n_num = d.n_num; c.n_value = d.n_value;
+    for (int i = 0; i < d.n_num; ++i) c.num_hidden[i] = d.num_hidden[i];
+    for (int i = 0; i < d.n_value; ++i) c.value_hidden[i] = d.value_hidden[i];
+    c.S_last = x.S_last; c.W = x.W; c.Wp = x.Wp; c.h0l = x.h0l;
+    c.maxnum = x.maxnum; c.maxval = x.maxval; c.maxdim = x.maxdim;
+    c.scale = 1.0f / std::sqrt((float)x.dh);
+    return c;
 }
 
-void make_plan(const upamd_model_desc &d, const upamd_minibatch &mb, Plan *pl) {
+const char *slot_name_table(int s, char *buf) {      // inverse of slot_of_name for the fixed slots (debugging)
+    (void)s; (void)buf;
+    return "";
+}
+
+void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_minibatch &mb, Plan *pl) {
     const Dims x = dims_of(d);
     const int64_t B = mb.B, M = std::max<int64_t>(mb.n_nodes, 1), NH = std::max<int64_t>(mb.n_he, 1),
                   NR = std::max<int64_t>(mb.n_rn, 1);
     const int D = x.D;
     int64_t off = 0;
-    auto add = [&](const std::string &name, int64_t n) {
-        pl->off[name] = off;
-        pl->len[name] = n;
+    for (int s = 0; s < S_COUNT; ++s) { pl->off[s] = -1; pl->len[s] = 0; }
+    auto add = [&](int slot, int64_t n) {
+        pl->off[slot] = off;
+        pl->len[slot] = n;
         off = align_up(off + std::max<int64_t>(n, 1), 64);
     };
-    add("rows", B * UPAMD_META_STRIDE);     // int32 row descriptors (MbView::rows)
-    add("We_pad", (int64_t)D * 32);
-    for (int l = 0; l < x.L; ++l) {
-        add("Wcat" + std::to_string(l), 2LL * D * D);
-        add("WcatT" + std::to_string(l), 2LL * D * D);
+    add(S_ROWS, B * UPAMD_META_STRIDE);     // int32 row descriptors (MbView::rows)
+    // ---- prepared parameters
+    add(S_WE_PAD, (int64_t)D * 32);
+    for (int l = 0; l < x.L; ++l) { add(S_WCAT + l, 2LL * D * D); add(S_WCATT + l, 2LL * D * D); }
+    add(S_WKK, (int64_t)D * D); add(S_WKKT, (int64_t)D * D); add(S_WVV, (int64_t)D * D); add(S_WVVT, (int64_t)D * D); add(S_BVV, D);
+    add(S_W1F, 2LL * D * x.h0l); add(S_W1FT, 2LL * D * x.h0l); add(S_WBD, (int64_t)D * x.h0l); add(S_WBDT, (int64_t)D * x.h0l);
+    add(S_R1T, (int64_t)D * x.h0r);
+    add(S_W1C, 2LL * D * 32); add(S_B1C, 2LL * D);      // first GCN layer collapsed onto the raw node features
+    {
+        int prev = x.Fn;
+        for (int i = 0; i < d.n_num; ++i) { add(S_WNT + i, (int64_t)prev * d.num_hidden[i]); prev = d.num_hidden[i]; }
+        prev = x.W;
+        for (int i = 0; i < d.n_value; ++i) { add(S_WVT + i, (int64_t)prev * d.value_hidden[i]); prev = d.value_hidden[i]; }
     }
-    add("Wkk", (int64_t)D * D); add("Wvv", (int64_t)D * D); add("bvv", D);
-    add("W1f", 2LL * D * x.h0l); add("W1fT", 2LL * D * x.h0l); add("Wbd", (int64_t)D * x.h0l); add("R1T", (int64_t)D * x.h0r);
-    add("constb", B * x.h0l); add("dconst", B * x.h0l);
-    add("wt", (int64_t)x.maxdim * x.maxdim);          // transposed-weight scratch of the per-sample layers
-    add("W1c", 2LL * D * 32); add("b1c", 2LL * D);    // first GCN layer collapsed onto the raw node features
-    add("dWc1", 2LL * D * D);                         // backward of that collapse
-    add("Xp", 2 * M * 16);
-    add("U0", B * x.Fn);
-    for (int i = 0; i < d.n_num; ++i) add("U" + std::to_string(i + 1), B * d.num_hidden[i]);
-    add("curg", B * UPAMD_NODE_PAD);
-    add("C", B * D);
-    for (int l = 0; l <= x.L; ++l) add("H" + std::to_string(l), M * D);
-    for (int l = 1; l <= x.L; ++l) add("PQ" + std::to_string(l), M * 2 * D);
-    add("hbarV", B * D); add("hbarE", B * D);
-    add("q0", B * D); add("q1", B * D); add("r", B * x.heads * D); add("alpha", (int64_t)x.heads * M);
-    add("s", B * x.heads * D); add("o", B * D); add("att", B * D);
-    add("SV", B * x.Wp);
-    add("Vw0p", (int64_t)d.value_hidden[0] * x.Wp);     // first value-head weight, columns zero-padded to Wp
-    for (int i = 0; i < d.n_value; ++i) add("V" + std::to_string(i + 1), B * d.value_hidden[i]);
-    add("FE", NH * 2 * D); add("hidl", NH * x.h0l); add("z_he", NH); add("p_he", NH);
-    add("XR", NR * D); add("hidr", NR * x.h0r); add("z_rn", NR); add("p_rn", NR);
-    add("lse", B); add("entk", B);
-    // backward temporaries
-    add("dzA", B * x.maxdim); add("dzB", B * x.maxdim); add("dnA", B * x.maxdim); add("dnB", B * x.maxdim);
-    add("datt", B * D);
-    add("do", B * D); add("ds", B * x.heads * D); add("dr", B * x.heads * D);
-    add("dq1", B * D); add("dq0", B * D); add("dC", B * D); add("dC_head", B * D);
-    // accumulate-into scratch of the backward, one contiguous block zeroed by a single memset ("zero_end" marks its end)
-    add("dWkk", (int64_t)D * D); add("dWvv", (int64_t)D * D); add("dbvv", D);
-    add("dW1f", 2LL * D * x.h0l); add("dWbd", (int64_t)D * x.h0l); add("Tn", 2LL * D * 32);
-    for (int l = 1; l <= x.L; ++l) add("cs" + std::to_string(l), 2LL * D);     // column sums of dP | dQ per layer
-    add("zero_end", 1);
-    add("dz_he", NH); add("dz_rn", NR); add("dprel", NH * x.h0l); add("dFE", NH * 2 * D); add("dMhe", NH * D);
-    add("dprer", NR * x.h0r); add("dXR", NR * D);
-    add("G0", M * D); add("G1", M * D); add("dPQ", M * 2 * D); add("dbias_part", B * 2 * D);
-    add("slabs", slab_floats(x, B, M, NH, NR));
-    const int64_t maxrows = std::max(M, std::max(NH, NR));
-    add("cs_part", (int64_t)colsum_pm_blocks(maxrows) * std::max(4 * D, 64));
+    add(S_WET, (int64_t)x.F * D); add(S_WQT, (int64_t)D * D); add(S_WIQT, (int64_t)D * D); add(S_WOT, (int64_t)D * D);
+    // ---- forward activations
+    add(S_XP, 2 * M * 16);
+    add(S_U + 0, B * x.Fn);
+    for (int i = 0; i < d.n_num; ++i) add(S_U + i + 1, B * d.num_hidden[i]);
+    add(S_CURG, B * UPAMD_NODE_PAD);
+    add(S_C, B * D);
+    for (int l = 0; l <= x.L; ++l) add(S_H + l, M * D);
+    for (int l = 1; l <= x.L; ++l) add(S_PQ + l, M * 2 * D);
+    add(S_HBARV, B * D); add(S_HBARE, B * D);
+    add(S_Q0, B * D); add(S_Q1, B * D); add(S_R, B * x.heads * D); add(S_ALPHA, (int64_t)x.heads * M);
+    add(S_S, B * x.heads * D); add(S_O, B * D); add(S_ATT, B * D);
+    add(S_SV, B * x.Wp);
+    for (int i = 1; i < d.n_value; ++i) add(S_V + i, B * d.value_hidden[i - 1]);
+    add(S_CONSTB, B * x.h0l);
+    add(S_FE, NH * 2 * D); add(S_HIDL, NH * x.h0l); add(S_Z_HE, NH); add(S_P_HE, NH);
+    add(S_XR, NR * D); add(S_HIDR, NR * x.h0r); add(S_Z_RN, NR); add(S_P_RN, NR);
+    add(S_LSE, B); add(S_ENTK, B);
+    // ---- backward
+    for (int i = 0; i < d.n_value; ++i) add(S_DAV + i, B * d.value_hidden[i]);
+    for (int i = 0; i < d.n_num; ++i) add(S_DAN + i, B * d.num_hidden[i]);
+    add(S_DSV, B * x.Wp); add(S_DATT, B * D); add(S_DO, B * D); add(S_DS, B * x.heads * D); add(S_DR, B * x.heads * D);
+    add(S_DQ1, B * D); add(S_DQ0, B * D); add(S_DC, B * D); add(S_DC_HEAD, B * D); add(S_DCONST, B * x.h0l);
+    add(S_DWKK, (int64_t)D * D); add(S_DWVV, (int64_t)D * D); add(S_DBVV, D);
+    add(S_DW1F, 2LL * D * x.h0l); add(S_DWBD, (int64_t)D * x.h0l); add(S_TN, 2LL * D * 32); add(S_DWC1, 2LL * D * D);
+    for (int l = 1; l <= x.L; ++l) { add(S_CS + l, 2LL * D); add(S_DBIAS + l, B * 2 * D); }
+    add(S_DZ_HE, NH); add(S_DZ_RN, NR); add(S_DPREL, NH * x.h0l); add(S_DFE, NH * 2 * D); add(S_DMHE, NH * D);
+    add(S_DPRER, NR * x.h0r); add(S_DXR, NR * D);
+    add(S_G0, M * D); add(S_G1, M * D); add(S_DPQ, M * 2 * D);
+    // split-K slabs: every weight-gradient product keeps its own region until the step's final reduction
+    for (int l = 2; l <= x.L; ++l) add(S_SLAB_W + l, (int64_t)tn_splits(2 * D, D, M) * 2 * D * D);
+    add(S_SLAB_XP1, (int64_t)tn_splits(2 * D, 32, M) * 2 * D * 32);
+    add(S_SLAB_XP2, (int64_t)tn_splits(D, 32, M) * D * 32);
+    add(S_SLAB_FE, (int64_t)tn_splits(2 * D, x.h0l, NH) * 2 * D * x.h0l);
+    add(S_SLAB_XR, (int64_t)tn_splits(D, x.h0r, NR) * D * x.h0r);
+    // per-sample weight gradients (grouped dY^T X): <= 16 row splits of every per-sample weight (+ the collapsed ones)
+    pl->small_slab_floats = 16LL * (P.n_floats + 4LL * D * D + 2LL * D * x.h0l + 4096);
+    add(S_SLAB_SMALL, pl->small_slab_floats);
+    const int64_t maxrows = std::max(NH, NR);
+    for (int k = 0; k < 4; ++k) add(S_CSP0 + k, (int64_t)colsum_pm_blocks(maxrows) * std::max(std::max(x.h0l, x.h0r), 16));
     pl->total = off;
 }
 
@@ -152,7 +203,7 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
         return fail(UPAMD_E_INVALID, "packed replay feature sizes (%d,%d) do not match the model (%d,%d)", layout->node_dim,
                     layout->numerical_dim, eng->d.node_dim, eng->d.numerical_dim);
     if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return fail(UPAMD_E_INVALID, "workspace must be 256-byte aligned");
-    make_plan(eng->d, *mb, pl);
+    make_plan(eng->d, eng->P, *mb, pl);
     if (pl->total * 4 > ws_bytes) return fail(UPAMD_E_WORKSPACE, "workspace too small: need %lld bytes, got %lld", (long long)pl->total * 4, (long long)ws_bytes);
     return 0;
 }
@@ -163,56 +214,82 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
         if (_rc) return _rc; \
     } while (0)
 
-// Row-major [rows, .] linear algebra of the per-sample layers.  Large, well-shaped products go to the MFMA
-// kernels (row-major operand variants); everything else to the generic strided kernel.
-struct Lin {
+// Slab-reduction jobs of a step: flushed as one launch (or several, when the job table would overflow)
+struct Reducer {
+    RedJobs jobs;
+    int blocks = 0;
     hipStream_t st;
-    Profiler *prof;
-    float *slabs;      // split-K scratch
-    float *wt;         // transposed-weight scratch
-    static constexpr int MIN_ROWS = 256;
-
-    // Y[R,N] = scale * act(X[R,K] W[N,K]^T + b)
-    int nt(const float *X, int64_t ldx, int R, int K, const float *W, int64_t ldw, const float *b, int N, float *Y,
-           int64_t ldy, int act, float scale) const {
-        GemmNT g{X, R, K, ldx, true, W, N, ldw, b, nullptr, Y, ldy, true, act, scale};
-        if (R >= MIN_ROWS && gemm_nt_mfma_ok(g)) return launch_gemm_nt_ex(g, st, prof);
-        return launch_smm(R, N, K, X, ldx, 1, W, 1, ldw, b, Y, ldy, 0, act, scale, st);
+    int add(const float *slab, int S, int64_t sstride, int I, int J, int mode, int jkeep, float *dst, int ldd, float *dst2 = nullptr,
+            int overwrite = 0) {
+        if (jobs.n >= RED_MAX_JOBS) CK(flush());
+        return red_add(&jobs, &blocks, slab, S, sstride, I, J, mode, jkeep, dst, ldd, dst2, overwrite);
     }
-    // Y[R,N] = X[R,K] Wm[K,N]   (Wm row-major dense, ld = N)
-    int nn(const float *X, int64_t ldx, int R, int K, const float *Wm, int N, float *Y, int64_t ldy) const {
-        GemmNT g{X, R, K, ldx, true, Wm, N, N, nullptr, nullptr, Y, ldy, true, 0, 1.f};
-        g.w_kn = true;                       // the kernel reads the [K][N] weight as it is
-        if (R >= MIN_ROWS && gemm_nt_mfma_ok(g)) return launch_gemm_nt_ex(g, st, prof);
-        return launch_smm(R, N, K, X, ldx, 1, Wm, N, 1, nullptr, Y, ldy, 0, 0, 1.f, st);
-    }
-    // dW[N,K] += dY[R,N]^T X[R,K];  db[N] += colsum(dY)
-    // (keep < K: X's trailing columns are zero padding, dW is [N, keep])
-    int tn_acc(const float *dY, int64_t ldy, int R, int N, const float *X, int64_t ldx, int K, float *dW, float *db,
-               int keep = -1) const {
-        if (keep < 0) keep = K;
-        GemmTN g{dY, N, ldy, X, K, ldx, R, true, slabs};
-        if (R >= MIN_ROWS && gemm_tn_mfma_ok(g)) {
-            int S = 1;
-            CK(launch_gemm_tn_ex(g, &S, st, prof));
-            CK(launch_reduce_slabs(slabs, S, N, K, 0, keep, dW, keep, st));
-        } else if (R >= 64) {       // reduction over rows, small output: split-K, fixed-order reduce
-            int S = 1;
-            CK(launch_smm_splitk(N, K, R, dY, 1, ldy, X, ldx, 1, slabs, &S, st));
-            CK(launch_reduce_slabs(slabs, S, N, K, 0, keep, dW, keep, st));
-        } else {
-            CK(launch_smm(N, keep, R, dY, 1, ldy, X, ldx, 1, nullptr, dW, keep, 1, 0, 1.f, st));
-        }
-        if (db) CK(launch_colsum_rm(dY, R, N, ldy, db, st));
-        return 0;
-    }
-    // Y[R,N] += X[R,K] W[N,K]^T
-    int nt_acc(const float *X, int64_t ldx, int R, int K, const float *W, int64_t ldw, int N, float *Y, int64_t ldy) const {
-        GemmNT g{X, R, K, ldx, true, W, N, ldw, nullptr, Y, Y, ldy, true, 0, 1.f};
-        if (R >= MIN_ROWS && gemm_nt_mfma_ok(g)) return launch_gemm_nt_ex(g, st, prof);
-        return launch_smm(R, N, K, X, ldx, 1, W, 1, ldw, nullptr, Y, ldy, 1, 0, 1.f, st);
+    int flush() {
+        int rc = launch_greduce(jobs, blocks, st);
+        jobs.n = 0;
+        blocks = 0;
+        return rc;
     }
 };
+
+// name -> (slot, rows, cols, kind) of the workspace tensors the tests / action heads read
+int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch &mb, const std::string &n, int64_t *rows,
+                 int64_t *cols, int *kind) {
+    const int64_t B = mb.B, M = mb.n_nodes, NH = mb.n_he, NR = mb.n_rn;
+    auto num = [&](size_t pos) { return atoi(n.c_str() + pos); };
+    *kind = 0;
+    if (n[0] == 'H' && n.size() > 1 && isdigit(n[1])) { *rows = M; *cols = x.D; *kind = 1; return num(1) <= x.L ? S_H + num(1) : -1; }
+    if (n.rfind("PQ", 0) == 0) { *rows = M; *cols = 2 * x.D; *kind = 1; return (num(2) >= 1 && num(2) <= x.L) ? S_PQ + num(2) : -1; }
+    if (n == "dPQ") { *rows = M; *cols = 2 * x.D; *kind = 1; return S_DPQ; }
+    if (n == "G0" || n == "G1") { *rows = M; *cols = x.D; *kind = 1; return n == "G0" ? S_G0 : S_G1; }
+    if (n == "Xp") { *rows = M; *cols = 32; *kind = 1; return S_XP; }
+    if (n == "FE" || n == "dFE") { *rows = NH; *cols = 2 * x.D; *kind = 1; return n == "FE" ? S_FE : S_DFE; }
+    if (n == "hidl" || n == "dprel") { *rows = NH; *cols = x.h0l; *kind = 1; return n == "hidl" ? S_HIDL : S_DPREL; }
+    if (n == "dMhe") { *rows = NH; *cols = x.D; *kind = 1; return S_DMHE; }
+    if (n == "XR" || n == "dXR") { *rows = NR; *cols = x.D; *kind = 1; return n == "XR" ? S_XR : S_DXR; }
+    if (n == "hidr" || n == "dprer") { *rows = NR; *cols = x.h0r; *kind = 1; return n == "hidr" ? S_HIDR : S_DPRER; }
+    if (n == "z_he" || n == "p_he" || n == "dz_he") { *rows = NH; *cols = 1; return n == "z_he" ? S_Z_HE : (n == "p_he" ? S_P_HE : S_DZ_HE); }
+    if (n == "z_rn" || n == "p_rn" || n == "dz_rn") { *rows = NR; *cols = 1; return n == "z_rn" ? S_Z_RN : (n == "p_rn" ? S_P_RN : S_DZ_RN); }
+    if (n == "alpha") { *rows = x.heads; *cols = M; return S_ALPHA; }
+    if (n == "SV" || n == "dSV") { *rows = B; *cols = x.Wp; return n == "SV" ? S_SV : S_DSV; }      // columns >= W are zero padding
+    if (n == "r" || n == "s" || n == "ds" || n == "dr") {
+        *rows = B; *cols = (int64_t)x.heads * x.D;
+        return n == "r" ? S_R : (n == "s" ? S_S : (n == "ds" ? S_DS : S_DR));
+    }
+    if (n == "lse" || n == "entk") { *rows = B; *cols = 1; return n == "lse" ? S_LSE : S_ENTK; }
+    if (n == "curg") { *rows = B; *cols = UPAMD_NODE_PAD; return S_CURG; }
+    if (n == "Wkk" || n == "Wvv" || n == "dWkk" || n == "dWvv") {
+        *rows = x.D; *cols = x.D;
+        return n == "Wkk" ? S_WKK : (n == "Wvv" ? S_WVV : (n == "dWkk" ? S_DWKK : S_DWVV));
+    }
+    if (n[0] == 'U' && n.size() > 1 && isdigit(n[1])) {
+        const int i = num(1);
+        if (i < 0 || i > d.n_num) return -1;
+        *rows = B; *cols = i == 0 ? x.Fn : d.num_hidden[i - 1];
+        return S_U + i;
+    }
+    if (n[0] == 'V' && n.size() > 1 && isdigit(n[1])) {
+        const int i = num(1);
+        if (i < 1 || i >= d.n_value) return -1;
+        *rows = B; *cols = d.value_hidden[i - 1];
+        return S_V + i;
+    }
+    *rows = B; *cols = x.D;
+    if (n == "C") return S_C;
+    if (n == "hbarV") return S_HBARV;
+    if (n == "hbarE") return S_HBARE;
+    if (n == "q0") return S_Q0;
+    if (n == "q1") return S_Q1;
+    if (n == "o") return S_O;
+    if (n == "att") return S_ATT;
+    if (n == "do") return S_DO;
+    if (n == "datt") return S_DATT;
+    if (n == "dq1") return S_DQ1;
+    if (n == "dq0") return S_DQ0;
+    if (n == "dC") return S_DC;
+    if (n == "dC_head") return S_DC_HEAD;
+    return -1;
+}
 
 }  // namespace
 
@@ -223,6 +300,7 @@ extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **
     if (rc) return rc;
     if (desc->n_land != 2 || desc->n_road != 2)
         return fail(UPAMD_E_INVALID, "this build supports pointer heads of the form [hidden, 1] only (got %d and %d layers)", desc->n_land, desc->n_road);
+    if (desc->L > MAXL) return fail(UPAMD_E_INVALID, "num_gcn_layers > %d", MAXL);
     upamd_engine *e = new upamd_engine();
     e->d = *desc;
     e->P = P;
@@ -278,7 +356,7 @@ extern "C" int upamd_workspace_bytes(upamd_engine *eng, const upamd_minibatch *m
     (void)training;
     if (!eng || !mb || !bytes) return fail(UPAMD_E_INVALID, "null argument");
     Plan pl;
-    make_plan(eng->d, *mb, &pl);
+    make_plan(eng->d, eng->P, *mb, &pl);
     *bytes = pl.total * 4 + 256;
     return UPAMD_OK;
 }
@@ -287,35 +365,13 @@ extern "C" int upamd_ws_tensor(upamd_engine *eng, const upamd_minibatch *mb, con
                                int64_t *rows, int64_t *cols, int32_t *kind) {
     if (!eng || !mb || !name) return fail(UPAMD_E_INVALID, "null argument");
     Plan pl;
-    make_plan(eng->d, *mb, &pl);
-    auto it = pl.off.find(name);
-    if (it == pl.off.end()) return fail(UPAMD_E_INVALID, "unknown workspace tensor '%s'", name);
+    make_plan(eng->d, eng->P, *mb, &pl);
     const Dims x = dims_of(eng->d);
-    const std::string n(name);
     int64_t r = 0, c = 0;
     int k = 0;
-    const int64_t B = mb->B, M = mb->n_nodes, NH = mb->n_he, NR = mb->n_rn;
-    if (n[0] == 'H' && isdigit(n[1])) { r = M; c = x.D; k = 1; }
-    else if (n.rfind("PQ", 0) == 0 || n == "dPQ") { r = M; c = 2 * x.D; k = 1; }
-    else if (n == "G0" || n == "G1") { r = M; c = x.D; k = 1; }
-    else if (n == "Xp") { r = M; c = 32; k = 1; }
-    else if (n == "FE" || n == "dFE") { r = NH; c = 2 * x.D; k = 1; }
-    else if (n == "hidl" || n == "dprel") { r = NH; c = x.h0l; k = 1; }
-    else if (n == "dMhe") { r = NH; c = x.D; k = 1; }
-    else if (n == "XR" || n == "dXR") { r = NR; c = x.D; k = 1; }
-    else if (n == "hidr" || n == "dprer") { r = NR; c = x.h0r; k = 1; }
-    else if (n == "z_he" || n == "p_he" || n == "dz_he") { r = NH; c = 1; }
-    else if (n == "z_rn" || n == "p_rn" || n == "dz_rn") { r = NR; c = 1; }
-    else if (n == "alpha") { r = x.heads; c = M; }
-    else if (n == "SV") { r = B; c = x.Wp; }      // columns >= W are zero padding
-    else if (n == "r" || n == "s" || n == "ds" || n == "dr") { r = B; c = (int64_t)x.heads * x.D; }
-    else if (n == "lse" || n == "entk") { r = B; c = 1; }
-    else if (n == "U0") { r = B; c = x.Fn; }
-    else if (n == "curg") { r = B; c = UPAMD_NODE_PAD; }
-    else if (n == "Wkk" || n == "Wvv" || n == "dWkk" || n == "dWvv") { r = x.D; c = x.D; }
-    else if (n[0] == 'U' || n[0] == 'V') { r = B; c = pl.len[n] / std::max<int64_t>(B, 1); }
-    else { r = B; c = x.D; }     // C, hbarV, hbarE, q0, q1, o, att, do, dq*, dC*
-    if (byte_offset) *byte_offset = it->second * 4;
+    const int slot = slot_of_name(eng->d, x, *mb, name, &r, &c, &k);
+    if (slot < 0 || pl.off[slot] < 0) return fail(UPAMD_E_INVALID, "unknown workspace tensor '%s'", name);
+    if (byte_offset) *byte_offset = pl.off[slot] * 4;
     if (rows) *rows = r;
     if (cols) *cols = c;
     if (kind) *kind = k;
@@ -340,100 +396,110 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     const PackedView pk = make_view(packed_dev, *layout);
     MbView mb = make_mb(*mbp);
     float *ws = static_cast<float *>(ws_dev);
-    auto W = [&](const std::string &n) { return ws + pl.off.at(n); };
+    auto W = [&](int slot) { return ws + pl.off[slot]; };
     auto PR = [&](int idx) { return prm + P.off(idx); };
     Profiler *prof = &eng->prof;
-    const Lin lin{st, prof, W("slabs"), W("wt")};
-    // row descriptors first: every per-graph kernel below (and the backward) reads them
-    CK(launch_gather_rows(pk, mb, reinterpret_cast<int32_t *>(W("rows")), st));
-    mb.rows = reinterpret_cast<const int32_t *>(W("rows"));
-
-    // -- per-step weight preparation (tiny)
-    CK(launch_pad_cols(PR(P.node_w), D, x.F, 32, W("We_pad"), st));
-    for (int l = 0; l < x.L; ++l)
-        CK(launch_prep_wcat(PR(P.edge_w[l]), D, W("Wcat" + std::to_string(l)), W("WcatT" + std::to_string(l)), st));
     const float *Win = PR(P.inproj_w), *bin = PR(P.inproj_b);
     const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
     const float *biq = bin, *biv = bin + 2 * D;
-    // Wkk = Wik Wk, Wvv = Wiv Wv, bvv = Wiv bv + biv
-    CK(lin.nn(Wik, D, D, D, PR(P.k_w), D, W("Wkk"), D));
-    CK(lin.nn(Wiv, D, D, D, PR(P.v_w), D, W("Wvv"), D));
-    CK(launch_smm(1, D, D, PR(P.v_b), D, 1, Wiv, 1, D, biv, W("bvv"), D, 0, 0, 1.f, st));
+    const bool land = mb.Nhe > 0, road = mb.Nrn > 0;
 
-    // -- inputs
-    CK(launch_gather_inputs(pk, mb, W("Xp"), W("U0"), W("curg"), st));
-    // numerical encoder (state_encoder.py:35-57,187)
+    // ---- 1. every gather-style parameter preparation in ONE launch
     {
+        PermJobs pj;
+        int blocks = 0;
+        CK(perm_add(&pj, &blocks, PERM_PAD_COLS, PR(P.node_w), nullptr, W(S_WE_PAD), nullptr, nullptr, nullptr, D, x.F, 32));
+        for (int l = 0; l < x.L; ++l)
+            CK(perm_add(&pj, &blocks, PERM_WCAT, PR(P.edge_w[l]), nullptr, W(S_WCAT + l), W(S_WCATT + l), nullptr, nullptr, D, D, 0));
+        CK(perm_add(&pj, &blocks, PERM_LAND_HEAD, PR(P.land_w[0]), nullptr, W(S_W1F), W(S_WBD), W(S_W1FT), W(S_WBDT), x.h0l, D, 0));
+        CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.road_w[0]), nullptr, W(S_R1T), nullptr, nullptr, nullptr, x.h0r, D, 0));
         int prev = x.Fn;
         for (int i = 0; i < d.n_num; ++i) {
-            CK(lin.nt(W("U" + std::to_string(i)), prev, B, prev, PR(P.num_w[i]), prev, PR(P.num_b[i]), d.num_hidden[i],
-                      W("U" + std::to_string(i + 1)), d.num_hidden[i], 1, 1.f));
+            CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.num_w[i]), nullptr, W(S_WNT + i), nullptr, nullptr, nullptr, d.num_hidden[i], prev, 0));
             prev = d.num_hidden[i];
         }
-    }
-    // node encoder on all nodes and on the current node (state_encoder.py:189-191)
-    CK(launch_gemm_nt(W("Xp"), mb.M, 32, W("We_pad"), D, PR(P.node_b), nullptr, W("H0"), 0, st, prof));
-    CK(launch_smm(B, D, x.F, W("curg"), UPAMD_NODE_PAD, 1, PR(P.node_w), 1, x.F, PR(P.node_b), W("C"), D, 0, 0, 1.f, st));
-    // GCN layers (state_encoder.py:194-197).  Layer 1 reads its P/Q straight from the raw node features:
-    // PQ_1 = H_0 Wcat_1^T = Xp (Wcat_1 We)^T + Wcat_1 be  (K = 32 instead of D: saves one full-size node GEMM)
-    CK(lin.nn(W("Wcat0"), D, 2 * D, D, W("We_pad"), 32, W("W1c"), 32));
-    CK(launch_smm(1, 2 * D, D, PR(P.node_b), D, 1, W("Wcat0"), 1, D, nullptr, W("b1c"), 2 * D, 0, 0, 1.f, st));
-    for (int l = 1; l <= x.L; ++l) {
-        const std::string sl = std::to_string(l);
-        if (l == 1)
-            CK(launch_gemm_nt(W("Xp"), mb.M, 32, W("W1c"), 2 * D, W("b1c"), nullptr, W("PQ1"), 0, st, prof));
-        else
-            CK(launch_gemm_nt(W("H" + std::to_string(l - 1)), mb.M, D, W("Wcat" + std::to_string(l - 1)), 2 * D, nullptr, nullptr,
-                              W("PQ" + sl), 0, st, prof));
-        // the last layer also writes the land-use pointer-head inputs FE (needs C, computed above)
-        CK(launch_edge_fwd(pk, mb, D, l == x.L, W("PQ" + sl), PR(P.edge_b[l - 1]), W("H" + std::to_string(l - 1)), W("H" + sl),
-                           W("hbarV"), W("hbarE"), W("C"), (l == x.L && mb.Nhe > 0) ? W("FE") : nullptr, st, prof));
-    }
-    const float *HL = W("H" + std::to_string(x.L));
-    // attention (state_encoder.py:150-161)
-    const float scale = 1.0f / std::sqrt((float)x.dh);
-    CK(lin.nt(W("C"), D, B, D, PR(P.q_w), D, PR(P.q_b), D, W("q0"), D, 0, 1.f));
-    CK(lin.nt(W("q0"), D, B, D, Wiq, D, biq, D, W("q1"), D, 0, scale));
-    for (int h = 0; h < x.heads; ++h)   // r[b,h,:] = q1[b, h-slice] @ Wkk[h-slice, :]
-        CK(lin.nn(W("q1") + h * x.dh, D, B, x.dh, W("Wkk") + (int64_t)h * x.dh * D, D, W("r") + (int64_t)h * D,
-                  (int64_t)x.heads * D));
-    CK(launch_attn_fwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("s"), st));
-    for (int h = 0; h < x.heads; ++h)   // o[b, h-slice] = s[b,h,:] @ Wvv[h-slice,:]^T + bvv[h-slice]
-        CK(lin.nt(W("s") + (int64_t)h * D, (int64_t)x.heads * D, B, D, W("Wvv") + (int64_t)h * x.dh * D, D, W("bvv") + h * x.dh,
-                  x.dh, W("o") + h * x.dh, D, 0, 1.f));
-    CK(lin.nt(W("o"), D, B, D, PR(P.outproj_w), D, PR(P.outproj_b), D, W("att"), D, 0, 1.f));
-    // value head (value.py:15-39)
-    CK(launch_assemble_sv(pk, mb, D, x.S_last, W("U" + std::to_string(d.n_num)), W("hbarV"), W("hbarE"), W("att"), W("SV"), x.Wp, st));
-    CK(launch_pad_cols(PR(P.value_w[0]), d.value_hidden[0], x.W, x.Wp, W("Vw0p"), st));
-    {
-        const float *prevp = W("SV");
-        int prev = x.Wp;
+        prev = x.W;
         for (int i = 0; i < d.n_value; ++i) {
-            float *out = (i == d.n_value - 1) ? value_dev : W("V" + std::to_string(i + 1));
-            CK(lin.nt(prevp, prev, B, prev, i == 0 ? W("Vw0p") : PR(P.value_w[i]), prev, PR(P.value_b[i]), d.value_hidden[i], out,
-                      d.value_hidden[i], i < d.n_value - 1, 1.f));
-            prevp = out;
+            CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.value_w[i]), nullptr, W(S_WVT + i), nullptr, nullptr, nullptr, d.value_hidden[i], prev, 0));
             prev = d.value_hidden[i];
         }
+        CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.node_w), nullptr, W(S_WET), nullptr, nullptr, nullptr, D, x.F, 0));
+        CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.q_w), nullptr, W(S_WQT), nullptr, nullptr, nullptr, D, D, 0));
+        CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, Wiq, nullptr, W(S_WIQT), nullptr, nullptr, nullptr, D, D, 0));
+        CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.outproj_w), nullptr, W(S_WOT), nullptr, nullptr, nullptr, D, D, 0));
+        CK(launch_permute(pj, blocks, st));
     }
-    // pointer heads (policy.py:19-65)
-    if (mb.Nhe > 0) {
+    // ---- 2. the collapsed weight products in ONE launch
+    //   Wkk = Wik Wk, Wvv = Wiv Wv, bvv = Wiv bv + biv (single-query attention, state_encoder.py:150-161);
+    //   W1c = Wcat_1 We, b1c = Wcat_1 be (first GCN layer straight from the raw node features)
+    {
+        SmmJobs sj;
+        int blocks = 0;
+        CK(smm_add(&sj, &blocks, D, D, D, Wik, D, 1, PR(P.k_w), D, 1, nullptr, W(S_WKK), D, 0, 1.f, W(S_WKKT), D));
+        CK(smm_add(&sj, &blocks, D, D, D, Wiv, D, 1, PR(P.v_w), D, 1, nullptr, W(S_WVV), D, 0, 1.f, W(S_WVVT), D));
+        CK(smm_add(&sj, &blocks, 1, D, D, PR(P.v_b), 0, 1, Wiv, 1, D, biv, W(S_BVV), D, 0, 1.f));
+        CK(smm_add(&sj, &blocks, 2 * D, 32, D, W(S_WCAT + 0), D, 1, W(S_WE_PAD), 32, 1, nullptr, W(S_W1C), 32, 0, 1.f));
+        CK(smm_add(&sj, &blocks, 1, 2 * D, D, PR(P.node_b), 0, 1, W(S_WCAT + 0), 1, D, nullptr, W(S_B1C), 2 * D, 0, 1.f));
+        CK(launch_gsmm(sj, blocks, st));
+    }
+    // ---- 3. per-sample chain before the graph part (+ row descriptors, + node-feature gather)
+    const ChainDims cd = chain_dims(d, x, B);
+    {
+        ChainFwdPre a;
+        memset(&a, 0, sizeof(a));
+        a.d = cd; a.pk = pk; a.mb = mb;
+        a.rows = reinterpret_cast<int32_t *>(W(S_ROWS)); a.Xp = W(S_XP);
+        for (int i = 0; i < d.n_num; ++i) { a.WnT[i] = W(S_WNT + i); a.bn[i] = PR(P.num_b[i]); }
+        a.WeT = W(S_WET); a.be = PR(P.node_b); a.WqT = W(S_WQT); a.bq = PR(P.q_b); a.WiqT = W(S_WIQT); a.biq = biq;
+        a.Wkk = W(S_WKK); a.WbdT = W(S_WBDT); a.b1l = PR(P.land_b0);
+        for (int i = 0; i <= d.n_num; ++i) a.U[i] = W(S_U + i);
+        a.curg = W(S_CURG); a.C = W(S_C); a.q0 = W(S_Q0); a.q1 = W(S_Q1); a.r = W(S_R);
+        a.constb = land ? W(S_CONSTB) : nullptr;
+        CK(launch_chain_fwd_pre(a, st));
+    }
+    mb.rows = reinterpret_cast<const int32_t *>(W(S_ROWS));
+    // ---- 4. node encoder on all nodes (state_encoder.py:189-190) and the GCN layers (state_encoder.py:194-197).
+    // Layer 1 reads its P/Q straight from the raw node features:
+    // PQ_1 = H_0 Wcat_1^T = Xp (Wcat_1 We)^T + Wcat_1 be  (K = 32 instead of D: saves one full-size node GEMM)
+    CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_WE_PAD), D, PR(P.node_b), nullptr, W(S_H + 0), 0, st, prof));
+    for (int l = 1; l <= x.L; ++l) {
+        if (l == 1)
+            CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_W1C), 2 * D, W(S_B1C), nullptr, W(S_PQ + 1), 0, st, prof));
+        else
+            CK(launch_gemm_nt(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), 2 * D, nullptr, nullptr, W(S_PQ + l), 0, st, prof));
+        // the last layer also writes the land-use pointer-head inputs FE (needs C, computed above)
+        CK(launch_edge_fwd(pk, mb, D, l == x.L, W(S_PQ + l), PR(P.edge_b[l - 1]), W(S_H + l - 1), W(S_H + l), W(S_HBARV), W(S_HBARE),
+                           W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, prof));
+    }
+    const float *HL = W(S_H + x.L);
+    // ---- 5. attention core, then the per-sample chain after it (out-projection, state_value, value head)
+    CK(launch_attn_fwd(pk, mb, D, x.heads, HL, W(S_R), W(S_ALPHA), W(S_S), st));
+    {
+        ChainFwdPost a;
+        memset(&a, 0, sizeof(a));
+        a.d = cd; a.rows = mb.rows;
+        a.s = W(S_S); a.hbarV = W(S_HBARV); a.hbarE = W(S_HBARE); a.Ulast = W(S_U + d.n_num);
+        a.WvvT = W(S_WVVT); a.bvv = W(S_BVV); a.WoT = W(S_WOT); a.bo = PR(P.outproj_b);
+        for (int i = 0; i < d.n_value; ++i) { a.WvT[i] = W(S_WVT + i); a.bv[i] = PR(P.value_b[i]); }
+        a.o = W(S_O); a.att = W(S_ATT); a.SV = W(S_SV);
+        for (int i = 1; i < d.n_value; ++i) a.V[i] = W(S_V + i);
+        a.value = value_dev;
+        CK(launch_chain_fwd_post(a, st));
+    }
+    // ---- 6. pointer heads (policy.py:19-65)
+    if (land) {
         // factorised first Linear: hid = tanh(FE [Wa+Wd | Wc]^T + ((Wb-Wd) c_b + b1)), the bias rows are
         // pre-written into hid and accumulated in place
-        CK(launch_prep_land_head(PR(P.land_w[0]), D, x.h0l, W("W1f"), W("Wbd"), st));
-        CK(lin.nt(W("C"), D, B, D, W("Wbd"), D, PR(P.land_b0), x.h0l, W("constb"), x.h0l, 0, 1.f));
-        CK(launch_he_bias_rows(pk, mb, x.h0l, W("constb"), W("hidl"), st));
-        CK(launch_gemm_nt(W("FE"), mb.Nhe, 2 * D, W("W1f"), x.h0l, nullptr, W("hidl"), W("hidl"), 1, st, prof));
-        CK(launch_rowdot_pm(W("hidl"), mb.Nhe, x.h0l, PR(P.land_w[1]), W("z_he"), st));
+        CK(launch_he_bias_rows(pk, mb, x.h0l, W(S_CONSTB), W(S_HIDL), st));
+        CK(launch_gemm_nt(W(S_FE), mb.Nhe, 2 * D, W(S_W1F), x.h0l, nullptr, W(S_HIDL), W(S_HIDL), 1, st, prof));
     }
-    if (mb.Nrn > 0) {
-        CK(launch_road_gather(pk, mb, D, HL, W("XR"), st));
-        CK(launch_gemm_nt(W("XR"), mb.Nrn, D, PR(P.road_w[0]), x.h0r, PR(P.road_b0), nullptr, W("hidr"), 1, st, prof));
-        CK(launch_rowdot_pm(W("hidr"), mb.Nrn, x.h0r, PR(P.road_w[1]), W("z_rn"), st));
+    if (road) {
+        CK(launch_road_gather(pk, mb, D, HL, W(S_XR), st));
+        CK(launch_gemm_nt(W(S_XR), mb.Nrn, D, PR(P.road_w[0]), x.h0r, PR(P.road_b0), nullptr, W(S_HIDR), 1, st, prof));
     }
-    CK(launch_pointer_fwd(pk, mb, W("z_he"), W("z_rn"), W("p_he"), W("p_rn"), logp_dev, ent_dev, W("lse"), st));
-    // the entropy is needed again by the backward: keep a copy next to lse
-    UPAMD_HIP(hipMemcpyAsync(W("entk"), ent_dev, sizeof(float) * (size_t)B, hipMemcpyDeviceToDevice, st));
+    // second (bias-free) Linear + masked softmax + log-prob / entropy in one kernel; the entropy is kept for the backward
+    CK(launch_pointer_fwd2(pk, mb, W(S_HIDL), PR(P.land_w[1]), x.h0l, W(S_HIDR), PR(P.road_w[1]), x.h0r, W(S_Z_HE), W(S_Z_RN), W(S_P_HE),
+                           W(S_P_RN), logp_dev, ent_dev, W(S_LSE), W(S_ENTK), st));
     return UPAMD_OK;
 }
 
@@ -455,171 +521,181 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     const PackedView pk = make_view(packed_dev, *layout);
     MbView mb = make_mb(*mbp);
     float *ws = static_cast<float *>(ws_dev);
-    auto W = [&](const std::string &n) { return ws + pl.off.at(n); };
-    mb.rows = reinterpret_cast<const int32_t *>(W("rows"));     // written by the forward of this minibatch
+    auto W = [&](int slot) { return ws + pl.off[slot]; };
+    mb.rows = reinterpret_cast<const int32_t *>(W(S_ROWS));     // written by the forward of this minibatch
     auto PR = [&](int idx) { return prm + P.off(idx); };
     auto GR = [&](int idx) { return grads + P.off(idx); };
     Profiler *prof = &eng->prof;
-    const Lin lin{st, prof, W("slabs"), W("wt")};
     const float *Win = PR(P.inproj_w);
     const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
     float *gWin = GR(P.inproj_w), *gbin = GR(P.inproj_b);
-    const float *HL = W("H" + std::to_string(x.L));
+    const float *HL = W(S_H + x.L);
+    const bool land = mb.Nhe > 0, road = mb.Nrn > 0;
+    const ChainDims cd = chain_dims(d, x, B);
+    Reducer red1, red2;             // reduction #1: everything independent; #2: what must follow the collapsed-product gradients
+    red1.st = st; red2.st = st;
+    int S = 1;
 
-    UPAMD_HIP(hipMemsetAsync(W("dWkk"), 0, sizeof(float) * (size_t)(W("zero_end") - W("dWkk")), st));      // every accumulate-into scratch
-    // ---- value head
-    float *dzA = W("dzA"), *dzB = W("dzB");
+    // ---- 1. per-sample chain, the part after the attention: value head, numerical encoder, out-projection, Wvv
     {
-        const float *dz = dvalue_dev;     // dz of the last layer is the seed itself ([B,1])
-        int64_t ldz = 1;
-        for (int i = d.n_value - 1; i >= 0; --i) {
-            const int N = d.value_hidden[i];
-            const int K = (i == 0) ? x.Wp : d.value_hidden[i - 1];
-            const float *Xin = (i == 0) ? W("SV") : W("V" + std::to_string(i));
-            if (i < d.n_value - 1) CK(launch_tanh_bwd(const_cast<float *>(dz), W("V" + std::to_string(i + 1)), (int64_t)B * N, st));
-            // first layer: SV rows are Wp wide (zero padded); only the W real columns of the gradient are kept
-            CK(lin.tn_acc(dz, ldz, B, N, Xin, K, K, GR(P.value_w[i]), GR(P.value_b[i]), i == 0 ? x.W : K));
-            float *dnext = (dz == dzA) ? dzB : dzA;
-            CK(lin.nn(dz, ldz, B, N, i == 0 ? W("Vw0p") : PR(P.value_w[i]), K, dnext, K));
-            dz = dnext;
-            ldz = K;
-        }
-        if (dz != dzA) UPAMD_HIP(hipMemcpyAsync(dzA, dz, sizeof(float) * (size_t)B * x.Wp, hipMemcpyDeviceToDevice, st));
+        ChainBwdPost a;
+        memset(&a, 0, sizeof(a));
+        a.d = cd; a.dvalue = dvalue_dev;
+        for (int i = 1; i < d.n_value; ++i) a.V[i] = W(S_V + i);
+        for (int i = 0; i <= d.n_num; ++i) a.U[i] = W(S_U + i);
+        for (int i = 0; i < d.n_value; ++i) { a.Wv[i] = PR(P.value_w[i]); a.dAv[i] = W(S_DAV + i); }
+        for (int i = 0; i < d.n_num; ++i) { a.Wn[i] = PR(P.num_w[i]); a.dAn[i] = W(S_DAN + i); }
+        a.Wo = PR(P.outproj_w); a.Wvv = W(S_WVV);
+        a.dSV = W(S_DSV); a.datt = W(S_DATT); a.dov = W(S_DO); a.ds = W(S_DS);
+        CK(launch_chain_bwd_post(a, st));
     }
-    const float *dSV = dzA;                          // [B, W] with row stride Wp
+    const float *dSV = W(S_DSV);                     // [B, W] with row stride Wp
     const float *dhbarV = dSV + x.S_last;            // column slices, ld = Wp
     const float *dhbarE = dSV + x.S_last + D;
-
-    // ---- numerical encoder backward
+    // ---- 2. attention core: writes G^L (mean + attention terms) and dr
+    float *G = W(S_G0), *Gn = W(S_G1);
+    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W(S_R), W(S_ALPHA), W(S_S), W(S_DS), dhbarV, x.Wp, G, W(S_DR), st));
+    // ---- 3. pointer heads: softmax backward + second-Linear backward fused
+    CK(launch_pointer_bwd2(pk, mb, W(S_Z_HE), W(S_Z_RN), W(S_P_HE), W(S_P_RN), W(S_ENTK), W(S_LSE), dlogp_dev, dent_dev, W(S_HIDL),
+                           PR(P.land_w[1]), x.h0l, W(S_HIDR), PR(P.road_w[1]), x.h0r, W(S_DZ_HE), W(S_DZ_RN), W(S_DPREL), W(S_DPRER), st));
+    if (land) {
+        int nb = 0;
+        CK(launch_colsum_pm_part(W(S_HIDL), mb.Nhe, x.h0l, W(S_DZ_HE), W(S_CSP0), &nb, st));        // dw2 = sum dz * hid
+        CK(red1.add(W(S_CSP0), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
+        CK(launch_colsum_pm_part(W(S_DPREL), mb.Nhe, x.h0l, nullptr, W(S_CSP1), &nb, st));         // db1 = sum dpre
+        CK(red1.add(W(S_CSP1), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
+        // dW1f = dpre^T FE (mapped back onto [Wa|Wb|Wc|Wd] after the reduction, together with dWbd = dconst^T C)
+        CK(launch_gemm_tn(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), &S, st, prof));
+        CK(red1.add(W(S_SLAB_FE), S, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+        CK(launch_he_segsum(pk, mb, x.h0l, W(S_DPREL), W(S_DCONST), st));
+        // dFE = dpre W1f, then the feature backward (dMhe for the last GCN layer, dC from the m*c term)
+        CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
+        CK(launch_he_feat_bwd(pk, mb, D, W(S_FE), W(S_C), W(S_DFE), W(S_DMHE), W(S_DC_HEAD), st));
+    }
+    if (road) {
+        int nb = 0;
+        CK(launch_colsum_pm_part(W(S_HIDR), mb.Nrn, x.h0r, W(S_DZ_RN), W(S_CSP2), &nb, st));
+        CK(red1.add(W(S_CSP2), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
+        CK(launch_colsum_pm_part(W(S_DPRER), mb.Nrn, x.h0r, nullptr, W(S_CSP3), &nb, st));
+        CK(red1.add(W(S_CSP3), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
+        CK(launch_gemm_tn(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), &S, st, prof));
+        CK(red1.add(W(S_SLAB_XR), S, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D));
+        CK(launch_gemm_nt(W(S_DPRER), mb.Nrn, x.h0r, W(S_R1T), D, nullptr, nullptr, W(S_DXR), 0, st, prof));
+        CK(launch_road_scatter_add(pk, mb, D, W(S_DXR), G, st));
+    }
+    // ---- 4. per-sample chain, the part before the graph: dr -> dq1 -> dq0 -> dC (+ the land-use head's two dC terms)
     {
-        float *bufA = W("dnA"), *bufB = W("dnB");
-        // compact the dUlast column slice of dSV into a dense [B, S_last] buffer
-        UPAMD_HIP(hipMemcpy2DAsync(bufA, sizeof(float) * x.S_last, dSV, sizeof(float) * x.Wp, sizeof(float) * x.S_last, B,
-                                   hipMemcpyDeviceToDevice, st));
-        float *dz = bufA;
-        for (int i = d.n_num - 1; i >= 0; --i) {
-            const int N = d.num_hidden[i];
-            const int K = (i == 0) ? x.Fn : d.num_hidden[i - 1];
-            CK(launch_tanh_bwd(dz, W("U" + std::to_string(i + 1)), (int64_t)B * N, st));
-            CK(lin.tn_acc(dz, N, B, N, W("U" + std::to_string(i)), K, K, GR(P.num_w[i]), GR(P.num_b[i])));
-            if (i > 0) {
-                float *dnext = (dz == bufA) ? bufB : bufA;
-                CK(lin.nn(dz, N, B, N, PR(P.num_w[i]), K, dnext, K));
-                dz = dnext;
-            }
-        }
+        ChainBwdPre a;
+        memset(&a, 0, sizeof(a));
+        a.d = cd; a.dr = W(S_DR);
+        a.dconst = land ? W(S_DCONST) : nullptr; a.dC_head = land ? W(S_DC_HEAD) : nullptr;
+        a.WkkT = W(S_WKKT); a.Wiq = Wiq; a.Wq = PR(P.q_w); a.Wbd = W(S_WBD);
+        a.dq1 = W(S_DQ1); a.dq0 = W(S_DQ0); a.dC = W(S_DC);
+        CK(launch_chain_bwd_pre(a, st));
     }
-
-    // ---- attention, dense part (datt compacted so the MFMA path sees aligned rows)
-    UPAMD_HIP(hipMemcpy2DAsync(W("datt"), sizeof(float) * D, dSV + x.S_last + 2 * D, sizeof(float) * x.Wp, sizeof(float) * D, B,
-                               hipMemcpyDeviceToDevice, st));
-    const float *datt = W("datt");
-    CK(lin.tn_acc(datt, D, B, D, W("o"), D, D, GR(P.outproj_w), GR(P.outproj_b)));
-    CK(lin.nn(datt, D, B, D, PR(P.outproj_w), D, W("do"), D));
-    CK(launch_colsum_rm(W("do"), B, D, D, W("dbvv"), st));
-    for (int h = 0; h < x.heads; ++h) {
-        // dWvv[h-slice,:] += do[:,h-slice]^T s[:,h,:]
-        CK(lin.tn_acc(W("do") + h * x.dh, D, B, x.dh, W("s") + (int64_t)h * D, (int64_t)x.heads * D, D,
-                      W("dWvv") + (int64_t)h * x.dh * D, nullptr));
-        // ds[:,h,:] = do[:,h-slice] Wvv[h-slice,:]
-        CK(lin.nn(W("do") + h * x.dh, D, B, x.dh, W("Wvv") + (int64_t)h * x.dh * D, D, W("ds") + (int64_t)h * D,
-                  (int64_t)x.heads * D));
-    }
-    // ---- attention core: writes G^L (mean + attention terms) and dr
-    float *G = W("G0"), *Gn = W("G1");
-    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W("r"), W("alpha"), W("s"), W("ds"), dhbarV, x.Wp, G, W("dr"), st));
-    for (int h = 0; h < x.heads; ++h) {
-        // dq1[:,h-slice] = dr[:,h,:] Wkk[h-slice,:]^T
-        CK(lin.nt(W("dr") + (int64_t)h * D, (int64_t)x.heads * D, B, D, W("Wkk") + (int64_t)h * x.dh * D, D, nullptr, x.dh,
-                  W("dq1") + h * x.dh, D, 0, 1.f));
-        // dWkk[h-slice,:] += q1[:,h-slice]^T dr[:,h,:]
-        CK(lin.tn_acc(W("q1") + h * x.dh, D, B, x.dh, W("dr") + (int64_t)h * D, (int64_t)x.heads * D, D,
-                      W("dWkk") + (int64_t)h * x.dh * D, nullptr));
-    }
-    const float scale = 1.0f / std::sqrt((float)x.dh);
-    CK(launch_scale(W("dq1"), (int64_t)B * D, scale, st));                                  // dpre = dq1 * scale
-    CK(lin.tn_acc(W("dq1"), D, B, D, W("q0"), D, D, gWin, gbin));                            // in_proj, q rows
-    CK(lin.nn(W("dq1"), D, B, D, Wiq, D, W("dq0"), D));
-    CK(lin.tn_acc(W("dq0"), D, B, D, W("C"), D, D, GR(P.q_w), GR(P.q_b)));
-    CK(lin.nn(W("dq0"), D, B, D, PR(P.q_w), D, W("dC"), D));
-    // collapsed products: Wkk = Wik Wk ; Wvv = Wiv Wv ; bvv = Wiv bv + biv
-    CK(lin.nt_acc(W("dWkk"), D, D, D, PR(P.k_w), D, D, gWin + (int64_t)D * D, D));                                   // dWik += dWkk Wk^T
-    CK(lin.tn_acc(Wik, D, D, D, W("dWkk"), D, D, GR(P.k_w), nullptr));                                               // dWk  += Wik^T dWkk
-    CK(lin.nt_acc(W("dWvv"), D, D, D, PR(P.v_w), D, D, gWin + 2LL * D * D, D));                                      // dWiv += dWvv Wv^T
-    CK(launch_smm(D, D, 1, W("dbvv"), 1, 1, PR(P.v_b), 1, 1, nullptr, gWin + 2LL * D * D, D, 1, 0, 1.f, st));         // dWiv += dbvv (x) bv
-    CK(lin.tn_acc(Wiv, D, D, D, W("dWvv"), D, D, GR(P.v_w), nullptr));                                               // dWv  += Wiv^T dWvv
-    CK(launch_smm(1, D, D, W("dbvv"), D, 1, Wiv, D, 1, nullptr, GR(P.v_b), D, 1, 0, 1.f, st));                         // dbv  += Wiv^T dbvv
-    CK(launch_axpy(gbin + 2 * D, W("dbvv"), D, 1.f, st));                                                            // dbiv += dbvv
-
-    // ---- pointer heads
-    CK(launch_pointer_bwd(pk, mb, W("z_he"), W("z_rn"), W("p_he"), W("p_rn"), W("entk"), W("lse"), dlogp_dev, dent_dev,
-                          W("dz_he"), W("dz_rn"), st));
-    int S = 1;
-    if (mb.Nhe > 0) {
-        CK(launch_colsum_pm(W("hidl"), mb.Nhe, x.h0l, W("dz_he"), W("cs_part"), GR(P.land_w[1]), st));          // dw2 += sum dz * hid
-        CK(launch_rowdot_bwd_pm(W("hidl"), mb.Nhe, x.h0l, PR(P.land_w[1]), W("dz_he"), W("dprel"), st));
-        CK(launch_colsum_pm(W("dprel"), mb.Nhe, x.h0l, nullptr, W("cs_part"), GR(P.land_b0), st));
-        // dW1f = dpre^T FE, mapped back onto [Wa|Wb|Wc|Wd] together with dWbd = dconst^T C
-        CK(launch_gemm_tn(W("FE"), 2 * D, W("dprel"), x.h0l, mb.Nhe, W("slabs"), &S, st, prof));
-        CK(launch_reduce_slabs(W("slabs"), S, 2 * D, x.h0l, 1, x.h0l, W("dW1f"), 2 * D, st));
-        CK(launch_he_segsum(pk, mb, x.h0l, W("dprel"), W("dconst"), st));
-        CK(lin.tn_acc(W("dconst"), x.h0l, B, x.h0l, W("C"), D, D, W("dWbd"), nullptr));
-        CK(launch_land_head_w_scatter(W("dW1f"), W("dWbd"), D, x.h0l, GR(P.land_w[0]), st));
-        // dC from the bias term, then dFE = dpre W1f and the feature backward
-        CK(lin.nn(W("dconst"), x.h0l, B, x.h0l, W("Wbd"), D, W("dC_head"), D));
-        CK(launch_axpy(W("dC"), W("dC_head"), (int64_t)B * D, 1.f, st));
-        CK(launch_transpose(W("W1f"), x.h0l, 2 * D, W("W1fT"), st));
-        CK(launch_gemm_nt(W("dprel"), mb.Nhe, x.h0l, W("W1fT"), 2 * D, nullptr, nullptr, W("dFE"), 0, st, prof));
-        CK(launch_he_feat_bwd(pk, mb, D, W("FE"), W("C"), W("dFE"), W("dMhe"), W("dC_head"), st));
-        CK(launch_axpy(W("dC"), W("dC_head"), (int64_t)B * D, 1.f, st));
-    }
-    if (mb.Nrn > 0) {
-        CK(launch_colsum_pm(W("hidr"), mb.Nrn, x.h0r, W("dz_rn"), W("cs_part"), GR(P.road_w[1]), st));
-        CK(launch_rowdot_bwd_pm(W("hidr"), mb.Nrn, x.h0r, PR(P.road_w[1]), W("dz_rn"), W("dprer"), st));
-        CK(launch_colsum_pm(W("dprer"), mb.Nrn, x.h0r, nullptr, W("cs_part"), GR(P.road_b0), st));
-        CK(launch_gemm_tn(W("XR"), D, W("dprer"), x.h0r, mb.Nrn, W("slabs"), &S, st, prof));
-        CK(launch_reduce_slabs(W("slabs"), S, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D, st));
-        CK(launch_transpose(PR(P.road_w[0]), x.h0r, D, W("R1T"), st));
-        CK(launch_gemm_nt(W("dprer"), mb.Nrn, x.h0r, W("R1T"), D, nullptr, nullptr, W("dXR"), 0, st, prof));
-        CK(launch_road_scatter_add(pk, mb, D, W("dXR"), G, st));
-    }
-
-    // ---- GCN layers, last to first
+    // ---- 5. GCN layers, last to first
     for (int l = x.L; l >= 1; --l) {
-        const std::string sl = std::to_string(l), sp = std::to_string(l - 1);
         const bool last = (l == x.L);
-        CK(launch_edge_bwd(pk, mb, D, last, W("PQ" + sl), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp,
-                           (last && mb.Nhe > 0) ? W("dMhe") : nullptr, W("dPQ"), W("dbias_part"), st, prof));
+        CK(launch_edge_bwd(pk, mb, D, last, W(S_PQ + l), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp, (last && land) ? W(S_DMHE) : nullptr,
+                           W(S_DPQ), W(S_DBIAS + l), st, prof));
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
-        CK(launch_reduce_rows_add(W("dbias_part"), B, 2 * D, W("cs" + sl), st));
-        CK(launch_add_p_panels(GR(P.edge_b[l - 1]), W("cs" + sl), D, st));
+        CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
         if (l > 1) {
-            CK(launch_gemm_tn(W("dPQ"), 2 * D, W("H" + sp), D, mb.M, W("slabs"), &S, st, prof));
-            CK(launch_reduce_slabs(W("slabs"), S, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D, st));
-            CK(launch_gemm_nt(W("dPQ"), mb.M, 2 * D, W("WcatT" + sp), D, nullptr, G, Gn, 0, st, prof));
+            CK(launch_gemm_tn(W(S_DPQ), 2 * D, W(S_H + l - 1), D, mb.M, W(S_SLAB_W + l), &S, st, prof));
+            CK(red1.add(W(S_SLAB_W + l), S, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D));
+            CK(launch_gemm_nt(W(S_DPQ), mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
             std::swap(G, Gn);
         } else {
             // layer 1: H_0 = Xp We^T + be, so dWcat_1 = dPQ_1^T H_0 = (dPQ_1^T Xp) We^T + colsum(dPQ_1) (x) be --
-            // two J = 32 reductions over the nodes instead of a full-size weight-gradient GEMM
-            CK(launch_gemm_tn(W("dPQ"), 2 * D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
-            CK(launch_reduce_slabs(W("slabs"), S, 2 * D, 32, 0, 32, W("Tn"), 32, st));
-            CK(lin.nt(W("Tn"), 32, 2 * D, 32, W("We_pad"), 32, nullptr, D, W("dWc1"), D, 0, 1.f));       // Tn We^T
-            CK(launch_smm(2 * D, D, 1, W("cs1"), 1, 1, PR(P.node_b), 1, 1, nullptr, W("dWc1"), D, 1, 0, 1.f, st));
-            CK(launch_reduce_slabs(W("dWc1"), 1, 2 * D, D, 2, D, GR(P.edge_w[0]), 2 * D, st));
+            // a J = 32 reduction over the nodes instead of a full-size weight-gradient GEMM.  Tn = dPQ_1^T Xp
+            CK(launch_gemm_tn(W(S_DPQ), 2 * D, W(S_XP), 32, mb.M, W(S_SLAB_XP1), &S, st, prof));
+            CK(red1.add(W(S_SLAB_XP1), S, 2LL * D * 32, 2 * D, 32, 0, 32, W(S_TN), 32, nullptr, 1));
         }
     }
-    // ---- node encoder.  G^0 = G^1 + dPQ_1 Wcat_1 is never formed (it is only needed for the encoder's own
+    // ---- 6. node encoder.  G^0 = G^1 + dPQ_1 Wcat_1 is never formed (it is only needed for the encoder's own
     // gradients): dWe = G^0^T X = G^1^T X + Wcat_1^T (dPQ_1^T X),  dbe = colsum(G^1) + Wcat_1^T colsum(dPQ_1).
-    // G holds G^1 and "dPQ" holds dPQ_1 here; this replaces a full-size dgrad GEMM by two K = M, J = 32 ones.
-    CK(launch_gemm_tn(G, D, W("Xp"), 32, mb.M, W("slabs"), &S, st, prof));
-    // Xp's column 31 is all ones (gather_inputs), so column 31 of G^1^T Xp is colsum(G^1): straight into dbe
-    CK(launch_reduce_slabs(W("slabs"), S, D, 32, 0, x.F, GR(P.node_w), x.F, st, GR(P.node_b)));
-    // "Tn" = dPQ_1^T Xp and "cs1" = colsum(dPQ_1) come from the l = 1 iteration of the loop above
-    // (split-K: 4 workgroups looping over K = 2D would be pure latency)
-    CK(launch_smm_splitk(D, x.F, 2 * D, W("WcatT0"), 2 * D, 1, W("Tn"), 32, 1, W("slabs"), &S, st));
-    CK(launch_reduce_slabs(W("slabs"), S, D, x.F, 0, x.F, GR(P.node_w), x.F, st));
-    CK(launch_smm_splitk(1, D, 2 * D, W("cs1"), 2 * D, 1, W("WcatT0"), 1, 2 * D, W("slabs"), &S, st));
-    CK(launch_reduce_slabs(W("slabs"), S, 1, D, 0, D, GR(P.node_b), D, st));
-    CK(lin.tn_acc(W("dC"), D, B, D, W("curg"), UPAMD_NODE_PAD, x.F, GR(P.node_w), GR(P.node_b)));
+    // G holds G^1 here.  Xp's column 31 is all ones, so column 31 of G^1^T Xp is colsum(G^1): straight into dbe
+    CK(launch_gemm_tn(G, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), &S, st, prof));
+    CK(red1.add(W(S_SLAB_XP2), S, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b)));
+    // ---- 7. every per-sample weight gradient dY^T X in ONE grouped MFMA launch
+    {
+        TnJobs tj;
+        float *slab = W(S_SLAB_SMALL);
+        int64_t used = 0;
+        struct Pending { Reducer *rd; const float *slab; int S, N, K; float *dst; int ldd, overwrite; };
+        std::vector<Pending> pending;       // the slabs are reduced after the grouped launch that fills them
+        // (A [B][N], X [B][K] | ones) -> dst [N][K] (ld), accumulate or overwrite; bias: X = nullptr
+        auto job = [&](Reducer &rd, const float *A, int64_t lda, int N, const float *X, int64_t ldx, int K, float *dst, int ldd,
+                       int overwrite) -> int {
+            if (tj.n >= TN_MAX_JOBS) return fail(UPAMD_E_LIMIT, "too many per-sample weight-gradient jobs");
+            const int splits = tn_job_splits(B);
+            if (used + (int64_t)splits * N * K > pl.small_slab_floats) return fail(UPAMD_E_WORKSPACE, "small-slab region exhausted");
+            int Sj = 1;
+            CK(tn_add(&tj, A, lda, N, X, ldx, K, B, slab + used, &Sj));
+            pending.push_back(Pending{&rd, slab + used, Sj, N, K, dst, ldd, overwrite});
+            used += (int64_t)Sj * N * K;
+            return 0;
+        };
+        for (int i = 0; i < d.n_value; ++i) {       // value head (value.py:15-34)
+            const int N = d.value_hidden[i];
+            const int K = i == 0 ? x.W : d.value_hidden[i - 1];
+            const float *X = i == 0 ? W(S_SV) : W(S_V + i);
+            CK(job(red1, W(S_DAV + i), N, N, X, i == 0 ? x.Wp : K, K, GR(P.value_w[i]), K, 0));
+            CK(job(red1, W(S_DAV + i), N, N, nullptr, 0, 1, GR(P.value_b[i]), 1, 0));
+        }
+        for (int i = 0; i < d.n_num; ++i) {         // numerical encoder
+            const int N = d.num_hidden[i];
+            const int K = i == 0 ? x.Fn : d.num_hidden[i - 1];
+            CK(job(red1, W(S_DAN + i), N, N, W(S_U + i), K, K, GR(P.num_w[i]), K, 0));
+            CK(job(red1, W(S_DAN + i), N, N, nullptr, 0, 1, GR(P.num_b[i]), 1, 0));
+        }
+        CK(job(red1, W(S_DATT), D, D, W(S_O), D, D, GR(P.outproj_w), D, 0));
+        CK(job(red1, W(S_DATT), D, D, nullptr, 0, 1, GR(P.outproj_b), 1, 0));
+        for (int h = 0; h < x.heads; ++h) {
+            // dWvv[h-slice,:] = do[:,h-slice]^T s[:,h,:] ;  dWkk[h-slice,:] = q1[:,h-slice]^T dr[:,h,:]
+            CK(job(red1, W(S_DO) + h * x.dh, D, x.dh, W(S_S) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWVV) + (int64_t)h * x.dh * D, D, 1));
+            CK(job(red1, W(S_Q1) + h * x.dh, D, x.dh, W(S_DR) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWKK) + (int64_t)h * x.dh * D, D, 1));
+        }
+        CK(job(red1, W(S_DO), D, D, nullptr, 0, 1, W(S_DBVV), 1, 1));
+        CK(job(red1, W(S_DQ1), D, D, W(S_Q0), D, D, gWin, D, 0));                    // in_proj, q rows
+        CK(job(red1, W(S_DQ1), D, D, nullptr, 0, 1, gbin, 1, 0));
+        CK(job(red1, W(S_DQ0), D, D, W(S_C), D, D, GR(P.q_w), D, 0));
+        CK(job(red1, W(S_DQ0), D, D, nullptr, 0, 1, GR(P.q_b), 1, 0));
+        if (land) CK(job(red1, W(S_DCONST), x.h0l, x.h0l, W(S_C), D, D, W(S_DWBD), D, 1));
+        // the current node's pass through the node encoder: after the collapsed-product gradients (same destination)
+        CK(job(red2, W(S_DC), D, D, W(S_CURG), UPAMD_NODE_PAD, x.F, GR(P.node_w), x.F, 0));
+        CK(job(red2, W(S_DC), D, D, nullptr, 0, 1, GR(P.node_b), 1, 0));
+        CK(launch_gtn(tj, st));
+        for (const Pending &q : pending) CK(q.rd->add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
+    }
+    // ---- 8. reduction #1: every split-K slab / partial sum of the step, fixed order
+    CK(red1.flush());
+    // ---- 9. gradients of the prepared parameters mapped back onto the stored ones
+    if (land) {
+        PermJobs pj;
+        int blocks = 0;
+        CK(perm_add(&pj, &blocks, PERM_LAND_SCATTER, W(S_DW1F), W(S_DWBD), GR(P.land_w[0]), nullptr, nullptr, nullptr, x.h0l, D, 0));
+        CK(launch_permute(pj, blocks, st));
+    }
+    {
+        SmmJobs sj;
+        int blocks = 0;
+        // Wkk = Wik Wk:  dWik += dWkk Wk^T,  dWk += Wik^T dWkk
+        CK(smm_add(&sj, &blocks, D, D, D, W(S_DWKK), D, 1, PR(P.k_w), 1, D, nullptr, gWin + (int64_t)D * D, D, 1, 1.f));
+        CK(smm_add(&sj, &blocks, D, D, D, Wik, 1, D, W(S_DWKK), D, 1, nullptr, GR(P.k_w), D, 1, 1.f));
+        // Wvv = Wiv Wv, bvv = Wiv bv + biv:  dWiv += dWvv Wv^T + dbvv (x) bv,  dWv += Wiv^T dWvv,  dbv += Wiv^T dbvv
+        CK(smm_add(&sj, &blocks, D, D, D, W(S_DWVV), D, 1, PR(P.v_w), 1, D, nullptr, gWin + 2LL * D * D, D, 1, 1.f, nullptr, 0, W(S_DBVV), PR(P.v_b)));
+        CK(smm_add(&sj, &blocks, D, D, D, Wiv, 1, D, W(S_DWVV), D, 1, nullptr, GR(P.v_w), D, 1, 1.f));
+        CK(smm_add(&sj, &blocks, 1, D, D, W(S_DBVV), 0, 1, Wiv, D, 1, nullptr, GR(P.v_b), D, 1, 1.f));
+        // first GCN layer: dWcat_1 = Tn We^T + cs1 (x) be;  dWe += Wcat_1^T Tn;  dbe += Wcat_1^T cs1   (Tn = dPQ_1^T Xp)
+        CK(smm_add(&sj, &blocks, 2 * D, D, 32, W(S_TN), 32, 1, W(S_WE_PAD), 1, 32, nullptr, W(S_DWC1), D, 0, 1.f, nullptr, 0, W(S_CS + 1), PR(P.node_b)));
+        CK(smm_add(&sj, &blocks, D, x.F, 2 * D, W(S_WCAT + 0), 1, D, W(S_TN), 32, 1, nullptr, GR(P.node_w), x.F, 1, 1.f));
+        CK(smm_add(&sj, &blocks, 1, D, 2 * D, W(S_CS + 1), 0, 1, W(S_WCAT + 0), D, 1, nullptr, GR(P.node_b), D, 1, 1.f));
+        CK(launch_gsmm(sj, blocks, st));
+    }
+    // ---- 10. reduction #2: dWcat_1 un-permuted into the layer's weight, dbiv += dbvv, the current node's encoder pass
+    CK(red2.add(W(S_DWC1), 1, 0, 2 * D, D, 2, D, GR(P.edge_w[0]), 2 * D));
+    CK(red2.add(W(S_DBVV), 1, 0, 1, D, 0, D, gbin + 2 * D, D));
+    CK(red2.flush());
     return UPAMD_OK;
 }

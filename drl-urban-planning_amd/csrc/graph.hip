@@ -687,4 +687,146 @@ int launch_pointer_bwd(const PackedView &pk, const MbView &mb, const float *z_he
     return 0;
 }
 
+// ---- fused forms: the second (bias-free) Linear of the pointer heads is evaluated inside the softmax kernels -----------
+//   z = w2 . hid[candidate]  (policy.py:19-43: Linear(h0, 1, bias=False) + Flatten), hid panel-major [h0/16][N][16]
+__device__ __forceinline__ float cand_logit(const float *__restrict__ hid, int64_t N, int64_t row, int h0,
+                                            const float *__restrict__ w2) {
+    float z = 0.f;
+    for (int p = 0; p < h0 / 16; ++p) {
+        const float4 *h4 = reinterpret_cast<const float4 *>(hid + ((int64_t)p * N + row) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 h = h4[q];
+            const float *w = w2 + p * 16 + q * 4;
+            z = fmaf(h.x, w[0], z); z = fmaf(h.y, w[1], z); z = fmaf(h.z, w[2], z); z = fmaf(h.w, w[3], z);
+        }
+    }
+    return z;
+}
+
+__global__ __launch_bounds__(256) void pointer_fwd2_kernel(PackedView pk, MbView mb, const float *__restrict__ hidl,
+                                                           const float *__restrict__ w2l, int h0l,
+                                                           const float *__restrict__ hidr, const float *__restrict__ w2r,
+                                                           int h0r, float *__restrict__ z_he, float *__restrict__ z_rn,
+                                                           float *__restrict__ p_he, float *__restrict__ p_rn,
+                                                           float *__restrict__ logp, float *__restrict__ ent,
+                                                           float *__restrict__ lse_out, float *__restrict__ ent_keep) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= mb.B) return;
+    const int lane = threadIdx.x & 63;
+    const int32_t *m = META(mb.idx[b]);
+    const int stage = m[4];
+    const int cnt = stage == 0 ? m[2] : (stage == 1 ? m[3] : 0);
+    if (stage > 1 || cnt == 0) {
+        // stage 2 rows: log_prob = entropy = 0 (policy.py:90-91); a row without any valid candidate: every logit is the
+        // pad constant, whose logsumexp is absorbed in fp32, so the reference's normalised logits are all 0
+        if (lane == 0) { logp[b] = 0.f; ent[b] = 0.f; lse_out[b] = 0.f; ent_keep[b] = 0.f; }
+        return;
+    }
+    const bool land = stage == 0;
+    const int64_t off = land ? mb.he_off[b] : mb.rn_off[b];
+    const int64_t NC = land ? mb.Nhe : mb.Nrn;
+    const float *hid = land ? hidl : hidr;
+    const float *w2 = land ? w2l : w2r;
+    const int h0 = land ? h0l : h0r;
+    float *z = (land ? z_he : z_rn) + off;
+    float *pp = (land ? p_he : p_rn) + off;
+    float mx = -INFINITY;
+    for (int i = lane; i < cnt; i += 64) {
+        const float zi = cand_logit(hid, NC, off + i, h0, w2);
+        z[i] = zi;                                 // kept for the backward (re-read below by the SAME lane only)
+        mx = fmaxf(mx, zi);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < cnt; i += 64) sum += expf(z[i] - mx);
+    sum = wave_sum(sum);
+    const float lse = mx + logf(sum);
+    float pz = 0.f;
+    for (int i = lane; i < cnt; i += 64) {
+        const float lp = z[i] - lse;
+        const float p = expf(lp);
+        pp[i] = p;
+        pz += p * lp;
+    }
+    pz = wave_sum(pz);
+    if (lane == 0) {
+        const int a = m[5];
+        const float za = a >= 0 ? cand_logit(hid, NC, off + a, h0, w2) : -4294967296.0f;    // recomputed: another lane wrote z[a]
+        logp[b] = za - lse;
+        ent[b] = -pz;
+        ent_keep[b] = -pz;
+        lse_out[b] = lse;
+    }
+}
+
+int launch_pointer_fwd2(const PackedView &pk, const MbView &mb, const float *hidl, const float *w2l, int h0l, const float *hidr,
+                        const float *w2r, int h0r, float *z_he, float *z_rn, float *p_he, float *p_rn, float *logp, float *ent,
+                        float *lse, float *ent_keep, hipStream_t st) {
+    hipLaunchKernelGGL(pointer_fwd2_kernel, dim3((mb.B + 3) / 4), dim3(256), 0, st, pk, mb, hidl, w2l, h0l, hidr, w2r, h0r, z_he,
+                       z_rn, p_he, p_rn, logp, ent, lse, ent_keep);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// dz_k = dlogp (delta_ka - p_k) - dent p_k (log p_k + H);  dpre[k'] = dz * w2[k'] * (1 - hid[k']^2)  (panel-major, in place
+// of the separate rowdot-backward pass)
+__global__ __launch_bounds__(256) void pointer_bwd2_kernel(PackedView pk, MbView mb, const float *__restrict__ z_he,
+                                                           const float *__restrict__ z_rn, const float *__restrict__ p_he,
+                                                           const float *__restrict__ p_rn, const float *__restrict__ ent,
+                                                           const float *__restrict__ lse, const float *__restrict__ dlogp,
+                                                           const float *__restrict__ dent, const float *__restrict__ hidl,
+                                                           const float *__restrict__ w2l, int h0l,
+                                                           const float *__restrict__ hidr, const float *__restrict__ w2r,
+                                                           int h0r, float *__restrict__ dz_he, float *__restrict__ dz_rn,
+                                                           float *__restrict__ dprel, float *__restrict__ dprer) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= mb.B) return;
+    const int lane = threadIdx.x & 63;
+    const int32_t *m = META(mb.idx[b]);
+    const int stage = m[4];
+    if (stage > 1) return;
+    const bool land = stage == 0;
+    const int cnt = land ? m[2] : m[3];
+    const int64_t off = land ? mb.he_off[b] : mb.rn_off[b];
+    const int64_t NC = land ? mb.Nhe : mb.Nrn;
+    const float *z = (land ? z_he : z_rn) + off;
+    const float *pp = (land ? p_he : p_rn) + off;
+    float *dz = (land ? dz_he : dz_rn) + off;
+    const float *hid = land ? hidl : hidr;
+    const float *w2 = land ? w2l : w2r;
+    float *dpre = land ? dprel : dprer;
+    const int h0 = land ? h0l : h0r;
+    const float gl = dlogp[b], ge = dent[b], H = ent[b], ls = lse[b];
+    const int a = m[5];
+    for (int i = lane; i < cnt; i += 64) {
+        const float p = pp[i];
+        float v = -gl * p - ge * p * ((z[i] - ls) + H);
+        if (i == a) v += gl;
+        dz[i] = v;
+        for (int pnl = 0; pnl < h0 / 16; ++pnl) {
+            const int64_t o = ((int64_t)pnl * NC + off + i) * 16;
+            const float4 *h4 = reinterpret_cast<const float4 *>(hid + o);
+            float4 *d4 = reinterpret_cast<float4 *>(dpre + o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 h = h4[q];
+                const float *w = w2 + pnl * 16 + q * 4;
+                d4[q] = make_float4(v * w[0] * (1.f - h.x * h.x), v * w[1] * (1.f - h.y * h.y), v * w[2] * (1.f - h.z * h.z),
+                                    v * w[3] * (1.f - h.w * h.w));
+            }
+        }
+    }
+}
+
+int launch_pointer_bwd2(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn, const float *p_he,
+                        const float *p_rn, const float *ent, const float *lse, const float *dlogp, const float *dent,
+                        const float *hidl, const float *w2l, int h0l, const float *hidr, const float *w2r, int h0r, float *dz_he,
+                        float *dz_rn, float *dprel, float *dprer, hipStream_t st) {
+    hipLaunchKernelGGL(pointer_bwd2_kernel, dim3((mb.B + 3) / 4), dim3(256), 0, st, pk, mb, z_he, z_rn, p_he, p_rn, ent, lse, dlogp,
+                       dent, hidl, w2l, h0l, hidr, w2r, h0r, dz_he, dz_rn, dprel, dprer);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace upamd

@@ -116,7 +116,80 @@ int launch_pointer_bwd(const PackedView &pk, const MbView &mb, const float *z_he
                        const float *p_he, const float *p_rn, const float *ent, const float *lse, const float *dlogp,
                        const float *dent, float *dz_he, float *dz_rn, hipStream_t st);
 
+// ---- chain.hip: fused small kernels (job tables are passed BY VALUE as kernel arguments, <= 4 KB each) ---------------
+enum { PERM_PAD_COLS = 0, PERM_TRANSPOSE, PERM_WCAT, PERM_LAND_HEAD, PERM_LAND_SCATTER };
+constexpr int PERM_MAX_JOBS = 32, SMM_MAX_JOBS = 20, TN_MAX_JOBS = 44, RED_MAX_JOBS = 56;
+struct PermJob { const float *src, *src2; float *dst, *dst2, *dst3, *dst4; int kind, rows, cols, aux, blk_begin, pad_; };
+struct PermJobs { int n = 0; PermJob j[PERM_MAX_JOBS]; };
+int perm_add(PermJobs *P, int *blocks, int kind, const float *src, const float *src2, float *dst, float *dst2, float *dst3,
+             float *dst4, int rows, int cols, int aux);
+int launch_permute(const PermJobs &P, int blocks, hipStream_t st);
+
+struct SmmJob { const float *A, *B, *bias, *u, *v; float *C, *CT; int64_t sa0, sa1, sb0, sb1, ldc, ldct; int I, J, K, accumulate;
+                float scale; int blk_begin, tiles_j, pad_; };
+struct SmmJobs { int n = 0; SmmJob j[SMM_MAX_JOBS]; };
+// C[i*ldc + j] (=|+=) scale * (sum_k A[i*sa0 + k*sa1] B[k*sb0 + j*sb1] + bias[j]) + u[i] v[j];  CT (optional) = C^T
+int smm_add(SmmJobs *P, int *blocks, int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, const float *B, int64_t sb0,
+            int64_t sb1, const float *bias, float *C, int64_t ldc, int accumulate, float scale, float *CT = nullptr,
+            int64_t ldct = 0, const float *u = nullptr, const float *v = nullptr);
+int launch_gsmm(const SmmJobs &P, int blocks, hipStream_t st);
+
+struct ChainDims {
+    int B, D, heads, dh, F, Fn, n_num, num_hidden[UPAMD_MAX_MLP], n_value, value_hidden[UPAMD_MAX_MLP];
+    int S_last, W, Wp, h0l, maxnum, maxval, maxdim;
+    float scale;        // 1 / sqrt(D / heads)
+};
+struct ChainFwdPre {
+    ChainDims d; PackedView pk; MbView mb;
+    int32_t *rows; float *Xp;
+    const float *WnT[UPAMD_MAX_MLP], *bn[UPAMD_MAX_MLP];      // [K][N] transposed weights
+    const float *WeT, *be, *WqT, *bq, *WiqT, *biq, *Wkk, *WbdT, *b1l;
+    float *U[UPAMD_MAX_MLP + 1], *curg, *C, *q0, *q1, *r, *constb;
+};
+struct ChainFwdPost {
+    ChainDims d; const int32_t *rows;
+    const float *s, *hbarV, *hbarE, *Ulast, *WvvT, *bvv, *WoT, *bo, *WvT[UPAMD_MAX_MLP], *bv[UPAMD_MAX_MLP];
+    float *o, *att, *SV, *V[UPAMD_MAX_MLP + 1], *value;
+};
+struct ChainBwdPost {
+    ChainDims d;
+    const float *dvalue, *V[UPAMD_MAX_MLP + 1], *U[UPAMD_MAX_MLP + 1];
+    const float *Wv[UPAMD_MAX_MLP], *Wn[UPAMD_MAX_MLP], *Wo, *Wvv;      // [N][K] weights as stored
+    float *dAv[UPAMD_MAX_MLP], *dAn[UPAMD_MAX_MLP], *dSV, *datt, *dov, *ds;
+};
+struct ChainBwdPre {
+    ChainDims d;
+    const float *dr, *dconst, *dC_head, *WkkT, *Wiq, *Wq, *Wbd;
+    float *dq1, *dq0, *dC;
+};
+int launch_chain_fwd_pre(const ChainFwdPre &a, hipStream_t st);
+int launch_chain_fwd_post(const ChainFwdPost &a, hipStream_t st);
+int launch_chain_bwd_post(const ChainBwdPost &a, hipStream_t st);
+int launch_chain_bwd_pre(const ChainBwdPre &a, hipStream_t st);
+
+struct TnJob { const float *A, *X; float *slab; int64_t lda, ldx; int N, K, rows, tiles_n, tiles_k, splits, chunk, wave_begin; };
+struct TnJobs { int n = 0; int total_waves = 0; TnJob j[TN_MAX_JOBS]; };
+int tn_job_splits(int rows);
+// slab[split][n][k] = sum_rows A[row*lda + n] * X[row*ldx + k]   (X == nullptr: ones, K = 1)
+int tn_add(TnJobs *P, const float *A, int64_t lda, int N, const float *X, int64_t ldx, int K, int rows, float *slab, int *S_out);
+int launch_gtn(const TnJobs &P, hipStream_t st);
+
+struct RedJob { const float *slab; float *dst, *dst2; int64_t sstride; int S, I, J, mode, jkeep, ldd, overwrite, blk_begin; };
+struct RedJobs { int n = 0; RedJob j[RED_MAX_JOBS]; };
+int red_add(RedJobs *P, int *blocks, const float *slab, int S, int64_t sstride, int I, int J, int mode, int jkeep, float *dst,
+            int ldd, float *dst2 = nullptr, int overwrite = 0);
+int launch_greduce(const RedJobs &P, int blocks, hipStream_t st);
+
+int launch_pointer_fwd2(const PackedView &pk, const MbView &mb, const float *hidl, const float *w2l, int h0l, const float *hidr,
+                        const float *w2r, int h0r, float *z_he, float *z_rn, float *p_he, float *p_rn, float *logp, float *ent,
+                        float *lse, float *ent_keep, hipStream_t st);
+int launch_pointer_bwd2(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn, const float *p_he,
+                        const float *p_rn, const float *ent, const float *lse, const float *dlogp, const float *dent,
+                        const float *hidl, const float *w2l, int h0l, const float *hidr, const float *w2r, int h0r, float *dz_he,
+                        float *dz_rn, float *dprel, float *dprer, hipStream_t st);
+
 // ---- dense.hip -------------------------------------------------------------------------
+int launch_colsum_pm_part(const float *X, int64_t rows, int cols, const float *w, float *part, int *nblk_out, hipStream_t st);
 // C[i*ldc + j] (=|+=) act( sum_k A[i*sa0 + k*sa1] * B[k*sb0 + j*sb1] + bias[j] ) * out_scale
 int launch_smm(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, const float *B, int64_t sb0,
                int64_t sb1, const float *bias, float *C, int64_t ldc, int accumulate, int act_tanh, float out_scale,
