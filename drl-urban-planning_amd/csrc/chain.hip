@@ -120,50 +120,59 @@ int perm_add(PermJobs *P, int *blocks, int kind, const float *src, const float *
 
 // ------------------------------------------------------------------------------------------ grouped small matmul
 // C[i*ldc + j] (=|+=) scale * ( sum_k A[i*sa0 + k*sa1] * B[k*sb0 + j*sb1] + bias[j] ) + u[i] * v[j]
-// 64 x 64 output tile per workgroup, 4 x 4 per thread, K staged through LDS in steps of 16 (same tile code as smm_kernel).
 __global__ __launch_bounds__(256) void gsmm_kernel(SmmJobs P) {
-    __shared__ __attribute__((aligned(16))) float As[16][68];
-    __shared__ __attribute__((aligned(16))) float Bs[16][68];
+    // 32 x 32 output tile per workgroup (2 x 2 per thread): these products are a few MFLOP each, so the tile is sized for
+    // workgroup count (a D x D product at D = 256 fills 64 CUs), not for reuse
+    __shared__ __attribute__((aligned(16))) float As[32][34];
+    __shared__ __attribute__((aligned(16))) float Bs[32][34];
     const int k = find_job(P.j, P.n, (int)blockIdx.x, &SmmJob::blk_begin);
     const SmmJob &J = P.j[k];
     const int t = (int)blockIdx.x - J.blk_begin;
-    const int i0 = (t / J.tiles_j) * 64, j0 = (t % J.tiles_j) * 64;
+    const int i0 = (t / J.tiles_j) * 32, j0 = (t % J.tiles_j) * 32;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int I = J.I, Jn = J.J, K = J.K;
-    float acc[4][4] = {};
-    const bool a_k_fast = (J.sa1 == 1), b_j_fast = (J.sb1 == 1);
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    const int sa0 = (int)J.sa0, sa1 = (int)J.sa1, sb0 = (int)J.sb0, sb1 = (int)J.sb1;
+    const float *__restrict__ A = J.A, *__restrict__ B = J.B;
+    float acc[2][2] = {};
+    const bool a_k_fast = (sa1 == 1), b_j_fast = (sb1 == 1);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        float ra[4], rb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {           // all eight loads of the step in flight before the LDS commit
+            const int e = tid + 256 * q;
+            int ai, ak, bj, bk;
+            if (a_k_fast) { ak = e & 31; ai = e >> 5; } else { ai = e & 31; ak = e >> 5; }
+            if (b_j_fast) { bj = e & 31; bk = e >> 5; } else { bk = e & 31; bj = e >> 5; }
+            const int gi = i0 + ai, gk = k0 + ak, gj = j0 + bj, gk2 = k0 + bk;
+            ra[q] = (gi < I && gk < K) ? A[gi * sa0 + gk * sa1] : 0.f;
+            rb[q] = (gj < Jn && gk2 < K) ? B[gk2 * sb0 + gj * sb1] : 0.f;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = tid + 256 * q;
             int ai, ak, bj, bk;
-            if (a_k_fast) { ak = e & 15; ai = e >> 4; } else { ai = e & 63; ak = e >> 6; }
-            if (b_j_fast) { bj = e & 63; bk = e >> 6; } else { bk = e & 15; bj = e >> 4; }
-            const int gi = i0 + ai, gk = k0 + ak;
-            As[ak][ai] = (gi < I && gk < K) ? J.A[gi * J.sa0 + gk * J.sa1] : 0.f;
-            const int gj = j0 + bj, gk2 = k0 + bk;
-            Bs[bk][bj] = (gj < Jn && gk2 < K) ? J.B[gk2 * J.sb0 + gj * J.sb1] : 0.f;
+            if (a_k_fast) { ak = e & 31; ai = e >> 5; } else { ai = e & 31; ak = e >> 5; }
+            if (b_j_fast) { bj = e & 31; bk = e >> 5; } else { bk = e & 31; bj = e >> 5; }
+            As[ak][ai] = ra[q];
+            Bs[bk][bj] = rb[q];
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const float4 a = *reinterpret_cast<const float4 *>(&As[kk][ty * 4]);
-            const float4 b = *reinterpret_cast<const float4 *>(&Bs[kk][tx * 4]);
-            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = fmaf(av[x], bv[y], acc[x][y]);
+        for (int kk = 0; kk < 32; ++kk) {
+            const float2 a = *reinterpret_cast<const float2 *>(&As[kk][ty * 2]);
+            const float2 b = *reinterpret_cast<const float2 *>(&Bs[kk][tx * 2]);
+            acc[0][0] = fmaf(a.x, b.x, acc[0][0]); acc[0][1] = fmaf(a.x, b.y, acc[0][1]);
+            acc[1][0] = fmaf(a.y, b.x, acc[1][0]); acc[1][1] = fmaf(a.y, b.y, acc[1][1]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int gi = i0 + ty * 4 + x;
+    for (int x = 0; x < 2; ++x) {
+        const int gi = i0 + ty * 2 + x;
         if (gi >= I) continue;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int gj = j0 + tx * 4 + y;
+        for (int y = 0; y < 2; ++y) {
+            const int gj = j0 + tx * 2 + y;
             if (gj >= Jn) continue;
             float v = acc[x][y];
             if (J.bias) v += J.bias[gj];
@@ -187,8 +196,8 @@ int smm_add(SmmJobs *P, int *blocks, int I, int Jn, int K, const float *A, int64
     J.sa0 = sa0; J.sa1 = sa1; J.sb0 = sb0; J.sb1 = sb1; J.ldc = ldc; J.ldct = ldct;
     J.I = I; J.J = Jn; J.K = K; J.accumulate = accumulate; J.scale = scale;
     J.blk_begin = *blocks;
-    J.tiles_j = (Jn + 63) / 64;
-    *blocks += ((I + 63) / 64) * J.tiles_j;
+    J.tiles_j = (Jn + 31) / 32;
+    *blocks += ((I + 31) / 32) * J.tiles_j;
     return 0;
 }
 
@@ -216,9 +225,21 @@ __device__ __forceinline__ void lin_rows(const float *__restrict__ Mat, int ld, 
             const float b = bias ? bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = b;
-#pragma unroll 4
-            for (int k = 0; k < K; ++k) {
-                const float w = Mat[(int64_t)k * ld + n];
+            const float *mp = Mat + n;
+            int k = 0;
+            for (; k + 16 <= K; k += 16) {          // 16 independent (coalesced) weight loads in flight, then the FMAs
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = mp[(int64_t)(k + u) * ld];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float4 i0 = *reinterpret_cast<const float4 *>(in + (k + u) * R), i1 = *reinterpret_cast<const float4 *>(in + (k + u) * R + 4);
+                    acc[0] = fmaf(w[u], i0.x, acc[0]); acc[1] = fmaf(w[u], i0.y, acc[1]); acc[2] = fmaf(w[u], i0.z, acc[2]); acc[3] = fmaf(w[u], i0.w, acc[3]);
+                    acc[4] = fmaf(w[u], i1.x, acc[4]); acc[5] = fmaf(w[u], i1.y, acc[5]); acc[6] = fmaf(w[u], i1.z, acc[6]); acc[7] = fmaf(w[u], i1.w, acc[7]);
+                }
+            }
+            for (; k < K; ++k) {
+                const float w = mp[(int64_t)k * ld];
                 const float4 i0 = *reinterpret_cast<const float4 *>(in + k * R), i1 = *reinterpret_cast<const float4 *>(in + k * R + 4);
                 acc[0] = fmaf(w, i0.x, acc[0]); acc[1] = fmaf(w, i0.y, acc[1]); acc[2] = fmaf(w, i0.z, acc[2]); acc[3] = fmaf(w, i0.w, acc[3]);
                 acc[4] = fmaf(w, i1.x, acc[4]); acc[5] = fmaf(w, i1.y, acc[5]); acc[6] = fmaf(w, i1.z, acc[6]); acc[7] = fmaf(w, i1.w, acc[7]);
@@ -234,7 +255,20 @@ __device__ __forceinline__ void lin_rows(const float *__restrict__ Mat, int ld, 
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
         if (n < N) {
-            for (int k = g; k < K; k += G) {
+            int k = g;
+            for (; k + 7 * G < K; k += 8 * G) {
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = Mat[(int64_t)(k + u * G) * ld + n];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float *ip = in + (k + u * G) * R;
+                    const float4 i0 = *reinterpret_cast<const float4 *>(ip), i1 = *reinterpret_cast<const float4 *>(ip + 4);
+                    acc[0] = fmaf(w[u], i0.x, acc[0]); acc[1] = fmaf(w[u], i0.y, acc[1]); acc[2] = fmaf(w[u], i0.z, acc[2]); acc[3] = fmaf(w[u], i0.w, acc[3]);
+                    acc[4] = fmaf(w[u], i1.x, acc[4]); acc[5] = fmaf(w[u], i1.y, acc[5]); acc[6] = fmaf(w[u], i1.z, acc[6]); acc[7] = fmaf(w[u], i1.w, acc[7]);
+                }
+            }
+            for (; k < K; k += G) {
                 const float w = Mat[(int64_t)k * ld + n];
                 const float4 i0 = *reinterpret_cast<const float4 *>(in + k * R), i1 = *reinterpret_cast<const float4 *>(in + k * R + 4);
                 acc[0] = fmaf(w, i0.x, acc[0]); acc[1] = fmaf(w, i0.y, acc[1]); acc[2] = fmaf(w, i0.z, acc[2]); acc[3] = fmaf(w, i0.w, acc[3]);
@@ -637,7 +671,15 @@ __global__ __launch_bounds__(256) void gtn_kernel(TnJobs P) {
     const int r0 = split * J.chunk, r1 = min(J.rows, r0 + J.chunk);
     const int n = tn * 32 + l31, kk = tk * 32 + l31;
     const bool nok = n < J.N, kok = kk < J.K;
-    const float *ap = J.A + n, *xp = J.X ? J.X + kk : nullptr;
+    // per-lane column offsets and the stride between consecutive rows.  Row-major: [rows][ld];  panel-major:
+    // [cols/16][rows][16].  Out-of-range lanes / rows read a valid (clamped) address and are zeroed by `am` / `xm`: the
+    // loads stay unconditional, so all 16 of an iteration are in flight together.
+    const int nc = nok ? n : 0, kc = kok ? kk : 0;
+    const int64_t acol = J.a_pm ? ((int64_t)(nc >> 4) * J.rows_total * 16 + (nc & 15)) : nc;
+    const int64_t xcol = J.x_pm ? ((int64_t)(kc >> 4) * J.rows_total * 16 + (kc & 15)) : kc;
+    const int64_t astep = J.a_pm ? 16 : J.lda, xstep = J.x_pm ? 16 : J.ldx;
+    const float *ap = J.A + acol, *xp = J.X ? J.X + xcol : nullptr;
+    const int last = r1 - 1;
     f32x16c acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -646,12 +688,15 @@ __global__ __launch_bounds__(256) void gtn_kernel(TnJobs P) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int row = r + 2 * u + lhi;
-            const bool in = row < r1;
-            av[u] = (in && nok) ? ap[(int64_t)row * J.lda] : 0.f;
-            xv[u] = (in && kok) ? (xp ? xp[(int64_t)row * J.ldx] : 1.f) : 0.f;
+            const int rc = row < r1 ? row : last;
+            av[u] = ap[(int64_t)rc * astep];
+            xv[u] = xp ? xp[(int64_t)rc * xstep] : 1.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], xv[u], acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) {
+            const bool in = r + 2 * u + lhi < r1;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((in && nok) ? av[u] : 0.f, (in && kok) ? xv[u] : 0.f, acc, 0, 0, 0);
+        }
     }
     float *slab = J.slab + (int64_t)split * J.N * J.K;
 #pragma unroll
@@ -661,20 +706,22 @@ __global__ __launch_bounds__(256) void gtn_kernel(TnJobs P) {
     }
 }
 
-int tn_job_splits(int rows) {
-    int s = (rows + 255) / 256;          // >= 256 rows per split
-    if (s > 16) s = 16;
+int tn_job_splits(int64_t rows) {
+    int64_t s = (rows + 255) / 256;      // >= 256 rows per split
+    if (s > 512) s = 512;
     if (s < 1) s = 1;
-    return s;
+    return (int)s;
 }
 
-int tn_add(TnJobs *P, const float *A, int64_t lda, int N, const float *X, int64_t ldx, int K, int rows, float *slab, int *S_out) {
+int tn_add(TnJobs *P, const float *A, int64_t lda, int N, const float *X, int64_t ldx, int K, int64_t rows, float *slab, int *S_out,
+           int a_pm, int x_pm) {
     if (P->n >= TN_MAX_JOBS) return fail(UPAMD_E_LIMIT, "too many grouped weight-gradient jobs");
     TnJob &J = P->j[P->n++];
-    J.A = A; J.X = X; J.slab = slab; J.lda = lda; J.ldx = ldx; J.N = N; J.K = K; J.rows = rows;
+    J.A = A; J.X = X; J.slab = slab; J.lda = lda; J.ldx = ldx; J.N = N; J.K = K; J.rows = (int)rows; J.rows_total = rows;
+    J.a_pm = a_pm; J.x_pm = x_pm;
     J.tiles_n = (N + 31) / 32; J.tiles_k = (K + 31) / 32;
     J.splits = tn_job_splits(rows);
-    J.chunk = ((rows + J.splits - 1) / J.splits + 15) / 16 * 16;
+    J.chunk = (int)(((rows + J.splits - 1) / J.splits + 15) / 16 * 16);
     J.wave_begin = P->total_waves;
     P->total_waves += J.tiles_n * J.tiles_k * J.splits;
     *S_out = J.splits;

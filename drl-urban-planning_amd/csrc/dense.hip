@@ -131,7 +131,7 @@ int launch_colsum_rm(const float *X, int rows, int cols, int64_t ld, float *dst,
 }
 
 // panel-major weighted column sums, two deterministic stages
-constexpr int CS_ROWS = 2048;
+constexpr int CS_ROWS = 512;       // rows per workgroup: enough workgroups for a 50 k-candidate minibatch to fill the chip
 int colsum_pm_blocks(int64_t rows) { return (int)((rows + CS_ROWS - 1) / CS_ROWS); }
 
 __global__ __launch_bounds__(256) void colsum_pm_kernel(const float *__restrict__ X, int64_t rows, int cols,

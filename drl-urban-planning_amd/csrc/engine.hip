@@ -151,11 +151,14 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     add(S_DPRER, NR * x.h0r); add(S_DXR, NR * D);
     add(S_G0, M * D); add(S_G1, M * D); add(S_DPQ, M * 2 * D);
     // split-K slabs: every weight-gradient product keeps its own region until the step's final reduction
-    for (int l = 2; l <= x.L; ++l) add(S_SLAB_W + l, (int64_t)tn_splits(2 * D, D, M) * 2 * D * D);
-    add(S_SLAB_XP1, (int64_t)tn_splits(2 * D, 32, M) * 2 * D * 32);
-    add(S_SLAB_XP2, (int64_t)tn_splits(D, 32, M) * D * 32);
-    add(S_SLAB_FE, (int64_t)tn_splits(2 * D, x.h0l, NH) * 2 * D * x.h0l);
-    add(S_SLAB_XR, (int64_t)tn_splits(D, x.h0r, NR) * D * x.h0r);
+    auto slab_floats = [](int I, int J, int64_t rows) {
+        return (int64_t)(tn_shape_mfma_ok(I, J) ? tn_splits(I, J, rows) : tn_job_splits(rows)) * I * J;
+    };
+    for (int l = 2; l <= x.L; ++l) add(S_SLAB_W + l, slab_floats(2 * D, D, M));
+    add(S_SLAB_XP1, slab_floats(2 * D, 32, M));
+    add(S_SLAB_XP2, slab_floats(D, 32, M));
+    add(S_SLAB_FE, slab_floats(2 * D, x.h0l, NH));
+    add(S_SLAB_XR, slab_floats(D, x.h0r, NR));
     // per-sample weight gradients (grouped dY^T X): <= 16 row splits of every per-sample weight (+ the collapsed ones)
     pl->small_slab_floats = 16LL * (P.n_floats + 4LL * D * D + 2LL * D * x.h0l + 4096);
     add(S_SLAB_SMALL, pl->small_slab_floats);
@@ -213,6 +216,19 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
         int _rc = (expr);   \
         if (_rc) return _rc; \
     } while (0)
+
+// slabs[s][I][J] = partial sums of A[rows, I](pm)^T * Bm[rows, J](pm): the tiled split-K MFMA kernel where the shape allows
+// (I % 128 == 0), otherwise one grouped-kernel launch with panel-major operands (narrow models: D = 16 ... 64)
+int node_tn(const float *A, int I, const float *Bm, int J, int64_t rows, float *slabs, int *S_out, hipStream_t st, Profiler *prof) {
+    if (tn_shape_mfma_ok(I, J)) return launch_gemm_tn(A, I, Bm, J, rows, slabs, S_out, st, prof);
+    TnJobs tj;
+    int rc = tn_add(&tj, A, 0, I, Bm, 0, J, rows, slabs, S_out, 1, 1);
+    if (rc) return rc;
+    const int began = prof_begin(prof, "gemm_tn_small", st, 2.0 * (double)rows * I * J, 4.0 * (double)rows * (I + J));
+    rc = launch_gtn(tj, st);
+    prof_end(prof, "gemm_tn_small", st, began);
+    return rc;
+}
 
 // Slab-reduction jobs of a step: flushed as one launch (or several, when the job table would overflow)
 struct Reducer {
@@ -565,7 +581,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_colsum_pm_part(W(S_DPREL), mb.Nhe, x.h0l, nullptr, W(S_CSP1), &nb, st));         // db1 = sum dpre
         CK(red1.add(W(S_CSP1), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
         // dW1f = dpre^T FE (mapped back onto [Wa|Wb|Wc|Wd] after the reduction, together with dWbd = dconst^T C)
-        CK(launch_gemm_tn(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), &S, st, prof));
+        CK(node_tn(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), &S, st, prof));
         CK(red1.add(W(S_SLAB_FE), S, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
         CK(launch_he_segsum(pk, mb, x.h0l, W(S_DPREL), W(S_DCONST), st));
         // dFE = dpre W1f, then the feature backward (dMhe for the last GCN layer, dC from the m*c term)
@@ -578,7 +594,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(red1.add(W(S_CSP2), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
         CK(launch_colsum_pm_part(W(S_DPRER), mb.Nrn, x.h0r, nullptr, W(S_CSP3), &nb, st));
         CK(red1.add(W(S_CSP3), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
-        CK(launch_gemm_tn(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), &S, st, prof));
+        CK(node_tn(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), &S, st, prof));
         CK(red1.add(W(S_SLAB_XR), S, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D));
         CK(launch_gemm_nt(W(S_DPRER), mb.Nrn, x.h0r, W(S_R1T), D, nullptr, nullptr, W(S_DXR), 0, st, prof));
         CK(launch_road_scatter_add(pk, mb, D, W(S_DXR), G, st));
@@ -601,21 +617,21 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
         CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
         if (l > 1) {
-            CK(launch_gemm_tn(W(S_DPQ), 2 * D, W(S_H + l - 1), D, mb.M, W(S_SLAB_W + l), &S, st, prof));
+            CK(node_tn(W(S_DPQ), 2 * D, W(S_H + l - 1), D, mb.M, W(S_SLAB_W + l), &S, st, prof));
             CK(red1.add(W(S_SLAB_W + l), S, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D));
             CK(launch_gemm_nt(W(S_DPQ), mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
             std::swap(G, Gn);
         } else {
             // layer 1: H_0 = Xp We^T + be, so dWcat_1 = dPQ_1^T H_0 = (dPQ_1^T Xp) We^T + colsum(dPQ_1) (x) be --
             // a J = 32 reduction over the nodes instead of a full-size weight-gradient GEMM.  Tn = dPQ_1^T Xp
-            CK(launch_gemm_tn(W(S_DPQ), 2 * D, W(S_XP), 32, mb.M, W(S_SLAB_XP1), &S, st, prof));
+            CK(node_tn(W(S_DPQ), 2 * D, W(S_XP), 32, mb.M, W(S_SLAB_XP1), &S, st, prof));
             CK(red1.add(W(S_SLAB_XP1), S, 2LL * D * 32, 2 * D, 32, 0, 32, W(S_TN), 32, nullptr, 1));
         }
     }
     // ---- 6. node encoder.  G^0 = G^1 + dPQ_1 Wcat_1 is never formed (it is only needed for the encoder's own
     // gradients): dWe = G^0^T X = G^1^T X + Wcat_1^T (dPQ_1^T X),  dbe = colsum(G^1) + Wcat_1^T colsum(dPQ_1).
     // G holds G^1 here.  Xp's column 31 is all ones, so column 31 of G^1^T Xp is colsum(G^1): straight into dbe
-    CK(launch_gemm_tn(G, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), &S, st, prof));
+    CK(node_tn(G, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), &S, st, prof));
     CK(red1.add(W(S_SLAB_XP2), S, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b)));
     // ---- 7. every per-sample weight gradient dY^T X in ONE grouped MFMA launch
     {

@@ -814,6 +814,7 @@ __global__ void gemm_tn_generic_kernel(const float *__restrict__ A, int I, const
 }
 
 static bool tn_use_mfma(int I, int J) { return I % 128 == 0 && J % 32 == 0; }
+bool tn_shape_mfma_ok(int I, int J) { return tn_use_mfma(I, J); }
 
 int tn_splits(int I, int J, int64_t M) {
     if (M <= 0) return 1;

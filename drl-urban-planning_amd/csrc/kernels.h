@@ -81,6 +81,7 @@ bool gemm_tn_mfma_ok(const GemmTN &g);
 int launch_gemm_tn_ex(const GemmTN &g, int *S_out, hipStream_t st, Profiler *prof);
 // slabs[S][I][J] = partial sums over row chunks of A[M,I](pm)^T * Bm[M,J](pm);  returns S via *S_out
 int tn_splits(int I, int J, int64_t M);
+bool tn_shape_mfma_ok(int I, int J);       // the tiled split-K kernel handles I % 128 == 0, J % 32 == 0; other shapes go to gtn_kernel
 int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, float *slabs, int *S_out,
                    hipStream_t st, Profiler *prof);
 // dst (+)= sum_s slabs[s]:  mode 0: dst[i*ldd + j], j < jkeep;  mode 1: dst[j*ldd + i];
@@ -118,7 +119,7 @@ int launch_pointer_bwd(const PackedView &pk, const MbView &mb, const float *z_he
 
 // ---- chain.hip: fused small kernels (job tables are passed BY VALUE as kernel arguments, <= 4 KB each) ---------------
 enum { PERM_PAD_COLS = 0, PERM_TRANSPOSE, PERM_WCAT, PERM_LAND_HEAD, PERM_LAND_SCATTER };
-constexpr int PERM_MAX_JOBS = 32, SMM_MAX_JOBS = 20, TN_MAX_JOBS = 44, RED_MAX_JOBS = 56;
+constexpr int PERM_MAX_JOBS = 32, SMM_MAX_JOBS = 20, TN_MAX_JOBS = 40, RED_MAX_JOBS = 56;
 struct PermJob { const float *src, *src2; float *dst, *dst2, *dst3, *dst4; int kind, rows, cols, aux, blk_begin, pad_; };
 struct PermJobs { int n = 0; PermJob j[PERM_MAX_JOBS]; };
 int perm_add(PermJobs *P, int *blocks, int kind, const float *src, const float *src2, float *dst, float *dst2, float *dst3,
@@ -167,11 +168,14 @@ int launch_chain_fwd_post(const ChainFwdPost &a, hipStream_t st);
 int launch_chain_bwd_post(const ChainBwdPost &a, hipStream_t st);
 int launch_chain_bwd_pre(const ChainBwdPre &a, hipStream_t st);
 
-struct TnJob { const float *A, *X; float *slab; int64_t lda, ldx; int N, K, rows, tiles_n, tiles_k, splits, chunk, wave_begin; };
+struct TnJob { const float *A, *X; float *slab; int64_t lda, ldx, rows_total; int N, K, rows, tiles_n, tiles_k, splits, chunk, wave_begin,
+               a_pm, x_pm; };
 struct TnJobs { int n = 0; int total_waves = 0; TnJob j[TN_MAX_JOBS]; };
-int tn_job_splits(int rows);
+int tn_job_splits(int64_t rows);
 // slab[split][n][k] = sum_rows A[row*lda + n] * X[row*ldx + k]   (X == nullptr: ones, K = 1)
-int tn_add(TnJobs *P, const float *A, int64_t lda, int N, const float *X, int64_t ldx, int K, int rows, float *slab, int *S_out);
+// a_pm / x_pm: the operand is panel-major [cols/16][rows][16] (ld ignored) instead of row-major
+int tn_add(TnJobs *P, const float *A, int64_t lda, int N, const float *X, int64_t ldx, int K, int64_t rows, float *slab, int *S_out,
+           int a_pm = 0, int x_pm = 0);
 int launch_gtn(const TnJobs &P, hipStream_t st);
 
 struct RedJob { const float *slab; float *dst, *dst2; int64_t sstride; int S, I, J, mode, jkeep, ldd, overwrite, blk_begin; };
