@@ -267,7 +267,9 @@ class _HipBackend:
                 if rows.size == 0:
                     out.append(None)
                     continue
-                width = meta[rows, pad_col]
+                # Categorical over the PADDED slots: records are trimmed, their header keeps the original pad sizes
+                width = np.array([packer.record_pads(x[b])[0 if pad_col == packer.M_PADN else 1] if packer.is_record(x[b])
+                                  else meta[b, pad_col] for b in rows])
                 if (width != width[0]).any():
                     raise ValueError('forward(): the rows of one stage must share their pad size to form one '
                                      'Categorical (got %s); use select_action / get_log_prob_entropy for ragged '
@@ -292,6 +294,13 @@ class _HipBackend:
 
 def _on_gpu(module):
     return next(module.parameters()).device.type == 'cuda'
+
+
+def _dense_states(x):
+    """CPU path input: compact wire records (rollout.ActionClient / arenas) expanded to the padded 9-tensor form."""
+    if not any(packer.is_record(s) for s in x):
+        return x
+    return [[torch.from_numpy(a) for a in packer.expand_state(s, padded=True)] if packer.is_record(s) else s for s in x]
 
 
 class UrbanPlanningPolicy(nn.Module):
@@ -322,7 +331,7 @@ class UrbanPlanningPolicy(nn.Module):
             land_dist = None if land is None else torch.distributions.Categorical(logits=land)
             road_dist = None if road is None else torch.distributions.Categorical(logits=road)
             return land_dist, road_dist, stage
-        s_land, s_road, _, land_mask, road_mask, stage = self.shared_net(x)
+        s_land, s_road, _, land_mask, road_mask, stage = self.shared_net(_dense_states(x))
         land_dist = road_dist = None
         is_land, is_road = stage[:, 0].bool(), stage[:, 1].bool()
         if is_land.any():
@@ -377,7 +386,7 @@ class UrbanPlanningValue(nn.Module):
         if _on_gpu(self):
             value, _, _, _ = self._backend[0].run(x, None)
             return value.unsqueeze(1)
-        _, _, state_value, _, _, _ = self.shared_net(x)
+        _, _, state_value, _, _, _ = self.shared_net(_dense_states(x))
         return self.value_head(state_value)
 
 

@@ -136,6 +136,12 @@ def is_record(obj):
         and int(obj[:4].view('<u4')[0]) == _REC_MAGIC
 
 
+def record_pads(record):
+    """(pad_n, pad_e) of the padded state a record was made from."""
+    h = record[:_REC_HEADER.itemsize].view(_REC_HEADER)[0]
+    return int(h['pad_n']), int(h['pad_e'])
+
+
 def expand_state(record, padded=False):
     """Record -> list of the 9 arrays.  padded=False: zero-copy views with the trimmed row counts (what pack_replay
     needs); padded=True: fresh arrays of the original pad sizes, equal to the state the record was made from."""

@@ -1,0 +1,321 @@
+"""Rollout side of the drop-in: what sits between the env workers and the HIP update.
+
+The reference samples with ``num_threads`` forked CPU workers (khrylib/rl/agents/agent.py:75-100); every env step
+evaluates the policy on ONE padded state on the CPU (urban_planning/agents/urban_planning_agent.py:49-91,
+policy.py:67-85), stores the padded 9-field state (~148 KB) in a python ``Memory`` (khrylib/utils/memory.py:4-23)
+and finally pickles the whole memory through a ``multiprocessing.Queue`` (agent.py:92-97).  After the update moved to
+the GPU that is where an iteration's time goes, so this module provides, each usable on its own:
+
+* ``ActionServer`` / ``ActionClient`` -- batched action serving: the networks stay on the GPU in the learner process;
+  workers write their state as a compact record into a shared-memory slot, the server answers every pending request
+  (B ~ number of workers) with ONE HIP forward and samples on the device (``Categorical.sample`` / arg-max, exactly the
+  reference's ``select_action`` semantics).  A client has the ``select_action(x, mean_action)`` signature of
+  ``policy_net``, so a worker just swaps the object it calls.  The per-iteration greedy evaluation
+  (urban_planning_agent.py:402-467) becomes one more client that runs while the sampling workers do -- no
+  CPU<->GPU round trip of the model, no serial eval phase.
+* ``SharedArena`` / ``ArenaMemory`` -- the worker-side replay container: ``push`` has ``Memory.push``'s signature but
+  appends the state as a compact record (packer.compact_state, lossless, ~2.5x smaller) to a shared-memory arena
+  instead of a python list, so nothing is pickled at the end of sampling: the worker reports a row count.
+* ``RecordBatch`` -- the learner-side ``TrajBatchDisc`` (urban_planning/utils/tools.py:4-16) over arenas (or plain
+  memories): ``states`` are zero-copy record views that ``pack_replay`` consumes directly.
+
+INTEGRATION.md shows the three-line patches of ``sample_worker`` / ``sample``.
+"""
+import multiprocessing
+import multiprocessing.connection
+import threading
+import time
+from multiprocessing import shared_memory
+
+import numpy as np
+import torch
+
+from . import packer
+
+_ALIGN = 64
+
+
+def _align(x, a=_ALIGN):
+    return (x + a - 1) // a * a
+
+
+def _to_record(state):
+    if packer.is_record(state):
+        return state
+    return packer.compact_state([f.detach().cpu().numpy() if isinstance(f, torch.Tensor) else f for f in state])
+
+
+# ------------------------------------------------------------------------------------------------ action serving
+class ActionClient:
+    """Worker-side handle: ``select_action(x, mean_action)`` like ``UrbanPlanningPolicy.select_action``."""
+
+    MAX_ROWS = 64
+
+    def __init__(self, shm_name, index, slot_bytes, conn):
+        self._shm_name, self.index, self.slot_bytes, self.conn = shm_name, index, slot_bytes, conn
+        self._shm = None
+        self.type = 'discrete'
+
+    def _slot(self):
+        if self._shm is None:               # attached lazily, i.e. in the process that uses the client
+            self._shm = shared_memory.SharedMemory(name=self._shm_name)
+        base = self.index * self.slot_bytes
+        return np.ndarray((self.slot_bytes,), dtype=np.uint8, buffer=self._shm.buf, offset=base)
+
+    def select_action(self, x, mean_action=False):
+        if len(x) > self.MAX_ROWS:
+            raise ValueError('at most %d states per request' % self.MAX_ROWS)
+        slot = self._slot()
+        cursor = _align(8 * self.MAX_ROWS)
+        sizes = []
+        for s in x:
+            rec = _to_record(s)
+            if cursor + rec.size > self.slot_bytes:
+                raise ValueError('state records of one request exceed the %d-byte slot' % self.slot_bytes)
+            slot[cursor:cursor + rec.size] = rec
+            sizes.append(int(rec.size))
+            cursor = _align(cursor + rec.size)
+        self.conn.send((sizes, bool(mean_action)))
+        status = self.conn.recv()
+        if status != 'ok':
+            raise RuntimeError('action server: %s' % status)
+        act = slot[:8 * len(x)].view(np.float32).reshape(len(x), 2).copy()
+        return torch.from_numpy(act)
+
+    def close(self):
+        if self._shm is not None:
+            self._shm.close()
+            self._shm = None
+
+
+class ActionServer:
+    """Owns the request slots; ``serve_once`` answers everything that is pending with one batched forward."""
+
+    def __init__(self, policy_net, num_clients, slot_bytes=1 << 20, linger_s=0.0002, mp_context=None):
+        self.policy_net = policy_net
+        self.num_clients, self.slot_bytes, self.linger_s = num_clients, _align(slot_bytes), linger_s
+        ctx = mp_context or multiprocessing.get_context('fork')
+        self.shm = shared_memory.SharedMemory(create=True, size=num_clients * self.slot_bytes)
+        self.pipes = [ctx.Pipe(duplex=True) for _ in range(num_clients)]
+        self._server_ends = [p[0] for p in self.pipes]
+        self._index_of = {id(c): i for i, c in enumerate(self._server_ends)}
+        self.stats = dict(batches=0, requests=0, rows=0, max_rows=0, busy_s=0.0)
+        self._thread = None
+        self._stop = threading.Event()
+
+    def client(self, i):
+        return ActionClient(self.shm.name, i, self.slot_bytes, self.pipes[i][1])
+
+    def _slot(self, i):
+        return np.ndarray((self.slot_bytes,), dtype=np.uint8, buffer=self.shm.buf, offset=i * self.slot_bytes)
+
+    def serve_once(self, timeout=0.05):
+        """Waits up to ``timeout`` for a request, lingers ``linger_s`` for the other workers' requests to arrive, then
+        answers all of them with one forward.  Returns the number of requests answered."""
+        live = [c for c in self._server_ends if not c.closed]
+        ready = multiprocessing.connection.wait(live, timeout)
+        if not ready:
+            return 0
+        if self.linger_s > 0:
+            time.sleep(self.linger_s)
+        reqs = []                                   # (client index, conn, sizes, mean)
+        for conn in live:
+            try:
+                if conn.poll(0):
+                    sizes, mean = conn.recv()
+                    reqs.append((self._index_of[id(conn)], conn, sizes, mean))
+            except (EOFError, OSError):
+                conn.close()
+        if not reqs:
+            return 0
+        t0 = time.perf_counter()
+        states, owner = [], []
+        for i, conn, sizes, mean in reqs:
+            slot = self._slot(i)
+            cursor = _align(8 * ActionClient.MAX_ROWS)
+            for sz in sizes:
+                states.append(slot[cursor:cursor + sz])
+                owner.append(mean)
+                cursor = _align(cursor + sz)
+        try:
+            actions = self._actions(states, np.asarray(owner, dtype=bool))
+            status = 'ok'
+        except Exception as exc:                    # report to the workers instead of dying silently
+            actions, status = None, '%s: %s' % (type(exc).__name__, exc)
+        row = 0
+        for i, conn, sizes, mean in reqs:
+            if actions is not None:
+                out = actions[row:row + len(sizes)]
+                self._slot(i)[:8 * len(sizes)] = np.ascontiguousarray(out, dtype=np.float32).view(np.uint8).reshape(-1)
+            row += len(sizes)
+            conn.send(status)
+        st = self.stats
+        st['batches'] += 1
+        st['requests'] += len(reqs)
+        st['rows'] += len(states)
+        st['max_rows'] = max(st['max_rows'], len(states))
+        st['busy_s'] += time.perf_counter() - t0
+        return len(reqs)
+
+    def _actions(self, states, mean_rows):
+        """One forward for all rows; per row arg-max (mean_action) or a sample (policy.py:67-85)."""
+        with torch.no_grad():
+            land_dist, road_dist, stage = self.policy_net.forward(states)
+            action = torch.zeros(stage.shape[0], 2, dtype=torch.float32, device=stage.device)
+            mean_t = torch.from_numpy(mean_rows).to(stage.device)
+            for col, dist in ((0, land_dist), (1, road_dist)):
+                if dist is None:
+                    continue
+                sel = stage[:, col].bool()
+                greedy = dist.probs.argmax(dim=1)
+                drawn = dist.sample()
+                action[sel, col] = torch.where(mean_t[sel], greedy, drawn).to(torch.float32)
+        return action.cpu().numpy()
+
+    # ---- background service in the learner process
+    def start(self):
+        if self._thread is None:
+            self._stop.clear()
+            self._thread = threading.Thread(target=self._loop, name='upamd-action-server', daemon=True)
+            self._thread.start()
+        return self
+
+    def _loop(self):
+        while not self._stop.is_set():
+            self.serve_once(timeout=0.02)
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+
+    def close(self):
+        self.stop()
+        for a, b in self.pipes:
+            a.close()
+            b.close()
+        self.shm.close()
+        try:
+            self.shm.unlink()
+        except FileNotFoundError:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------ replay transport
+class SharedArena:
+    """A shared-memory arena one worker appends its rollout to: compact state records + the per-row scalars.
+
+    Layout: int64 header [n_rows, n_bytes] | per-row table f64[cap_rows][6] = (record offset, record size, action0,
+    action1, mask, reward) + exp in a second table | record bytes.  The learner reads it in place."""
+
+    ROW = 7          # offset, size, action0, action1, mask, reward, exp
+
+    def __init__(self, cap_rows, cap_bytes, name=None):
+        self.cap_rows, self.cap_bytes = int(cap_rows), _align(int(cap_bytes))
+        self._table_off = _align(16)
+        self._data_off = _align(self._table_off + 8 * self.ROW * self.cap_rows)
+        total = self._data_off + self.cap_bytes
+        if name is None:
+            self.shm = shared_memory.SharedMemory(create=True, size=total)
+            self.owner = True
+            self.header[:] = 0
+        else:
+            self.shm = shared_memory.SharedMemory(name=name)
+            self.owner = False
+
+    @property
+    def name(self):
+        return self.shm.name
+
+    @property
+    def header(self):
+        return np.ndarray((2,), dtype=np.int64, buffer=self.shm.buf, offset=0)
+
+    @property
+    def table(self):
+        return np.ndarray((self.cap_rows, self.ROW), dtype=np.float64, buffer=self.shm.buf, offset=self._table_off)
+
+    @property
+    def data(self):
+        return np.ndarray((self.cap_bytes,), dtype=np.uint8, buffer=self.shm.buf, offset=self._data_off)
+
+    def reset(self):
+        self.header[:] = 0
+
+    def append(self, state, action, mask, reward, exp):
+        rec = _to_record(state)
+        n, used = int(self.header[0]), int(self.header[1])
+        if n >= self.cap_rows or used + rec.size > self.cap_bytes:
+            raise MemoryError('rollout arena full (%d rows, %d bytes)' % (n, used))
+        self.data[used:used + rec.size] = rec
+        a = np.asarray(action, dtype=np.float64).reshape(-1)
+        self.table[n] = (used, rec.size, a[0], a[1] if a.size > 1 else 0.0, float(mask), float(reward), float(exp))
+        self.header[1] = _align(used + rec.size, 8)
+        self.header[0] = n + 1                      # published last
+
+    def __len__(self):
+        return int(self.header[0])
+
+    def rows(self):
+        """(states as zero-copy record views, actions f32[n,2], masks, rewards, exps) of what has been appended."""
+        n = len(self)
+        t = self.table[:n]
+        data = self.data
+        states = [data[int(o):int(o) + int(s)] for o, s in zip(t[:, 0], t[:, 1])]
+        return states, t[:, 2:4].astype(np.float32), t[:, 4].copy(), t[:, 5].copy(), t[:, 6].copy()
+
+    def close(self, unlink=None):
+        self.shm.close()
+        if self.owner if unlink is None else unlink:
+            try:
+                self.shm.unlink()
+            except FileNotFoundError:
+                pass
+
+
+class ArenaMemory:
+    """Drop-in for khrylib.utils.memory.Memory on the worker side: ``push(state, action, mask, next_state, reward, exp)``
+    appends to the worker's arena (``next_state`` is not kept: ``update_params`` never reads it)."""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def push(self, state, action, mask, next_state, reward, exp):
+        self.arena.append(state, action, mask, reward, exp)
+
+    def __len__(self):
+        return len(self.arena)
+
+
+class RecordBatch:
+    """``TrajBatchDisc`` (urban_planning/utils/tools.py:4-16) over worker arenas and / or plain ``Memory`` objects, in
+    worker order: ``states`` hold compact records (views into the arenas), the per-row arrays are stacked."""
+
+    def __init__(self, memory_list):
+        states, actions, masks, rewards, exps = [], [], [], [], []
+        for m in memory_list:
+            arena = getattr(m, 'arena', m if isinstance(m, SharedArena) else None)
+            if arena is not None:
+                s, a, mk, rw, ex = arena.rows()
+            else:                                    # a khrylib Memory: rows of [state, action, mask, next_state, reward, exp]
+                rows = m.sample()
+                s = [_to_record(r[0]) for r in rows]
+                a = np.stack([np.asarray(r[1], dtype=np.float32).reshape(-1)[:2] for r in rows]) if rows else np.zeros((0, 2), np.float32)
+                mk = np.array([r[2] for r in rows], dtype=np.float64)
+                rw = np.array([r[4] for r in rows], dtype=np.float64)
+                ex = np.array([r[5] for r in rows], dtype=np.float64)
+            states += s
+            actions.append(a)
+            masks.append(mk)
+            rewards.append(rw)
+            exps.append(ex)
+        self.states = states
+        self.actions = np.concatenate(actions) if actions else np.zeros((0, 2), np.float32)
+        self.masks = np.concatenate(masks) if masks else np.zeros(0)
+        self.rewards = np.concatenate(rewards) if rewards else np.zeros(0)
+        self.exps = np.concatenate(exps) if exps else np.zeros(0)
+        self.next_states = None
+
+    def __len__(self):
+        return len(self.states)

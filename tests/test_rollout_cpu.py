@@ -1,0 +1,137 @@
+"""Rollout transport and batched action serving on the CPU path (forked workers, shared memory, pipes): the same
+server object serves the HIP modules on a GPU box (tests/test_gpu_rollout.py)."""
+import multiprocessing as mp
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from drl_urban_planning_amd import packer, rollout, synth
+
+
+def _policy(seed=3, D=16):
+    cfg = helpers.make_cfg(D=D, L=2, max_nodes=64, max_edges=200)
+    policy_net, value_net, ac = helpers.build_product(cfg, seed=seed)
+    ac.load_state_dict(helpers.perturbed_state_dict(ac, seed + 1, scale=0.2))
+    return policy_net, value_net, ac
+
+
+def _states(T, seed, road_fraction=0.4):
+    return synth.make_replay(T, 'hlg', max_nodes=64, max_edges=200, seed=seed, road_fraction=road_fraction, n_range=(20, 55))
+
+
+def _worker(client, pid, n_steps, arena_name, cap_rows, cap_bytes, out_q):
+    """What a patched ``sample_worker`` does per env step: ask the server for an action, push the transition."""
+    arena = rollout.SharedArena(cap_rows, cap_bytes, name=arena_name)
+    memory = rollout.ArenaMemory(arena)
+    rep = _states(n_steps, 100 + pid)
+    greedy = []
+    for t, s in enumerate(rep.states):
+        mean = (t % 3 == 0)
+        a = client.select_action([[torch.from_numpy(f) for f in s]], mean).numpy().squeeze(0)
+        stage = int(np.argmax(s[8]))
+        assert (s[6] if stage == 0 else s[7])[int(a[stage])], 'action outside the mask'
+        assert a[1 - stage] == 0
+        if mean:
+            greedy.append((t, a.copy()))
+        memory.push(s, a, 0 if t == n_steps - 1 else 1, None, 0.5 * t, 1 - int(mean))
+    out_q.put((pid, len(memory), greedy))
+    client.close()
+    arena.close(unlink=False)
+
+
+def test_action_server_and_arena_transport_with_forked_workers():
+    policy_net, value_net, ac = _policy()
+    n_workers, n_steps = 3, 9
+    server = rollout.ActionServer(policy_net, n_workers, slot_bytes=1 << 18).start()
+    arenas = [rollout.SharedArena(64, 1 << 20) for _ in range(n_workers)]
+    ctx = mp.get_context('fork')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(server.client(i), i, n_steps, arenas[i].name, 64, 1 << 20, q)) for i in range(n_workers)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in procs:
+        pid, n, greedy = q.get(timeout=120)
+        results[pid] = (n, greedy)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    server.stop()
+    assert server.stats['requests'] == n_workers * n_steps and server.stats['batches'] <= server.stats['requests']
+    # greedy answers == the module's own select_action(mean_action=True) on the same states
+    for pid, (n, greedy) in results.items():
+        assert n == n_steps
+        rep = _states(n_steps, 100 + pid)
+        for t, a in greedy:
+            want = policy_net.select_action([[torch.from_numpy(f) for f in rep.states[t]]], True).numpy().squeeze(0)
+            assert np.array_equal(a, want)
+    # the learner-side batch: records in place, per-row arrays in worker order; packs identically to the padded states
+    batch = rollout.RecordBatch([rollout.ArenaMemory(a) for a in arenas])
+    assert len(batch) == n_workers * n_steps and all(packer.is_record(s) for s in batch.states)
+    ref_states = sum((_states(n_steps, 100 + pid).states for pid in range(n_workers)), [])
+    for rec, ref in zip(batch.states, ref_states):
+        for a, b in zip(packer.expand_state(rec, padded=True), ref):
+            assert np.array_equal(a, b)
+    assert batch.masks.tolist() == ([1] * (n_steps - 1) + [0]) * n_workers
+    np.testing.assert_array_equal(batch.rewards[:n_steps], 0.5 * np.arange(n_steps))
+    assert set(batch.exps.tolist()) == {0.0, 1.0}
+    pk = packer.pack_replay(batch.states, batch.actions, 23, 52, pin=False)
+    pk0 = packer.pack_replay(ref_states, batch.actions, 23, 52, pin=False)
+    cols = [c for c in range(13) if c not in (packer.M_PADN, packer.M_PADE)]
+    assert np.array_equal(pk.meta[:, cols], pk0.meta[:, cols])
+    server.close()
+    for a in arenas:
+        a.close()
+
+
+def test_server_batches_concurrent_requests_and_reports_errors():
+    policy_net, _, _ = _policy(seed=5)
+    server = rollout.ActionServer(policy_net, 4, slot_bytes=1 << 18, linger_s=0.0)
+    rep = _states(4, 7)
+    import threading
+    out = [None] * 4
+
+    def ask(i):
+        out[i] = server.client(i).select_action([rep.states[i]], True)
+    threads = [threading.Thread(target=ask, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    import time
+    time.sleep(0.3)                       # all four requests are pending before the server looks
+    served = server.serve_once(timeout=1.0)
+    for t in threads:
+        t.join()
+    assert served == 4 and server.stats['batches'] == 1 and server.stats['max_rows'] == 4
+    want = policy_net.select_action([[torch.from_numpy(f) for f in s] for s in rep.states], True)
+    assert torch.equal(torch.cat(out), want)
+    # a request the networks cannot evaluate comes back as an error, the server keeps running
+    # (two states of one stage with different pad sizes cannot form one padded Categorical)
+    other = synth.make_replay(1, 'hlg', max_nodes=80, max_edges=240, seed=7, road_fraction=0.0, n_range=(20, 55)).states[0]
+    same_stage = [s for s in rep.states if s[8][0] == 1][:1] or [_states(1, 8, 0.0).states[0]]
+    err = []
+
+    def ask_bad():
+        try:
+            server.client(0).select_action([same_stage[0], other], True)
+        except RuntimeError as exc:
+            err.append(str(exc))
+    t = threading.Thread(target=ask_bad)
+    t.start()
+    for _ in range(20):
+        if server.serve_once(timeout=0.5):
+            break
+    t.join(timeout=10)
+    assert err and 'action server' in err[0]
+    server.close()
+
+
+def test_arena_overflow_is_loud():
+    arena = rollout.SharedArena(2, 1 << 16)
+    rep = _states(3, 9)
+    for s, a in zip(rep.states[:2], rep.actions[:2]):
+        arena.append(s, a, 1, 0.0, 1)
+    with pytest.raises(MemoryError):
+        arena.append(rep.states[2], rep.actions[2], 1, 0.0, 1)
+    arena.close()
