@@ -10,6 +10,7 @@ __version__ = '0.1.0'
 
 _LAZY = {
     'create_sgnn_model': ('models', 'create_sgnn_model'),
+    'create_mlp_model': ('models', 'create_mlp_model'),
     'ActorCritic': ('models', 'ActorCritic'),
     'PPOUpdater': ('agent', 'PPOUpdater'),
     'HipUpdateMixin': ('agent', 'HipUpdateMixin'),

@@ -382,6 +382,27 @@ __global__ __launch_bounds__(256) void chain_fwd_pre_kernel(ChainFwdPre a) {
     // current node through the node encoder (state_encoder.py:191)
     lin_rows(a.WeT, d.D, d.F, d.D, cur, a.be, Cc, 0, 1.f, part);
     rows_store(a.C, d.D, d.D, b0, nr, Cc);
+    if (d.mlp) {
+        // rl-mlp: mean edge embedding = node_encoder(mean of the selected endpoints' raw features) (state_encoder.py:290,296);
+        // the mean features also become rows [B, 2B) of the node-encoder weight-gradient job, rows [2B, 3B) stay zero
+        for (int i = tid; i < UPAMD_NODE_PAD * R; i += 256) {
+            const int r = i / UPAMD_NODE_PAD, k = i % UPAMD_NODE_PAD;
+            const float v = r < nr ? a.pk.xbar[(int64_t)a.mb.idx[b0 + r] * UPAMD_NODE_PAD + k] : 0.f;
+            cur[k * R + r] = v;
+            if (r < nr) {
+                a.curg[(int64_t)(d.B + b0 + r) * UPAMD_NODE_PAD + k] = v;
+                a.curg[(int64_t)(2 * d.B + b0 + r) * UPAMD_NODE_PAD + k] = 0.f;
+            }
+        }
+        __syncthreads();
+        lin_rows(a.WeT, d.D, d.F, d.D, cur, a.be, q0, 0, 1.f, part);
+        rows_store(a.hbarE, d.D, d.D, b0, nr, q0);
+        if (a.constb) {
+            lin_rows(a.WbdT, d.h0l, d.D, d.h0l, Cc, a.b1l, cb, 0, 1.f, part);
+            rows_store(a.constb, d.h0l, d.h0l, b0, nr, cb);
+        }
+        return;
+    }
     // attention query path (state_encoder.py:150-156 + nn.MultiheadAttention's q in-projection and scaling)
     lin_rows(a.WqT, d.D, d.D, d.D, Cc, a.bq, q0, 0, 1.f, part);
     rows_store(a.q0, d.D, d.D, b0, nr, q0);
@@ -430,10 +451,10 @@ __global__ __launch_bounds__(256) void chain_fwd_post_kernel(ChainFwdPost a) {
     float *v1 = sv + d.Wp * R;                      // [maxval][R]
     float *v2 = v1 + d.maxval * R;
     float *part = v2 + d.maxval * R;                // [256][R]
-    rows_load(a.s, (int64_t)d.heads * d.D, d.heads * d.D, b0, nr, ss);
+    if (!d.mlp) rows_load(a.s, (int64_t)d.heads * d.D, d.heads * d.D, b0, nr, ss);
     __syncthreads();
     // o[i] = bvv[i] + sum_j s[h(i)][j] Wvv[i][j]      (WvvT[j][i])
-    for (int i = tid; i < d.D; i += 256) {
+    for (int i = tid; !d.mlp && i < d.D; i += 256) {
         const int h = i / d.dh;
         float acc[R];
         const float b = a.bvv[i];
@@ -450,9 +471,12 @@ __global__ __launch_bounds__(256) void chain_fwd_post_kernel(ChainFwdPost a) {
         for (int r = 0; r < R; ++r) oo[i * R + r] = acc[r];
     }
     __syncthreads();
-    rows_store(a.o, d.D, d.D, b0, nr, oo);
-    lin_rows(a.WoT, d.D, d.D, d.D, oo, a.bo, att, 0, 1.f, part);
-    rows_store(a.att, d.D, d.D, b0, nr, att);
+    if (!d.mlp) {
+        rows_store(a.o, d.D, d.D, b0, nr, oo);
+        lin_rows(a.WoT, d.D, d.D, d.D, oo, a.bo, att, 0, 1.f, part);
+        rows_store(a.att, d.D, d.D, b0, nr, att);
+    }
+    const int natt = d.mlp ? 0 : d.D;       // rl-mlp: no attended current node in state_value (state_encoder.py:299-300)
     // state_value = [h_num ; mean nodes ; mean edges ; attended current node ; stage]  (state_encoder.py:204-205)
     for (int i = tid; i < d.Wp * R; i += 256) {
         const int r = i / d.Wp, j = i % d.Wp;
@@ -462,8 +486,8 @@ __global__ __launch_bounds__(256) void chain_fwd_post_kernel(ChainFwdPost a) {
             if (j < d.S_last) v = a.Ulast[b * d.S_last + j];
             else if (j < d.S_last + d.D) v = a.hbarV[b * d.D + j - d.S_last];
             else if (j < d.S_last + 2 * d.D) v = a.hbarE[b * d.D + j - d.S_last - d.D];
-            else if (j < d.S_last + 3 * d.D) v = att[(j - d.S_last - 2 * d.D) * R + r];
-            else if (j < d.W) v = (a.rows[b * UPAMD_META_STRIDE + 4] == (j - d.S_last - 3 * d.D)) ? 1.f : 0.f;
+            else if (j < d.S_last + 2 * d.D + natt) v = att[(j - d.S_last - 2 * d.D) * R + r];
+            else if (j < d.W) v = (a.rows[b * UPAMD_META_STRIDE + 4] == (j - d.S_last - 2 * d.D - natt)) ? 1.f : 0.f;
             a.SV[b * d.Wp + j] = v;
         }
         sv[j * R + r] = v;
@@ -553,6 +577,7 @@ __global__ __launch_bounds__(256) void chain_bwd_post_kernel(ChainBwdPost a) {
         }
     }
     __syncthreads();
+    if (d.mlp) return;
     // ---- attention output path: datt -> do = Wo^T datt -> ds[h] = Wvv[h-slice]^T do[h-slice]
     const float *datt = dsv + (d.S_last + 2 * d.D) * R;
     rows_store(a.datt, d.D, d.D, b0, nr, datt);
@@ -591,9 +616,27 @@ __global__ __launch_bounds__(256) void chain_bwd_pre_kernel(ChainBwdPre a) {
     float *gc = g0 + d.D * R;
     float *dcb = gc + d.D * R;                      // [h0l][R]
     float *part = dcb + d.h0l * R;
-    rows_load(a.dr, (int64_t)d.heads * d.D, d.heads * d.D, b0, nr, drr);
+    if (!d.mlp) rows_load(a.dr, (int64_t)d.heads * d.D, d.heads * d.D, b0, nr, drr);
     if (a.dconst) rows_load(a.dconst, d.h0l, d.h0l, b0, nr, dcb);
     __syncthreads();
+    if (d.mlp) {
+        // no query path: dC = dconst Wbd + the land-use head's m*c term; dhbarE goes behind dC (rows [B, 2B))
+        for (int e = tid; e < d.D * R; e += 256) gc[e] = 0.f;
+        __syncthreads();
+        if (a.dconst) {
+            lin_rows(a.Wbd, d.D, d.h0l, d.D, dcb, nullptr, g1, 0, 1.f, part);
+            for (int e = tid; e < d.D * R; e += 256) gc[e] += g1[e];
+            __syncthreads();
+        }
+        for (int i = tid; i < d.D * nr; i += 256) {
+            const int r = i / d.D, n = i % d.D;
+            float v = gc[n * R + r];
+            if (a.dC_head) v += a.dC_head[(int64_t)(b0 + r) * d.D + n];
+            a.dC[(int64_t)(b0 + r) * d.D + n] = v;
+            a.dC[(int64_t)(d.B + b0 + r) * d.D + n] = a.dSV[(int64_t)(b0 + r) * d.Wp + d.S_last + d.D + n];
+        }
+        return;
+    }
     // dq1[i] = scale * sum_j dr[h(i)][j] Wkk[i][j]      (WkkT[j][i])
     for (int i = tid; i < d.D; i += 256) {
         const int h = i / d.dh;

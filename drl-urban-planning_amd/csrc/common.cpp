@@ -21,7 +21,10 @@ int validate_desc(const upamd_model_desc *d) {
     if (d->node_dim <= 0 || d->node_dim > UPAMD_NODE_PAD) return fail(UPAMD_E_INVALID, "node_dim must be in [1,24]");
     if (d->numerical_dim <= 0) return fail(UPAMD_E_INVALID, "numerical_dim must be > 0");
     if (d->D <= 0 || d->D % 16 != 0) return fail(UPAMD_E_INVALID, "gcn_node_dim must be a positive multiple of 16 (got %d)", d->D);
-    if (d->L <= 0 || d->L > 16) return fail(UPAMD_E_INVALID, "num_gcn_layers must be in [1,16]");
+    if (d->encoder != UPAMD_ENCODER_SGNN && d->encoder != UPAMD_ENCODER_MLP) return fail(UPAMD_E_INVALID, "unknown encoder kind %d", d->encoder);
+    const bool mlp = d->encoder == UPAMD_ENCODER_MLP;
+    if (!mlp && (d->L <= 0 || d->L > 16)) return fail(UPAMD_E_INVALID, "num_gcn_layers must be in [1,16]");
+    if (mlp && d->L != 0) return fail(UPAMD_E_INVALID, "the rl-mlp encoder has no GCN layers (L must be 0)");
     if (d->heads <= 0 || d->D % d->heads != 0) return fail(UPAMD_E_INVALID, "gcn_node_dim must be divisible by num_attention_heads");
     auto chk = [&](int n, const int32_t *h, const char *what, bool last_one, bool mult16) -> int {
         if (n <= 0 || n > UPAMD_MAX_MLP) return fail(UPAMD_E_INVALID, "%s: between 1 and %d layers supported", what, UPAMD_MAX_MLP);
@@ -66,10 +69,12 @@ int build_param_layout(const upamd_model_desc *d, ParamLayout *out) {
     }
     P.node_w = add(e + "node_encoder.weight", D, d->node_dim, 0);
     P.node_b = add(e + "node_encoder.bias", D, 1, 0);
+    const bool mlp = d->encoder == UPAMD_ENCODER_MLP;     // MLPStateEncoder (state_encoder.py:217-236): numerical + node encoder only
     for (int l = 0; l < d->L; ++l) {
         P.edge_w.push_back(add(e + "edge_fc_layers." + std::to_string(l) + ".linear_0.weight", D, 2 * D, 0));
         P.edge_b.push_back(add(e + "edge_fc_layers." + std::to_string(l) + ".linear_0.bias", D, 1, 0));
     }
+    if (!mlp) {
     P.inproj_w = add(e + "attention_layer.in_proj_weight", 3 * D, D, 0);
     P.inproj_b = add(e + "attention_layer.in_proj_bias", 3 * D, 1, 0);
     P.outproj_w = add(e + "attention_layer.out_proj.weight", D, D, 0);
@@ -80,7 +85,9 @@ int build_param_layout(const upamd_model_desc *d, ParamLayout *out) {
     P.k_b = add(e + "attention_key_layer.bias", D, 1, 0);
     P.v_w = add(e + "attention_value_layer.weight", D, D, 0);
     P.v_b = add(e + "attention_value_layer.bias", D, 1, 0);
-    prev = 3 * D + d->num_hidden[d->n_num - 1] + 3;   // output_value_size, state_encoder.py:33
+    }
+    // output_value_size: state_encoder.py:33 (sgnn: + the attended current node) / :236 (mlp)
+    prev = (mlp ? 2 : 3) * D + d->num_hidden[d->n_num - 1] + 3;
     for (int i = 0; i < d->n_value; ++i) {
         P.value_w.push_back(add("value_head.linear_" + std::to_string(i) + ".weight", d->value_hidden[i], prev, 0));
         P.value_b.push_back(add("value_head.linear_" + std::to_string(i) + ".bias", d->value_hidden[i], 1, 0));

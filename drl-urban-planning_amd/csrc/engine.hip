@@ -5,6 +5,7 @@
 // (chain.hip), so a training step is ~45 launches instead of ~165: what remains is one launch per big GEMM / message-
 // passing pass plus a handful of grouped kernels.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -59,13 +60,15 @@ struct Dims {
     int Wp;                                  // its row stride in the workspace: W padded to a multiple of 16
     int h0l, h0r;                            // hidden sizes of the two pointer heads
     int maxnum, maxval, maxdim;
+    bool mlp;                                // rl-mlp encoder (UPAMD_ENCODER_MLP)
 };
 
 Dims dims_of(const upamd_model_desc &d) {
     Dims x;
     x.D = d.D; x.L = d.L; x.heads = d.heads; x.dh = d.D / d.heads; x.F = d.node_dim; x.Fn = d.numerical_dim;
+    x.mlp = d.encoder == UPAMD_ENCODER_MLP;
     x.S_last = d.num_hidden[d.n_num - 1];
-    x.W = 3 * d.D + x.S_last + 3;
+    x.W = (x.mlp ? 2 : 3) * d.D + x.S_last + 3;
     x.Wp = (x.W + 15) / 16 * 16;
     x.h0l = d.land_hidden[0];
     x.h0r = d.road_hidden[0];
@@ -86,6 +89,7 @@ ChainDims chain_dims(const upamd_model_desc &d, const Dims &x, int B) {
     for (int i = 0; i < d.n_value; ++i) c.value_hidden[i] = d.value_hidden[i];
     c.S_last = x.S_last; c.W = x.W; c.Wp = x.Wp; c.h0l = x.h0l;
     c.maxnum = x.maxnum; c.maxval = x.maxval; c.maxdim = x.maxdim;
+    c.mlp = x.mlp ? 1 : 0;
     c.scale = 1.0f / std::sqrt((float)x.dh);
     return c;
 }
@@ -126,7 +130,7 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     add(S_XP, 2 * M * 16);
     add(S_U + 0, B * x.Fn);
     for (int i = 0; i < d.n_num; ++i) add(S_U + i + 1, B * d.num_hidden[i]);
-    add(S_CURG, B * UPAMD_NODE_PAD);
+    add(S_CURG, (x.mlp ? 3 : 1) * B * UPAMD_NODE_PAD);      // mlp: + rows of mean edge features + zero rows (node-encoder job)
     add(S_C, B * D);
     for (int l = 0; l <= x.L; ++l) add(S_H + l, M * D);
     for (int l = 1; l <= x.L; ++l) add(S_PQ + l, M * 2 * D);
@@ -143,7 +147,7 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     for (int i = 0; i < d.n_value; ++i) add(S_DAV + i, B * d.value_hidden[i]);
     for (int i = 0; i < d.n_num; ++i) add(S_DAN + i, B * d.num_hidden[i]);
     add(S_DSV, B * x.Wp); add(S_DATT, B * D); add(S_DO, B * D); add(S_DS, B * x.heads * D); add(S_DR, B * x.heads * D);
-    add(S_DQ1, B * D); add(S_DQ0, B * D); add(S_DC, B * D); add(S_DC_HEAD, B * D); add(S_DCONST, B * x.h0l);
+    add(S_DQ1, B * D); add(S_DQ0, B * D); add(S_DC, (x.mlp ? 3 : 1) * B * D); add(S_DC_HEAD, B * D); add(S_DCONST, B * x.h0l);
     add(S_DWKK, (int64_t)D * D); add(S_DWVV, (int64_t)D * D); add(S_DBVV, D);
     add(S_DW1F, 2LL * D * x.h0l); add(S_DWBD, (int64_t)D * x.h0l); add(S_TN, 2LL * D * 32); add(S_DWC1, 2LL * D * D);
     for (int l = 1; l <= x.L; ++l) { add(S_CS + l, 2LL * D); add(S_DBIAS + l, B * 2 * D); }
@@ -183,6 +187,8 @@ PackedView make_view(const void *packed_dev, const upamd_pack_layout &L) {
     v.hinc_ptr = reinterpret_cast<const int32_t *>(b + L.off_hinc_ptr);
     v.hinc_nbr = reinterpret_cast<const uint16_t *>(b + L.off_hinc_nbr);
     v.hinc_he = reinterpret_cast<const uint16_t *>(b + L.off_hinc_he);
+    v.he_sel = reinterpret_cast<const uint16_t *>(b + L.off_he_sel);
+    v.xbar = reinterpret_cast<const float *>(b + L.off_xbar);
     v.numerical = reinterpret_cast<const float *>(b + L.off_numerical);
     v.cur = reinterpret_cast<const float *>(b + L.off_cur);
     v.Fn = L.numerical_dim;
@@ -211,10 +217,24 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
     return 0;
 }
 
-#define CK(expr)            \
-    do {                    \
-        int _rc = (expr);   \
-        if (_rc) return _rc; \
+// UPAMD_DEBUG_SYNC=1: synchronise after every launch and name the one that faulted (debugging aid; off by default)
+static const bool g_debug_sync = getenv("UPAMD_DEBUG_SYNC") && atoi(getenv("UPAMD_DEBUG_SYNC")) != 0;
+static int debug_sync(const char *what) {
+    if (!g_debug_sync) return 0;
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(UPAMD_E_HIP, "device fault after: %s (%s)", what, hipGetErrorString(e));
+    fprintf(stderr, "[upamd] ok: %.90s\n", what);
+    return 0;
+}
+
+#define CK(expr)                                   \
+    do {                                           \
+        int _rc = (expr);                          \
+        if (_rc) return _rc;                       \
+        if (g_debug_sync) {                        \
+            _rc = debug_sync(#expr);               \
+            if (_rc) return _rc;                   \
+        }                                          \
     } while (0)
 
 // slabs[s][I][J] = partial sums of A[rows, I](pm)^T * Bm[rows, J](pm): the tiled split-K MFMA kernel where the shape allows
@@ -415,11 +435,60 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     auto W = [&](int slot) { return ws + pl.off[slot]; };
     auto PR = [&](int idx) { return prm + P.off(idx); };
     Profiler *prof = &eng->prof;
-    const float *Win = PR(P.inproj_w), *bin = PR(P.inproj_b);
+    const float *Win = x.mlp ? prm : PR(P.inproj_w), *bin = x.mlp ? prm : PR(P.inproj_b);      // (unused by the rl-mlp encoder)
     const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
     const float *biq = bin, *biv = bin + 2 * D;
     const bool land = mb.Nhe > 0, road = mb.Nrn > 0;
 
+    if (x.mlp) {
+        // ===== rl-mlp encoder (MLPStateEncoder, state_encoder.py:217-308): node encoder only, pooled means, no attention
+        {
+            PermJobs pj;
+            int blocks = 0;
+            CK(perm_add(&pj, &blocks, PERM_PAD_COLS, PR(P.node_w), nullptr, W(S_WE_PAD), nullptr, nullptr, nullptr, D, x.F, 32));
+            CK(perm_add(&pj, &blocks, PERM_LAND_HEAD, PR(P.land_w[0]), nullptr, W(S_W1F), W(S_WBD), W(S_W1FT), W(S_WBDT), x.h0l, D, 0));
+            CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.road_w[0]), nullptr, W(S_R1T), nullptr, nullptr, nullptr, x.h0r, D, 0));
+            int prev = x.Fn;
+            for (int i = 0; i < d.n_num; ++i) {
+                CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.num_w[i]), nullptr, W(S_WNT + i), nullptr, nullptr, nullptr, d.num_hidden[i], prev, 0));
+                prev = d.num_hidden[i];
+            }
+            prev = x.W;
+            for (int i = 0; i < d.n_value; ++i) {
+                CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.value_w[i]), nullptr, W(S_WVT + i), nullptr, nullptr, nullptr, d.value_hidden[i], prev, 0));
+                prev = d.value_hidden[i];
+            }
+            CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.node_w), nullptr, W(S_WET), nullptr, nullptr, nullptr, D, x.F, 0));
+            CK(launch_permute(pj, blocks, st));
+        }
+        const ChainDims cd = chain_dims(d, x, B);
+        {
+            ChainFwdPre a;
+            memset(&a, 0, sizeof(a));
+            a.d = cd; a.pk = pk; a.mb = mb;
+            a.rows = reinterpret_cast<int32_t *>(W(S_ROWS)); a.Xp = W(S_XP);
+            for (int i = 0; i < d.n_num; ++i) { a.WnT[i] = W(S_WNT + i); a.bn[i] = PR(P.num_b[i]); }
+            a.WeT = W(S_WET); a.be = PR(P.node_b); a.WbdT = W(S_WBDT); a.b1l = PR(P.land_b0);
+            for (int i = 0; i <= d.n_num; ++i) a.U[i] = W(S_U + i);
+            a.curg = W(S_CURG); a.C = W(S_C); a.hbarE = W(S_HBARE);
+            a.constb = land ? W(S_CONSTB) : nullptr;
+            CK(launch_chain_fwd_pre(a, st));
+        }
+        mb.rows = reinterpret_cast<const int32_t *>(W(S_ROWS));
+        CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_WE_PAD), D, PR(P.node_b), nullptr, W(S_H + 0), 0, st, prof));
+        CK(launch_mlp_pool_fwd(pk, mb, D, W(S_H + 0), PR(P.node_b), W(S_C), W(S_HBARV), land ? W(S_FE) : nullptr, st));
+        {
+            ChainFwdPost a;
+            memset(&a, 0, sizeof(a));
+            a.d = cd; a.rows = mb.rows;
+            a.hbarV = W(S_HBARV); a.hbarE = W(S_HBARE); a.Ulast = W(S_U + d.n_num);
+            for (int i = 0; i < d.n_value; ++i) { a.WvT[i] = W(S_WVT + i); a.bv[i] = PR(P.value_b[i]); }
+            a.SV = W(S_SV);
+            for (int i = 1; i < d.n_value; ++i) a.V[i] = W(S_V + i);
+            a.value = value_dev;
+            CK(launch_chain_fwd_post(a, st));
+        }
+    } else {
     // ---- 1. every gather-style parameter preparation in ONE launch
     {
         PermJobs pj;
@@ -487,9 +556,8 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         CK(launch_edge_fwd(pk, mb, D, l == x.L, W(S_PQ + l), PR(P.edge_b[l - 1]), W(S_H + l - 1), W(S_H + l), W(S_HBARV), W(S_HBARE),
                            W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, prof));
     }
-    const float *HL = W(S_H + x.L);
     // ---- 5. attention core, then the per-sample chain after it (out-projection, state_value, value head)
-    CK(launch_attn_fwd(pk, mb, D, x.heads, HL, W(S_R), W(S_ALPHA), W(S_S), st));
+    CK(launch_attn_fwd(pk, mb, D, x.heads, W(S_H + x.L), W(S_R), W(S_ALPHA), W(S_S), st));
     {
         ChainFwdPost a;
         memset(&a, 0, sizeof(a));
@@ -502,6 +570,8 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         a.value = value_dev;
         CK(launch_chain_fwd_post(a, st));
     }
+    }
+    const float *HL = W(S_H + x.L);
     // ---- 6. pointer heads (policy.py:19-65)
     if (land) {
         // factorised first Linear: hid = tanh(FE [Wa+Wd | Wc]^T + ((Wb-Wd) c_b + b1)), the bias rows are
@@ -542,9 +612,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     auto PR = [&](int idx) { return prm + P.off(idx); };
     auto GR = [&](int idx) { return grads + P.off(idx); };
     Profiler *prof = &eng->prof;
-    const float *Win = PR(P.inproj_w);
+    const float *Win = x.mlp ? prm : PR(P.inproj_w);                                           // (unused by the rl-mlp encoder)
     const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
-    float *gWin = GR(P.inproj_w), *gbin = GR(P.inproj_b);
+    float *gWin = x.mlp ? grads : GR(P.inproj_w), *gbin = x.mlp ? grads : GR(P.inproj_b);
     const float *HL = W(S_H + x.L);
     const bool land = mb.Nhe > 0, road = mb.Nrn > 0;
     const ChainDims cd = chain_dims(d, x, B);
@@ -552,6 +622,108 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     red1.st = st; red2.st = st;
     int S = 1;
 
+    if (x.mlp) {
+        // ===== rl-mlp encoder: value head / numerical encoder -> pooled means + pointer heads -> node encoder
+        {
+            ChainBwdPost a;
+            memset(&a, 0, sizeof(a));
+            a.d = cd; a.dvalue = dvalue_dev;
+            for (int i = 1; i < d.n_value; ++i) a.V[i] = W(S_V + i);
+            for (int i = 0; i <= d.n_num; ++i) a.U[i] = W(S_U + i);
+            for (int i = 0; i < d.n_value; ++i) { a.Wv[i] = PR(P.value_w[i]); a.dAv[i] = W(S_DAV + i); }
+            for (int i = 0; i < d.n_num; ++i) { a.Wn[i] = PR(P.num_w[i]); a.dAn[i] = W(S_DAN + i); }
+            a.dSV = W(S_DSV);
+            CK(launch_chain_bwd_post(a, st));
+        }
+        const float *dSVm = W(S_DSV);
+        float *G0 = W(S_G0);
+        CK(launch_pointer_bwd2(pk, mb, W(S_Z_HE), W(S_Z_RN), W(S_P_HE), W(S_P_RN), W(S_ENTK), W(S_LSE), dlogp_dev, dent_dev, W(S_HIDL),
+                               PR(P.land_w[1]), x.h0l, W(S_HIDR), PR(P.road_w[1]), x.h0r, W(S_DZ_HE), W(S_DZ_RN), W(S_DPREL), W(S_DPRER), st));
+        if (land) {
+            int nb = 0;
+            CK(launch_colsum_pm_part(W(S_HIDL), mb.Nhe, x.h0l, W(S_DZ_HE), W(S_CSP0), &nb, st));
+            CK(red1.add(W(S_CSP0), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
+            CK(launch_colsum_pm_part(W(S_DPREL), mb.Nhe, x.h0l, nullptr, W(S_CSP1), &nb, st));
+            CK(red1.add(W(S_CSP1), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
+            CK(node_tn(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), &S, st, prof));
+            CK(red1.add(W(S_SLAB_FE), S, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+            CK(launch_he_segsum(pk, mb, x.h0l, W(S_DPREL), W(S_DCONST), st));
+            CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
+            // a candidate that is not a live edge has the bias as its embedding: its gradient is kept (-> dbe)
+            CK(launch_he_feat_bwd(pk, mb, D, W(S_FE), W(S_C), W(S_DFE), W(S_DMHE), W(S_DC_HEAD), st, 1));
+        }
+        // G^0 = the node mean's share + every candidate's dM at its selected endpoint; rows [2B, 3B) of the node-encoder
+        // job = the per-graph sums of the non-live candidates' dM (bias only: their X rows are zero)
+        CK(launch_mlp_pool_bwd(pk, mb, D, dSVm + x.S_last, x.Wp, land ? W(S_DMHE) : nullptr, G0, W(S_DC) + 2LL * B * D, st));
+        if (road) {
+            int nb = 0;
+            CK(launch_colsum_pm_part(W(S_HIDR), mb.Nrn, x.h0r, W(S_DZ_RN), W(S_CSP2), &nb, st));
+            CK(red1.add(W(S_CSP2), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
+            CK(launch_colsum_pm_part(W(S_DPRER), mb.Nrn, x.h0r, nullptr, W(S_CSP3), &nb, st));
+            CK(red1.add(W(S_CSP3), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
+            CK(node_tn(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), &S, st, prof));
+            CK(red1.add(W(S_SLAB_XR), S, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D));
+            CK(launch_gemm_nt(W(S_DPRER), mb.Nrn, x.h0r, W(S_R1T), D, nullptr, nullptr, W(S_DXR), 0, st, prof));
+            CK(launch_road_scatter_add(pk, mb, D, W(S_DXR), G0, st));
+        }
+        {
+            ChainBwdPre a;
+            memset(&a, 0, sizeof(a));
+            a.d = cd;
+            a.dconst = land ? W(S_DCONST) : nullptr; a.dC_head = land ? W(S_DC_HEAD) : nullptr;
+            a.Wbd = W(S_WBD); a.dSV = dSVm; a.dC = W(S_DC);
+            CK(launch_chain_bwd_pre(a, st));
+        }
+        // node encoder on all nodes: dWe += G^0^T X, dbe += colsum(G^0) (Xp's column of ones)
+        CK(node_tn(G0, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), &S, st, prof));
+        CK(red1.add(W(S_SLAB_XP2), S, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b)));
+        {
+            TnJobs tj;
+            float *slab = W(S_SLAB_SMALL);
+            int64_t used = 0;
+            struct Pending { Reducer *rd; const float *slab; int S, N, K; float *dst; int ldd, overwrite; };
+            std::vector<Pending> pending;
+            auto job = [&](Reducer &rd, const float *A, int64_t lda, int N, const float *X, int64_t ldx, int K, int64_t rows, float *dst,
+                           int ldd, int overwrite) -> int {
+                const int splits = tn_job_splits(rows);
+                if (used + (int64_t)splits * N * K > pl.small_slab_floats) return fail(UPAMD_E_WORKSPACE, "small-slab region exhausted");
+                int Sj = 1;
+                CK(tn_add(&tj, A, lda, N, X, ldx, K, rows, slab + used, &Sj));
+                pending.push_back(Pending{&rd, slab + used, Sj, N, K, dst, ldd, overwrite});
+                used += (int64_t)Sj * N * K;
+                return 0;
+            };
+            for (int i = 0; i < d.n_value; ++i) {
+                const int N = d.value_hidden[i];
+                const int K = i == 0 ? x.W : d.value_hidden[i - 1];
+                const float *X = i == 0 ? W(S_SV) : W(S_V + i);
+                CK(job(red1, W(S_DAV + i), N, N, X, i == 0 ? x.Wp : K, K, B, GR(P.value_w[i]), K, 0));
+                CK(job(red1, W(S_DAV + i), N, N, nullptr, 0, 1, B, GR(P.value_b[i]), 1, 0));
+            }
+            for (int i = 0; i < d.n_num; ++i) {
+                const int N = d.num_hidden[i];
+                const int K = i == 0 ? x.Fn : d.num_hidden[i - 1];
+                CK(job(red1, W(S_DAN + i), N, N, W(S_U + i), K, K, B, GR(P.num_w[i]), K, 0));
+                CK(job(red1, W(S_DAN + i), N, N, nullptr, 0, 1, B, GR(P.num_b[i]), 1, 0));
+            }
+            if (land) CK(job(red1, W(S_DCONST), x.h0l, x.h0l, W(S_C), D, D, B, W(S_DWBD), D, 1));
+            // the node encoder's three per-sample uses in ONE job over 3B rows: [dC ; dhbarE ; non-live dM sums] x
+            // [current node ; mean edge features ; 0]
+            CK(job(red2, W(S_DC), D, D, W(S_CURG), UPAMD_NODE_PAD, x.F, 3LL * B, GR(P.node_w), x.F, 0));
+            CK(job(red2, W(S_DC), D, D, nullptr, 0, 1, 3LL * B, GR(P.node_b), 1, 0));
+            CK(launch_gtn(tj, st));
+            for (const Pending &q : pending) CK(q.rd->add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
+        }
+        CK(red1.flush());
+        if (land) {
+            PermJobs pj;
+            int blocks = 0;
+            CK(perm_add(&pj, &blocks, PERM_LAND_SCATTER, W(S_DW1F), W(S_DWBD), GR(P.land_w[0]), nullptr, nullptr, nullptr, x.h0l, D, 0));
+            CK(launch_permute(pj, blocks, st));
+        }
+        CK(red2.flush());
+        return UPAMD_OK;
+    }
     // ---- 1. per-sample chain, the part after the attention: value head, numerical encoder, out-projection, Wvv
     {
         ChainBwdPost a;

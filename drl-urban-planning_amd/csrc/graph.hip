@@ -510,7 +510,7 @@ int launch_he_segsum(const PackedView &pk, const MbView &mb, int h0, const float
 __global__ __launch_bounds__(256) void he_feat_bwd_kernel(PackedView pk, MbView mb, int NP,
                                                           const float *__restrict__ FE, const float *__restrict__ C,
                                                           const float *__restrict__ dFE, float *__restrict__ dMhe,
-                                                          float *__restrict__ dC_head) {
+                                                          float *__restrict__ dC_head, int keep_dead) {
     __shared__ float part[256];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP, t = mb.idx[b];
     const int32_t *m = META(t);
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void he_feat_bwd_kernel(PackedView pk, MbView 
     const float cc = C[(int64_t)b * D + p * 16 + c];
     for (int q = qg; q < nh; q += 16) {
         const int64_t row = q0 + q;
-        const float live = pk.he_live[m[11] + q] ? 1.f : 0.f;
+        const float live = (keep_dead || pk.he_live[m[11] + q]) ? 1.f : 0.f;      // sgnn: a non-live candidate's message is the constant 0
         const float mm = FE[((int64_t)p * NH + row) * 16 + c];
         const float g1 = dFE[((int64_t)p * NH + row) * 16 + c], g2 = dFE[((int64_t)(NP + p) * NH + row) * 16 + c];
         dMhe[((int64_t)p * NH + row) * 16 + c] = live * (g1 + g2 * cc);
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(256) void he_feat_bwd_kernel(PackedView pk, MbView 
 }
 
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
-                       const float *dFE, float *dMhe, float *dC_head, hipStream_t st) {
-    hipLaunchKernelGGL(he_feat_bwd_kernel, dim3(mb.B * (D / 16)), dim3(256), 0, st, pk, mb, D / 16, FE, C, dFE, dMhe, dC_head);
+                       const float *dFE, float *dMhe, float *dC_head, hipStream_t st, int keep_dead) {
+    hipLaunchKernelGGL(he_feat_bwd_kernel, dim3(mb.B * (D / 16)), dim3(256), 0, st, pk, mb, D / 16, FE, C, dFE, dMhe, dC_head, keep_dead);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }
@@ -683,6 +683,98 @@ int launch_pointer_bwd(const PackedView &pk, const MbView &mb, const float *z_he
                        const float *p_he, const float *p_rn, const float *ent, const float *lse, const float *dlogp,
                        const float *dent, float *dz_he, float *dz_rn, hipStream_t st) {
     hipLaunchKernelGGL(pointer_bwd_kernel, dim3((mb.B + 3) / 4), dim3(256), 0, st, pk, mb, z_he, z_rn, p_he, p_rn, ent, lse, dlogp, dent, dz_he, dz_rn);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// rl-mlp encoder (MLPStateEncoder, state_encoder.py:217-308): no message passing.  h_nodes = node_encoder(x) (H^0);
+// an edge's embedding is node_encoder(features of ONE endpoint) = the H^0 row of that endpoint (a candidate that is not
+// a live edge has zero features: its embedding is the bias).  One workgroup per (graph, 16-column panel).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp_pool_fwd_kernel(PackedView pk, MbView mb, int NP, const float *__restrict__ H0,
+                                                           const float *__restrict__ be, const float *__restrict__ C,
+                                                           float *__restrict__ hbarV, float *__restrict__ FE) {
+    __shared__ float part[256];
+    const int b = blockIdx.x / NP, p = blockIdx.x % NP;
+    const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;
+    const int n = m[0], nh = m[2], D = NP * 16;
+    const int64_t o = m[14], M = mb.M, NH = mb.Nhe, q0 = m[15];
+    const int c = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const uint8_t *nmask = pk.nmask + m[9];
+    const float *Hg = H0 + ((int64_t)p * M + o) * 16;
+    float acc = 0.f;
+    for (int j = slot; j < n; j += 16)
+        if (nmask[j]) acc += Hg[(int64_t)j * 16 + c];
+    part[slot * 16 + c] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += part[q * 16 + threadIdx.x];
+        hbarV[(int64_t)b * D + p * 16 + threadIdx.x] = tot / (float)m[6];
+    }
+    if (FE && nh > 0) {
+        const float cc = C[(int64_t)b * D + p * 16 + c], bias = be[p * 16 + c];
+        for (int q = slot; q < nh; q += 16) {
+            const float mm = pk.he_live[m[11] + q] ? Hg[(int64_t)pk.he_sel[m[11] + q] * 16 + c] : bias;
+            FE[((int64_t)p * NH + q0 + q) * 16 + c] = mm;
+            FE[((int64_t)(NP + p) * NH + q0 + q) * 16 + c] = mm * cc;
+        }
+    }
+}
+
+int launch_mlp_pool_fwd(const PackedView &pk, const MbView &mb, int D, const float *H0, const float *be, const float *C,
+                        float *hbarV, float *FE, hipStream_t st) {
+    hipLaunchKernelGGL(mlp_pool_fwd_kernel, dim3(mb.B * (D / 16)), dim3(256), 0, st, pk, mb, D / 16, H0, be, C, hbarV, FE);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void mlp_pool_bwd_kernel(PackedView pk, MbView mb, int NP, const float *__restrict__ dhbarV,
+                                                           int ld, const float *__restrict__ dMhe, float *__restrict__ G0,
+                                                           float *__restrict__ dbe_extra) {
+    __shared__ float part[256];
+    const int b = blockIdx.x / NP, p = blockIdx.x % NP;
+    const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;
+    const int n = m[0], nh = dMhe ? m[2] : 0, D = NP * 16;
+    const int64_t o = m[14], M = mb.M, NH = mb.Nhe, q0 = m[15];
+    const int c = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const uint8_t *nmask = pk.nmask + m[9];
+    const int32_t *hp = pk.hinc_ptr + m[13];
+    const uint16_t *hhe = pk.hinc_he + 2 * (int64_t)m[11];
+    const float gmean = dhbarV[(int64_t)b * ld + p * 16 + c] / (float)m[6];
+    // node-centric, fixed order: a node sums the candidates that list it AND selected it (a self-loop candidate is listed
+    // twice in a row: counted once)
+    for (int j = slot; j < n; j += 16) {
+        float v = nmask[j] ? gmean : 0.f;
+        if (nh > 0) {
+            const int k0 = hp[j], k1 = hp[j + 1];
+            for (int k = k0; k < k1; ++k) {
+                const int h = hhe[k];
+                if (pk.he_sel[m[11] + h] != j || (k > k0 && hhe[k - 1] == h)) continue;
+                v += dMhe[((int64_t)p * NH + q0 + h) * 16 + c];
+            }
+        }
+        G0[((int64_t)p * M + o + j) * 16 + c] = v;
+    }
+    // candidates that are not live edges: their embedding is the bias
+    float extra = 0.f;
+    for (int q = slot; q < nh; q += 16)
+        if (!pk.he_live[m[11] + q]) extra += dMhe[((int64_t)p * NH + q0 + q) * 16 + c];
+    part[slot * 16 + c] = extra;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += part[q * 16 + threadIdx.x];
+        dbe_extra[(int64_t)b * D + p * 16 + threadIdx.x] = tot;
+    }
+}
+
+int launch_mlp_pool_bwd(const PackedView &pk, const MbView &mb, int D, const float *dhbarV, int ld, const float *dMhe, float *G0,
+                        float *dbe_extra, hipStream_t st) {
+    hipLaunchKernelGGL(mlp_pool_bwd_kernel, dim3(mb.B * (D / 16)), dim3(256), 0, st, pk, mb, D / 16, dhbarV, ld, dMhe, G0, dbe_extra);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

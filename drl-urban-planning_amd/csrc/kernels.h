@@ -22,10 +22,10 @@ struct PackedView {   // device pointers into the packed replay (upamd_pack_layo
     const float *X;
     const uint8_t *nmask;
     const int32_t *rowptr;
-    const uint16_t *inc_nbr, *he_src, *he_dst, *rn_node, *order, *hinc_nbr, *hinc_he;
+    const uint16_t *inc_nbr, *he_src, *he_dst, *rn_node, *order, *hinc_nbr, *hinc_he, *he_sel;
     const int32_t *hinc_ptr;
     const uint8_t *he_live;
-    const float *numerical, *cur;
+    const float *numerical, *cur, *xbar;
     int Fn;
 };
 
@@ -105,7 +105,14 @@ int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, co
                     const float *alpha, const float *s, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL, float *dr,
                     hipStream_t st);
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
-                       const float *dFE, float *dMhe, float *dC_head, hipStream_t st);
+                       const float *dFE, float *dMhe, float *dC_head, hipStream_t st, int keep_dead = 0);
+// rl-mlp encoder (state_encoder.py:284-308): masked node mean of H^0 and the land-use head inputs gathered from H^0 rows
+int launch_mlp_pool_fwd(const PackedView &pk, const MbView &mb, int D, const float *H0, const float *be, const float *C,
+                        float *hbarV, float *FE, hipStream_t st);
+// ... and its backward: G^0 = dhbarV / n_mask on masked nodes + the candidates' dM routed to their selected endpoint;
+// candidates that are not live edges (m == bias) contribute to dbe_extra[b][D]
+int launch_mlp_pool_bwd(const PackedView &pk, const MbView &mb, int D, const float *dhbarV, int ld, const float *dMhe, float *G0,
+                        float *dbe_extra, hipStream_t st);
 int launch_he_bias_rows(const PackedView &pk, const MbView &mb, int h0, const float *constb, float *hid, hipStream_t st);
 int launch_he_segsum(const PackedView &pk, const MbView &mb, int h0, const float *dpre, float *dconst, hipStream_t st);
 int launch_road_gather(const PackedView &pk, const MbView &mb, int D, const float *HL, float *XR, hipStream_t st);
@@ -138,6 +145,7 @@ int launch_gsmm(const SmmJobs &P, int blocks, hipStream_t st);
 struct ChainDims {
     int B, D, heads, dh, F, Fn, n_num, num_hidden[UPAMD_MAX_MLP], n_value, value_hidden[UPAMD_MAX_MLP];
     int S_last, W, Wp, h0l, maxnum, maxval, maxdim;
+    int mlp;            // rl-mlp encoder: no attention path; state_value = [h_num ; mean nodes ; mean edges ; stage]
     float scale;        // 1 / sqrt(D / heads)
 };
 struct ChainFwdPre {
@@ -146,6 +154,7 @@ struct ChainFwdPre {
     const float *WnT[UPAMD_MAX_MLP], *bn[UPAMD_MAX_MLP];      // [K][N] transposed weights
     const float *WeT, *be, *WqT, *bq, *WiqT, *biq, *Wkk, *WbdT, *b1l;
     float *U[UPAMD_MAX_MLP + 1], *curg, *C, *q0, *q1, *r, *constb;
+    float *hbarE;        // mlp: We xbar_E + be  (mean over the live edges of the encoded selected endpoint)
 };
 struct ChainFwdPost {
     ChainDims d; const int32_t *rows;
@@ -161,6 +170,7 @@ struct ChainBwdPost {
 struct ChainBwdPre {
     ChainDims d;
     const float *dr, *dconst, *dC_head, *WkkT, *Wiq, *Wq, *Wbd;
+    const float *dSV;    // mlp: dhbarE (a column slice of dSV) is copied behind dC: rows [B, 2B) of the node-encoder job
     float *dq1, *dq0, *dC;
 };
 int launch_chain_fwd_pre(const ChainFwdPre &a, hipStream_t st);

@@ -177,6 +177,8 @@ extern "C" int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *p
     L.off_hinc_ptr = place((nodes + T) * 4);
     L.off_hinc_nbr = place(2 * he * 2);
     L.off_hinc_he = place(2 * he * 2);
+    L.off_he_sel = place(he * 2);
+    L.off_xbar = place(T * UPAMD_NODE_PAD * 4);
     L.total_bytes = off;
     *layout = L;
     return UPAMD_OK;
@@ -204,6 +206,8 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
     int32_t *hinc_ptr = reinterpret_cast<int32_t *>(base + L.off_hinc_ptr);
     uint16_t *hinc_nbr = reinterpret_cast<uint16_t *>(base + L.off_hinc_nbr);
     uint16_t *hinc_he = reinterpret_cast<uint16_t *>(base + L.off_hinc_he);
+    uint16_t *he_sel = reinterpret_cast<uint16_t *>(base + L.off_he_sel);
+    float *xbar = reinterpret_cast<float *>(base + L.off_xbar);
     const int F = L.node_dim, Fn = L.numerical_dim;
 
     int rc = parallel_for(T, n_threads, [&](int64_t t) -> int {
@@ -218,6 +222,26 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
             for (int c = F; c < UPAMD_NODE_PAD; ++c) dst[c] = 0.f;
             nmask[o_node + v] = s.node_mask[v] ? 1 : 0;
         }
+        // rl-mlp encoder: the endpoint that represents an edge (state_encoder.py:263-282) and the mean of those
+        // endpoints' raw features over the live edges (the encoder is linear, so mean(W x + b) = W mean(x) + b)
+        auto selected = [&](int k) -> int {
+            const int i = (int)s.edge_index[2 * k], j = (int)s.edge_index[2 * k + 1];
+            const float *xj = s.feat + (int64_t)j * F;
+            int best = 0;
+            for (int c = 1; c < std::min(F, UPAMD_MLP_TYPE_COLS); ++c)
+                if (xj[c] > xj[best]) best = c;
+            return best == UPAMD_MLP_FEASIBLE ? j : i;
+        };
+        {
+            double acc[UPAMD_NODE_PAD] = {0};
+            for (int k = 0; k < E; ++k)
+                if (s.edge_mask[k]) {
+                    const float *xs = s.feat + (int64_t)selected(k) * F;
+                    for (int c = 0; c < F; ++c) acc[c] += xs[c];
+                }
+            float *xb = xbar + t * UPAMD_NODE_PAD;
+            for (int c = 0; c < UPAMD_NODE_PAD; ++c) xb[c] = (c < F && e > 0) ? (float)(acc[c] / e) : 0.f;
+        }
         // candidates
         std::vector<int32_t> he_of_slot;
         if (stage == 0) {
@@ -230,6 +254,7 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
                     he_src[o_he + q] = live ? (uint16_t)s.edge_index[2 * k] : 0;
                     he_dst[o_he + q] = live ? (uint16_t)s.edge_index[2 * k + 1] : 0;
                     he_live[o_he + q] = live ? 1 : 0;
+                    he_sel[o_he + q] = live ? (uint16_t)selected(k) : 0;
                     he_slot[o_he + q] = k;
                     ++q;
                 }

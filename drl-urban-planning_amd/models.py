@@ -121,6 +121,48 @@ class SGNNStateEncoder(nn.Module):
         return state_land, h, state_value, land_mask, road_mask, stage
 
 
+class MLPStateEncoder(nn.Module):
+    """Parameter container + CPU forward of the ``rl-mlp`` ablation encoder (state_encoder.py:217-308): numerical
+    encoder + node encoder only -- no message passing, no attention.  An edge is embedded as the node encoder applied to
+    the raw features of ONE endpoint (the second one if that node's type is FEASIBLE, else the first; masked edges have
+    zero features, i.e. embed to the bias)."""
+    NUM_TYPE_COLS = 14        # city_config.NUM_TYPES + 1 (urban_planning/envs/city_config.py:53)
+    FEASIBLE = 1              # city_config.FEASIBLE     (urban_planning/envs/city_config.py:24)
+
+    def __init__(self, cfg, agent):
+        super().__init__()
+        self.cfg = cfg
+        self.agent = agent
+        D = cfg['gcn_node_dim']
+        self.numerical_feature_encoder = _mlp(agent.numerical_feature_size, cfg['state_encoder_hidden_size'],
+                                              first_flatten=True)
+        self.node_encoder = nn.Linear(agent.node_dim, D)
+        self.max_num_nodes = cfg['max_num_nodes']
+        self.max_num_edges = cfg['max_num_edges']
+        self.output_policy_land_use_size = 4 * D
+        self.output_policy_road_size = D
+        self.output_value_size = 2 * D + cfg['state_encoder_hidden_size'][-1] + 3
+
+    def forward(self, x):
+        numerical, nodes, edge_index, cur, node_mask, edge_mask, land_mask, road_mask, stage = SGNNStateEncoder.batch_data(x)
+        h_num = self.numerical_feature_encoder(numerical)
+        F_ = nodes.size(-1)
+        x1 = torch.gather(nodes, 1, edge_index[..., 0].unsqueeze(-1).expand(-1, -1, F_))
+        x2 = torch.gather(nodes, 1, edge_index[..., 1].unsqueeze(-1).expand(-1, -1, F_))
+        second = x2[..., :self.NUM_TYPE_COLS].argmax(-1) == self.FEASIBLE
+        xe = torch.where(second.unsqueeze(-1), x2, x1) * edge_mask.unsqueeze(-1).to(nodes.dtype)
+        h = self.node_encoder(nodes)
+        m = self.node_encoder(xe)
+        c = self.node_encoder(cur.unsqueeze(1))
+        fe, fn = edge_mask.unsqueeze(-1).to(h.dtype), node_mask.unsqueeze(-1).to(h.dtype)
+        mean_e = (m * fe).sum(1) / fe.sum(1)
+        mean_n = (h * fn).sum(1) / fn.sum(1)
+        state_value = torch.cat([h_num, mean_n, mean_e, stage], dim=1)
+        cc = c.expand(-1, m.size(1), -1)
+        state_land = torch.cat([m, cc, m * cc, m - cc], dim=-1)
+        return state_land, h, state_value, land_mask, road_mask, stage
+
+
 class _HipNetwork(torch.autograd.Function):
     """value / log-prob / entropy of a packed minibatch through the native engine."""
 
@@ -194,8 +236,9 @@ class _HipBackend:
         self._engine = None
 
     def desc(self):
+        kind = native.ENCODER_MLP if isinstance(self.shared_net, MLPStateEncoder) else native.ENCODER_SGNN
         return native.make_desc(self.shared_net.cfg, self.policy_cfg, self.value_cfg, self.shared_net.agent.node_dim,
-                                self.shared_net.agent.numerical_feature_size)
+                                self.shared_net.agent.numerical_feature_size, encoder=kind)
 
     def engine(self, device):
         if self._engine is None or self._engine.device != torch.device(device):
@@ -395,6 +438,17 @@ def create_sgnn_model(cfg, agent):
     (``state_encoder_specs``, ``policy_specs``, ``value_specs``); ``agent`` carries ``node_dim``,
     ``numerical_feature_size`` and ``dtype``."""
     shared_net = SGNNStateEncoder(cfg.state_encoder_specs, agent)
+    backend = _HipBackend(shared_net, cfg.policy_specs, cfg.value_specs)
+    policy_net = UrbanPlanningPolicy(cfg.policy_specs, agent, shared_net, backend)
+    value_net = UrbanPlanningValue(cfg.value_specs, agent, shared_net, backend)
+    backend.policy_net, backend.value_net = policy_net, value_net
+    return policy_net, value_net
+
+
+def create_mlp_model(cfg, agent):
+    """Drop-in for urban_planning/models/model.py:22-33 (``--agent rl-mlp``): the same policy / value heads on the
+    ``MLPStateEncoder``; on a GPU device it runs on the same HIP engine (encoder kind UPAMD_ENCODER_MLP)."""
+    shared_net = MLPStateEncoder(cfg.state_encoder_specs, agent)
     backend = _HipBackend(shared_net, cfg.policy_specs, cfg.value_specs)
     policy_net = UrbanPlanningPolicy(cfg.policy_specs, agent, shared_net, backend)
     value_net = UrbanPlanningValue(cfg.value_specs, agent, shared_net, backend)

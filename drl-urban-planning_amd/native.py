@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libupamd.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_MLP = 4
 META_STRIDE = 16
 NODE_PAD = 24
@@ -23,7 +23,7 @@ class ModelDesc(C.Structure):
                 ('n_num', C.c_int32), ('num_hidden', C.c_int32 * MAX_MLP),
                 ('n_land', C.c_int32), ('land_hidden', C.c_int32 * MAX_MLP),
                 ('n_road', C.c_int32), ('road_hidden', C.c_int32 * MAX_MLP),
-                ('n_value', C.c_int32), ('value_hidden', C.c_int32 * MAX_MLP)]
+                ('n_value', C.c_int32), ('value_hidden', C.c_int32 * MAX_MLP), ('encoder', C.c_int32)]
 
 
 class PackLayout(C.Structure):
@@ -34,7 +34,7 @@ class PackLayout(C.Structure):
                 ('off_he_dst', C.c_int64), ('off_he_live', C.c_int64), ('off_he_slot', C.c_int64),
                 ('off_rn_node', C.c_int64), ('off_numerical', C.c_int64), ('off_cur', C.c_int64),
                 ('off_order', C.c_int64), ('off_hinc_ptr', C.c_int64), ('off_hinc_nbr', C.c_int64),
-                ('off_hinc_he', C.c_int64), ('total_bytes', C.c_int64)]
+                ('off_hinc_he', C.c_int64), ('off_he_sel', C.c_int64), ('off_xbar', C.c_int64), ('total_bytes', C.c_int64)]
 
 
 class Minibatch(C.Structure):
@@ -131,16 +131,20 @@ def check(rc, what=''):
         raise RuntimeError('%s failed (%d): %s' % (what or 'native call', rc, msg.decode() if msg else ''))
 
 
-def make_desc(state_encoder_specs, policy_specs, value_specs, node_dim, numerical_dim):
+ENCODER_SGNN, ENCODER_MLP = 0, 1
+
+
+def make_desc(state_encoder_specs, policy_specs, value_specs, node_dim, numerical_dim, encoder=ENCODER_SGNN):
     """Model description from the reference's three spec dicts (hlg.yaml:21-33)."""
-    if state_encoder_specs.get('num_edge_fc_layers', 1) != 1:
+    if encoder == ENCODER_SGNN and state_encoder_specs.get('num_edge_fc_layers', 1) != 1:
         raise NotImplementedError('num_edge_fc_layers > 1 is not supported by the HIP path '
                                   '(every shipped config uses 1)')
     d = ModelDesc()
     d.node_dim, d.numerical_dim = int(node_dim), int(numerical_dim)
+    d.encoder = int(encoder)
     d.D = int(state_encoder_specs['gcn_node_dim'])
-    d.L = int(state_encoder_specs['num_gcn_layers'])
-    d.heads = int(state_encoder_specs['num_attention_heads'])
+    d.L = int(state_encoder_specs['num_gcn_layers']) if encoder == ENCODER_SGNN else 0
+    d.heads = int(state_encoder_specs['num_attention_heads']) if encoder == ENCODER_SGNN else 1
 
     def fill(n_field, arr_field, values):
         values = [int(v) for v in values]

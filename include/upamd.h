@@ -27,7 +27,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define UPAMD_ABI_VERSION 1
+#define UPAMD_ABI_VERSION 2
 
 #define UPAMD_OK 0
 #define UPAMD_E_INVALID (-1)   /* bad argument / unsupported configuration            */
@@ -48,6 +48,12 @@ const char *upamd_last_error(void);
  * Constraints of this build: D % 16 == 0, D % heads == 0, num_edge_fc_layers == 1 (all shipped
  * configs), node_dim <= 24, policy-head hidden sizes are multiples of 16 and end in 1.
  * ------------------------------------------------------------------------------------------ */
+#define UPAMD_ENCODER_SGNN 0   /* SGNNStateEncoder  (urban_planning/models/state_encoder.py:7-214,   --agent rl-sgnn) */
+#define UPAMD_ENCODER_MLP 1    /* MLPStateEncoder   (urban_planning/models/state_encoder.py:217-308, --agent rl-mlp): no
+                                  message passing, no attention; L / heads are ignored                                  */
+#define UPAMD_MLP_TYPE_COLS 14 /* city_config.NUM_TYPES + 1 one-hot type columns                                        */
+#define UPAMD_MLP_FEASIBLE 1   /* city_config.FEASIBLE                                                                  */
+
 typedef struct upamd_model_desc {
     int32_t node_dim;                        /* agent.node_dim (23)                               */
     int32_t numerical_dim;                   /* agent.numerical_feature_size (52)                 */
@@ -62,6 +68,7 @@ typedef struct upamd_model_desc {
     int32_t road_hidden[UPAMD_MAX_MLP];
     int32_t n_value;                         /* len(value_head_hidden_size), last == 1            */
     int32_t value_hidden[UPAMD_MAX_MLP];
+    int32_t encoder;                         /* UPAMD_ENCODER_SGNN | UPAMD_ENCODER_MLP             */
 } upamd_model_desc;
 
 /* Flat fp32 parameter buffer layout.  Tensor names are the reference's de-duplicated
@@ -115,6 +122,11 @@ typedef struct upamd_pack_layout {
     int64_t off_hinc_ptr;  /* int32 [total_nodes + T]   per graph n+1 offsets into the candidate-incidence lists */
     int64_t off_hinc_nbr;  /* u16   [2*total_he]        per node: neighbour across each incident LIVE candidate edge */
     int64_t off_hinc_he;   /* u16   [2*total_he]        ... and that candidate's local index                         */
+    /* inputs of the rl-mlp encoder (urban_planning/models/state_encoder.py:263-282): an edge is represented by the raw
+     * features of ONE endpoint -- the second one if that node's type (arg-max of the first NUM_TYPES+1 = 14 feature
+     * columns) is FEASIBLE (= 1, urban_planning/envs/city_config.py:24,53), else the first one */
+    int64_t off_he_sel;    /* u16   [total_he]          the selected endpoint of every candidate edge               */
+    int64_t off_xbar;      /* f32   [T][UPAMD_NODE_PAD] mean over the live edges of the selected endpoint's features */
     int64_t total_bytes;
 } upamd_pack_layout;
 

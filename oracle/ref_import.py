@@ -31,11 +31,11 @@ def load_reference():
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     import torch  # noqa: F401
-    from urban_planning.models.model import create_sgnn_model, ActorCritic
+    from urban_planning.models.model import create_sgnn_model, create_mlp_model, ActorCritic
     from khrylib.rl.core import estimate_advantages
     from khrylib.rl.agents import AgentPPO
     from urban_planning.agents.urban_planning_agent import UrbanPlanningAgent, tensorfy
-    ns = types.SimpleNamespace(create_sgnn_model=create_sgnn_model, ActorCritic=ActorCritic,
+    ns = types.SimpleNamespace(create_sgnn_model=create_sgnn_model, create_mlp_model=create_mlp_model, ActorCritic=ActorCritic,
                                estimate_advantages=estimate_advantages, AgentPPO=AgentPPO,
                                UrbanPlanningAgent=UrbanPlanningAgent, tensorfy=tensorfy)
     return ns

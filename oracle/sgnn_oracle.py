@@ -127,11 +127,52 @@ def self_attention(P, h_current_node, h_nodes, node_mask, num_heads):
     return out.transpose(0, 1).squeeze(1)
 
 
+MLP_TYPE_COLS = 14        # city_config.NUM_TYPES + 1 (urban_planning/envs/city_config.py:53)
+MLP_FEASIBLE = 1          # city_config.FEASIBLE     (urban_planning/envs/city_config.py:24)
+
+
+def is_mlp_params(P):
+    """The rl-mlp encoder (MLPStateEncoder, state_encoder.py:217-236) has neither edge MLPs nor attention."""
+    return 'shared_net.attention_layer.in_proj_weight' not in P
+
+
+def mlp_encoder_forward(P, x, keep=None):
+    """MLPStateEncoder.forward, state_encoder.py:284-308 (+ compute_edge_features :262-282)."""
+    numerical, node_features, edge_index, cur, node_mask, edge_mask, land_use_mask, road_mask, stage = batch_data(x)
+    E = edge_index.size(1)
+    h = numerical.flatten(1)
+    for key in _seq_keys(P, 'shared_net.numerical_feature_encoder.'):
+        h = torch.tanh(F.linear(h, P[key + '.weight'], P[key + '.bias']))
+    h_numerical = h
+    We, be = P['shared_net.node_encoder.weight'], P['shared_net.node_encoder.bias']
+    Fd = node_features.size(-1)
+    x1 = torch.gather(node_features, 1, edge_index[:, :, 0].unsqueeze(-1).expand(-1, -1, Fd))
+    x2 = torch.gather(node_features, 1, edge_index[:, :, 1].unsqueeze(-1).expand(-1, -1, Fd))
+    second = torch.eq(torch.argmax(x2[:, :, :MLP_TYPE_COLS], dim=-1), MLP_FEASIBLE)
+    edge_features = torch.where(second.unsqueeze(-1).expand_as(x2), x2, x1)
+    edge_features = torch.where(edge_mask.unsqueeze(-1).expand_as(edge_features), edge_features,
+                                torch.zeros_like(edge_features))
+    h_nodes = F.linear(node_features, We, be)
+    h_edges = F.linear(edge_features, We, be)
+    h_cur = F.linear(cur.unsqueeze(1), We, be)
+    h_edges_mean = mean_features(h_edges, edge_mask)
+    h_nodes_mean = mean_features(h_nodes, node_mask)
+    state_value = torch.cat([h_numerical, h_nodes_mean, h_edges_mean, stage], dim=1)
+    h_cur_rep = h_cur.repeat(1, E, 1)
+    state_policy_land_use = torch.cat([h_edges, h_cur_rep, h_edges * h_cur_rep, h_edges - h_cur_rep], dim=-1)
+    if keep is not None:
+        keep.update(h_nodes_0=h_nodes, h_edges_0=h_edges, h_numerical=h_numerical, h_cur=h_cur.squeeze(1),
+                    h_edges_mean=h_edges_mean, h_nodes_mean=h_nodes_mean, state_value=state_value)
+    return state_policy_land_use, h_nodes, state_value, land_use_mask, road_mask, stage
+
+
 def encoder_forward(P, x, num_heads=1, keep=None):
     """SGNNStateEncoder.forward, state_encoder.py:184-214.  ``x``: list[B] of list[9] tensors.
 
     ``keep`` (dict) receives named intermediates for stage-by-stage parity checks.
     """
+    if is_mlp_params(P):
+        return mlp_encoder_forward(P, x, keep)
     numerical, node_features, edge_index, cur, node_mask, edge_mask, land_use_mask, road_mask, stage = batch_data(x)
     N = node_features.size(1)
     E = edge_index.size(1)

@@ -13,7 +13,7 @@ if ROOT not in sys.path:
 from drl_urban_planning_amd import synth  # noqa: E402
 
 
-def quirky_replay(T, max_nodes, max_edges, seed=0, road_fraction=0.35, n_lo=8, full_row=True):
+def quirky_replay(T, max_nodes, max_edges, seed=0, road_fraction=0.35, n_lo=8, full_row=True, dead_candidate=False):
     """T small states; row 0 has a self-loop and a duplicated edge, row 1 has isolated nodes,
     row 2 (if ``full_row``) is unpadded (n == max_nodes, e == max_edges)."""
     states, actions = [], []
@@ -51,6 +51,10 @@ def quirky_replay(T, max_nodes, max_edges, seed=0, road_fraction=0.35, n_lo=8, f
                 a[1] = 0.0
             if stage == 1 and not s[7][int(a[1])]:
                 a[1] = float(np.flatnonzero(s[7])[0])
+        if dead_candidate and i >= 3 and stage == 0 and int(s[5].sum()) < max_edges:
+            # a land-use candidate on a slot that is NOT a live edge (edge_mask False): the reference still scores it
+            # (sgnn: zero message; rl-mlp: the embedding of zero features = the encoder bias)
+            s[6][int(s[5].sum())] = True
         states.append(s)
         actions.append(a)
     rng = np.random.default_rng(seed * 7919 + 100003)

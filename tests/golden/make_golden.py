@@ -48,6 +48,12 @@ CASES = {
                    max_nodes=30, max_edges=64, T=12, B=6, epochs=1, seed=9, road_fraction=1.0,
                    hyper=dict(lr=4e-4, eps=1e-5, weight_decay=0.0, gamma=1.0, tau=0.0, clip_epsilon=0.2,
                               value_pred_coef=0.5, entropy_coef=0.01)),
+    # the rl-mlp ablation encoder (urban_planning/models/state_encoder.py:217-308, model.py:22-33)
+    'case_m': dict(model=dict(D=32, L=0, S=(64, 16), heads=1, land_head=(32, 1), road_head=(16, 1),
+                              value_head=(32, 32, 1)), encoder='mlp', dead_candidate=True,
+                   max_nodes=40, max_edges=96, T=24, B=8, epochs=2, seed=13, road_fraction=0.3,
+                   hyper=dict(lr=4e-4, eps=1e-5, weight_decay=1e-4, gamma=0.99, tau=0.95, clip_epsilon=0.2,
+                              value_pred_coef=0.5, entropy_coef=0.01)),
 }
 
 
@@ -57,7 +63,8 @@ def build(ref, spec):
                              max_edges=spec['max_edges'], land_head=m['land_head'], road_head=m['road_head'],
                              value_head=m['value_head'])
     torch.manual_seed(spec['seed'])
-    policy_net, value_net = ref.create_sgnn_model(cfg, ref_import.DuckAgent())
+    create = ref.create_mlp_model if spec.get('encoder') == 'mlp' else ref.create_sgnn_model
+    policy_net, value_net = create(cfg, ref_import.DuckAgent())
     # default inits give tiny logits spreads; perturb so softmaxes/ratios are non-trivial
     with torch.no_grad():
         for p in ref.ActorCritic(policy_net, value_net).parameters():
@@ -74,7 +81,7 @@ def main():
         for k, v in ac.state_dict().items():
             out['sd/' + k] = v.detach().numpy().copy()
         replay = cases.quirky_replay(spec['T'], spec['max_nodes'], spec['max_edges'], seed=spec['seed'],
-                                     road_fraction=spec['road_fraction'])
+                                     road_fraction=spec['road_fraction'], **(dict(dead_candidate=True) if spec.get('dead_candidate') else {}))
         for k, v in cases.stack_states(replay.states).items():
             out['st/' + k] = v
         out['actions'] = replay.actions

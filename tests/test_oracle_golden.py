@@ -10,16 +10,19 @@ import cases
 from oracle import sgnn_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASE_HEADS = {'case_a': 1, 'case_b': 2, 'case_c': 1}
-CASE_B = {'case_a': 8, 'case_b': 5, 'case_c': 6}
-CASE_EPOCHS = {'case_a': 2, 'case_b': 2, 'case_c': 1}
-CASE_SEED = {'case_a': 3, 'case_b': 5, 'case_c': 9}
+CASE_HEADS = {'case_a': 1, 'case_b': 2, 'case_c': 1, 'case_m': 1}
+CASE_B = {'case_a': 8, 'case_b': 5, 'case_c': 6, 'case_m': 8}
+CASE_EPOCHS = {'case_a': 2, 'case_b': 2, 'case_c': 1, 'case_m': 2}
+CASE_SEED = {'case_a': 3, 'case_b': 5, 'case_c': 9, 'case_m': 13}
 CASE_HYPER = {
     'case_a': dict(lr=4e-4, eps=1e-5, weight_decay=0.0, gamma=1.0, tau=0.0, clip_epsilon=0.2,
                    value_pred_coef=0.5, entropy_coef=0.01),
     'case_b': dict(lr=1e-3, eps=1e-5, weight_decay=1e-3, gamma=0.97, tau=0.9, clip_epsilon=0.1,
                    value_pred_coef=0.5, entropy_coef=0.02),
     'case_c': dict(lr=4e-4, eps=1e-5, weight_decay=0.0, gamma=1.0, tau=0.0, clip_epsilon=0.2,
+                   value_pred_coef=0.5, entropy_coef=0.01),
+    # the rl-mlp ablation encoder (state_encoder.py:217-308), generated with the reference's create_mlp_model
+    'case_m': dict(lr=4e-4, eps=1e-5, weight_decay=1e-4, gamma=0.99, tau=0.95, clip_epsilon=0.2,
                    value_pred_coef=0.5, entropy_coef=0.01),
 }
 
@@ -31,7 +34,7 @@ def load_case(name):
     return z, sd, states
 
 
-@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c'])
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m'])
 def test_forward_matches_reference(name):
     z, sd, states = load_case(name)
     P = orc.leaf_params(orc.split_actor_critic_state_dict(sd), requires_grad=False)
@@ -51,7 +54,7 @@ def test_forward_matches_reference(name):
     np.testing.assert_allclose(keep['h_edges_%d' % L].numpy(), z['fwd/h_edges_last'], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c'])
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m'])
 def test_minibatch_losses_and_grads_match_reference(name):
     z, sd, states = load_case(name)
     P = orc.leaf_params(orc.split_actor_critic_state_dict(sd))
@@ -82,7 +85,7 @@ def test_gae_matches_reference(name):
         assert np.array_equal(ret.numpy(), z['gae/%s_ret' % tag])
 
 
-@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c'])
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m'])
 def test_update_params_matches_reference(name):
     """Full update_params: permutation schedule, tail drop, first-step double clip, Adam."""
     z, sd, states = load_case(name)

@@ -172,3 +172,30 @@ def test_compact_wire_record_is_lossless_and_packs_identically():
     assert all(np.array_equal(sa[k], sb[k]) for k in sa if k != 'meta')
     with pytest.raises(ValueError):
         packer.expand_state(recs[0][:100])
+
+
+def test_mlp_encoder_inputs_selected_endpoint_and_mean_features():
+    """rl-mlp encoder inputs (state_encoder.py:262-282): per candidate the endpoint that represents the edge (the second
+    one iff its type is FEASIBLE), per state the mean of those endpoints' raw features over the live edges."""
+    replay = cases.quirky_replay(10, 30, 70, seed=4, road_fraction=0.3, dead_candidate=True)
+    pk = packer.pack_replay(replay.states, replay.actions, synth.NODE_DIM, synth.NUMERICAL_DIM, pin=False)
+    L, T = pk.layout, pk.T
+    he_sel = pk.section('he_sel', np.uint16, max(int(L.total_he), 1))
+    he_live = pk.section('he_live', np.uint8, max(int(L.total_he), 1))
+    xbar = pk.section('xbar', np.float32, T * native.NODE_PAD).reshape(T, native.NODE_PAD)
+    saw_second = False
+    for t, s in enumerate(replay.states):
+        feat, ei, emask, lmask = s[1], s[2], s[5], s[6]
+        sel = np.where(feat[ei[:, 1], :14].argmax(1) == 1, ei[:, 1], ei[:, 0])
+        saw_second |= bool((sel[emask] == ei[emask, 1]).any() and (ei[emask, 0] != ei[emask, 1]).any())
+        want = feat[sel[emask]].astype(np.float64).mean(0)
+        np.testing.assert_allclose(xbar[t, :23], want, rtol=1e-6, atol=1e-7)
+        assert not xbar[t, 23:].any()
+        if pk.meta[t, packer.M_STAGE] == 0:
+            o = pk.meta[t, packer.M_HE_OFF]
+            slots = np.flatnonzero(lmask)
+            for q, k in enumerate(slots):
+                assert he_live[o + q] == emask[k]
+                if emask[k]:
+                    assert he_sel[o + q] == sel[k]
+    assert saw_second
