@@ -191,9 +191,10 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_mfma_kernel(const float *__res
 //   * a lane reads chunk c = 2g + (lane >> 5) of its row: k = 8g + 4 (lane >> 5) + t, t = 0..3.  MFMA step (g, t)
 //     therefore contracts k = 8g + t (lanes 0-31) and k = 8g + 4 + t (lanes 32-63): any assignment of k to steps is
 //     valid as long as A and B use the same one.  One 16-byte read feeds four MFMA steps of a fragment.
-//   * two LDS stages of BKP panels each, one raw s_barrier per chunk; chunk ks + 1 is issued behind the first panel's
-//     fragment reads of chunk ks (hipcc drains all LDS-DMA before a ds_read that follows one, so deeper rings buy
-//     nothing from HIP source) and lands while chunk ks's 32 * BKP MFMAs run.
+//   * two LDS stages of one 16-wide K chunk each, one raw s_barrier per chunk; chunk ks + 1 is issued behind the fragment
+//     reads of chunk ks (hipcc drains all LDS-DMA before a ds_read that follows one, so deeper rings buy nothing from
+//     HIP source) and lands while chunk ks's 32 MFMAs run.  Software-pipelined variants (fragment reads between the MFMA
+//     halves, inline-asm reads with counted lgkmcnt, s_setprio, 32- and 64-wide chunks) measured no better and were removed.
 // Only the panel-major A / C, row-major [N][K] weight form (the dominant launches); everything else keeps the
 // register-staged kernel above.
 typedef __attribute__((address_space(1))) const void *gptr_t;
@@ -227,28 +228,31 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BKP, int NSTAGE, int MINW, int MODE = 0>
-__global__ __launch_bounds__(256, MINW) void gemm_nt_dma_kernel(const float *__restrict__ A, int64_t M, int K,
-                                                                const float *__restrict__ W, int N, int64_t ldw,
-                                                                const float *__restrict__ bias,
-                                                                const float *__restrict__ R, float *__restrict__ C,
-                                                                int act_tanh, float alpha, int MT, int NT, int stagger_mode,
-                                                                int stagger_cycles) {
-    constexpr int BM = 128, BN = 128;
-    constexpr int PANEL = 128 * 16;                 // floats of one operand panel (8 KB)
-    constexpr int STAGE = 2 * BKP * PANEL;          // A panels then B panels
-    constexpr int G = 4 * BKP;                      // LDS-DMA instructions per wave and chunk
+// Workgroup tile (64 WM) x (64 WN), one 64 x 64 output block per wave.  128 x 128 (4 waves) is the measured optimum:
+// 256 x 128 / 128 x 256 are 3-5 % slower, 256 x 256 (16 waves on one barrier) 14 % (profiles/r02_gemm_lab.md).
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma2_kernel(const float *__restrict__ A, int64_t M, int K,
+                                                                    const float *__restrict__ W, int N, int64_t ldw,
+                                                                    const float *__restrict__ bias,
+                                                                    const float *__restrict__ R, float *__restrict__ C,
+                                                                    int act_tanh, float alpha, int MT, int NT, int stagger_mode,
+                                                                    int stagger_cycles) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int APANEL = BM * 16, STAGE = (BM + BN) * 16;      // floats: A panel then B panel
+    constexpr int NI = (BM + BN) / 16;                           // 1 KiB LDS-DMA instructions per chunk
+    constexpr int PER = NI / NW;                                 // ... per wave
+    static_assert(NI % NW == 0, "the DMA instructions of a chunk must divide evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];      // the ONLY LDS object of this kernel
 
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
     const int mt = (slot / NT) * 8 + xcd, nt = slot % NT;
     if (mt >= MT) return;
-    first_wave_stagger(stagger_mode & 7, stagger_cycles);
+    first_wave_stagger(stagger_mode, stagger_cycles);
     const int64_t m0 = (int64_t)mt * BM;
     const int n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w / WN, wc = w % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     f32x16 acc[2][2];
@@ -259,31 +263,32 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_dma_kernel(const float *__r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // per-lane DMA sources: this wave fills LDS slots [(2w + j) * 64, +64) of every panel, slot q = 4 row + c'
-    const float *asrc[2], *bsrc[2];
+    // DMA instruction t of a chunk fills 16 rows (64 slots of 16 B, slot = 4 row + c') of the A (t < BM/16) or B panel
+    const float *src[PER];
+    int64_t step[PER];
+    int dst[PER];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = (2 * w + j) * 64 + lane, row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
-        int64_t gm = m0 + row;
-        if (gm >= M) gm = M - 1;                    // rows past the end: valid address, result never stored
-        asrc[j] = A + gm * 16 + c * 4;
-        bsrc[j] = W + (int64_t)(n0 + row) * ldw + c * 4;
+    for (int j = 0; j < PER; ++j) {
+        const int t = w * PER + j;
+        const bool isA = t < BM / 16;
+        const int row = (isA ? t : t - BM / 16) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        if (isA) {
+            int64_t gm = m0 + row;
+            if (gm >= M) gm = M - 1;                // rows past the end: valid address, result never stored
+            src[j] = A + gm * 16 + c * 4;
+            step[j] = M * 16;
+            dst[j] = t * 256;
+        } else {
+            src[j] = W + (int64_t)(n0 + row) * ldw + c * 4;
+            step[j] = 16;
+            dst[j] = APANEL + (t - BM / 16) * 256;
+        }
     }
-    const int64_t a_panel = M * 16;
     auto issue = [&](int kc, int s) {
 #pragma unroll
-        for (int pp = 0; pp < BKP; ++pp) {
-            const int kp = kc * BKP + pp;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float *la = smem + s * STAGE + pp * PANEL + (2 * w + j) * 256;
-                float *lb = smem + s * STAGE + (BKP + pp) * PANEL + (2 * w + j) * 256;
-                __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + kp * a_panel), (lptr_t)la, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[j] + kp * 16), (lptr_t)lb, 16, 0, 0);
-            }
-        }
+        for (int j = 0; j < PER; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kc * step[j]), (lptr_t)(smem + s * STAGE + dst[j]), 16, 0, 0);
     };
-    // fragment offsets (floats) inside a panel: row * 16 + 4 * ((2g + lhi) ^ ((row >> 2) & 3))
     int aoff[2][2], boff[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -291,20 +296,23 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_dma_kernel(const float *__r
         for (int g = 0; g < 2; ++g) {
             const int sw = ((2 * g + lhi) ^ ((l31 >> 2) & 3)) * 4;
             aoff[i][g] = (wr * 64 + i * 32 + l31) * 16 + sw;
-            boff[i][g] = (wc * 64 + i * 32 + l31) * 16 + sw;
+            boff[i][g] = APANEL + (wc * 64 + i * 32 + l31) * 16 + sw;
         }
-
-    const int KS = (K >> 4) / BKP;
-    auto frags = [&](const float *sa, const float *sb, float4 (&a)[2][2], float4 (&b)[2][2]) {
+    const int KS = K >> 4;
+    issue(0, 0);
+    for (int ks = 0; ks < KS; ++ks) {
+        wait_vmcnt<0>();                            // this wave's part of chunk ks has landed
+        __builtin_amdgcn_s_barrier();               // ... and everyone's; all reads of chunk ks-1 are done
+        const float *st = smem + (ks & 1) * STAGE;
+        float4 a[2][2], b[2][2];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[g][i] = *reinterpret_cast<const float4 *>(sa + aoff[i][g]);
-                b[g][i] = *reinterpret_cast<const float4 *>(sb + boff[i][g]);
+                a[g][i] = *reinterpret_cast<const float4 *>(st + aoff[i][g]);
+                b[g][i] = *reinterpret_cast<const float4 *>(st + boff[i][g]);
             }
-    };
-    auto mfmas = [&](const float4 (&a)[2][2], const float4 (&b)[2][2]) {
+        if (ks + 1 < KS) issue(ks + 1, (ks + 1) & 1);      // behind the fragment reads (hipcc drains LDS-DMA before a ds_read)
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -319,165 +327,6 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_dma_kernel(const float *__r
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0);
             }
-    };
-    if (MODE == 0) {
-        issue(0, 0);
-        for (int ks = 0; ks < KS; ++ks) {
-            wait_vmcnt<0>();                            // this wave's part of chunk ks has landed
-            __builtin_amdgcn_s_barrier();               // ... and everyone's; all reads of chunk ks-1 are done
-            const float *st = smem + (ks & 1) * STAGE;
-            // The compiler drains every LDS-DMA (vmcnt(0)) before any ds_read that follows one, so the next chunk is issued
-            // BEHIND the first panel's fragment reads: its flight then overlaps this chunk's MFMAs instead of stalling them.
-            float4 a[2][2], b[2][2];
-            frags(st, st + BKP * PANEL, a, b);
-            if (ks + 1 < KS) issue(ks + 1, (ks + 1) & 1);
-            mfmas(a, b);
-#pragma unroll
-            for (int pp = 1; pp < BKP; ++pp) {
-                frags(st + pp * PANEL, st + (BKP + pp) * PANEL, a, b);
-                mfmas(a, b);
-            }
-        }
-    } else {
-        // Software-pipelined form (BKP == 1).  A wave's own non-MFMA work -- the wait for the next chunk, the barrier, the
-        // fragment reads, the DMA issue -- is placed BETWEEN the two 16-MFMA halves of the current chunk, where it issues
-        // while the matrix pipe is still executing the MFMAs ahead of it; the fragments of chunk k+1 are in registers before
-        // chunk k's last MFMA retires, so the wave's MFMA stream never pauses at a chunk boundary.  (All co-resident waves
-        // of a SIMD advance in lockstep, so a pause in one is a pause in all: the un-pipelined loop leaves the pipe idle
-        // ~20 % of the time at full clock.)
-        static_assert(MODE == 0 || BKP == 1, "the pipelined loop handles one panel per chunk");
-        float4 a0[2], b0[2], a1[2], b1[2];          // fragment sets of the two k-groups (g = 0, 1)
-        auto read_g = [&](const float *st, int g, float4 (&a)[2], float4 (&b)[2]) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const float4 *>(st + aoff[i][g]);
-                b[i] = *reinterpret_cast<const float4 *>(st + PANEL + boff[i][g]);
-            }
-        };
-        auto mfma_g = [&](const float4 (&a)[2], const float4 (&b)[2]) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float av[2] = {t == 0 ? a[0].x : t == 1 ? a[0].y : t == 2 ? a[0].z : a[0].w,
-                                     t == 0 ? a[1].x : t == 1 ? a[1].y : t == 2 ? a[1].z : a[1].w};
-                const float bv[2] = {t == 0 ? b[0].x : t == 1 ? b[0].y : t == 2 ? b[0].z : b[0].w,
-                                     t == 0 ? b[1].x : t == 1 ? b[1].y : t == 2 ? b[1].z : b[1].w};
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0);
-            }
-        };
-        if (MODE <= 2) {
-            issue(0, 0);
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            read_g(smem, 0, a0, b0);
-            read_g(smem, 1, a1, b1);
-            if (KS > 1) issue(1, 1);
-            for (int ks = 0; ks < KS; ++ks) {
-                const bool more = ks + 1 < KS;
-                const float *nxt = smem + ((ks + 1) & 1) * STAGE;
-                __builtin_amdgcn_sched_barrier(0);
-                if (MODE == 2) __builtin_amdgcn_s_setprio(2);
-                mfma_g(a0, b0);
-                if (MODE == 2) __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    // chunk ks+1 was issued one half-iteration ago at least; every wave's reads of chunk ks are complete
-                    // (lgkmcnt(0)) before anyone's DMA of chunk ks+2 may overwrite that stage
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    read_g(nxt, 0, a0, b0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (MODE == 2) __builtin_amdgcn_s_setprio(2);
-                mfma_g(a1, b1);
-                if (MODE == 2) __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    read_g(nxt, 1, a1, b1);
-                    if (ks + 2 < KS) issue(ks + 2, ks & 1);
-                }
-            }
-        } else {
-            // MODE 3: the fragment reads are inline asm, so hipcc neither drains the LDS-DMA queue in front of them nor
-            // waits lgkmcnt(0) at the loop header; every wait below is counted by hand (in-order LGKM counter: the four
-            // reads of the g = 1 set are always the youngest outstanding).
-            f32x4 xa0[2], xb0[2], xa1[2], xb1[2];
-            const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
-            unsigned oa[2][2], ob[2][2];            // byte addresses inside stage 0
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    oa[i][g] = lds0 + 4u * (unsigned)aoff[i][g];
-                    ob[i][g] = lds0 + 4u * (unsigned)(PANEL + boff[i][g]);
-                }
-            auto rd = [&](f32x4 &dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
-            auto read_set = [&](unsigned stage_bytes, int g, f32x4 (&a)[2], f32x4 (&b)[2]) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    rd(a[i], oa[i][g] + stage_bytes);
-                    rd(b[i], ob[i][g] + stage_bytes);
-                }
-            };
-            auto mfma_x = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][t], a[i][t], acc[i][j], 0, 0, 0);
-            };
-            issue(0, 0);
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            read_set(0, 0, xa0, xb0);
-            read_set(0, 1, xa1, xb1);
-            if (KS > 1) issue(1, 1);
-            for (int ks = 0; ks < KS; ++ks) {
-                const bool more = ks + 1 < KS;
-                const unsigned nxt = ((ks + 1) & 1) * (unsigned)(STAGE * 4);
-                // g = 0 set ready (the g = 1 set, 4 younger reads, may still be in flight)
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xa0[0]), "+v"(xa0[1]), "+v"(xb0[0]), "+v"(xb0[1])::"memory");
-                __builtin_amdgcn_sched_barrier(0);
-                if (MODE == 4) __builtin_amdgcn_s_setprio(2);
-                mfma_x(xa0, xb0);
-                if (MODE == 4) __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                // g = 1 set ready = every read of this chunk's stage done; next chunk landed (this wave's part)
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xa1[0]), "+v"(xa1[1]), "+v"(xb1[0]), "+v"(xb1[1])::"memory");
-                if (more) {
-                    __builtin_amdgcn_s_barrier();
-                    read_set(nxt, 0, xa0, xb0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (MODE == 4) __builtin_amdgcn_s_setprio(2);
-                mfma_x(xa1, xb1);
-                if (MODE == 4) __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    read_set(nxt, 1, xa1, xb1);
-                    if (ks + 2 < KS) issue(ks + 2, ks & 1);
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (keeps the counter argument of lgkmcnt(4) simple)
-                }
-            }
-        }
-    }
-
-    if (stagger_mode & 8) {     // lab only: keep the accumulators alive but write one value per lane (no C traffic)
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-        if (sacc == 12345.678f) C[0] = sacc;
-        return;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -517,21 +366,21 @@ void set_gemm_stagger(int mode, int cycles) {
     if (cycles >= 0) g_stagger_cycles = cycles;
 }
 
-template <int BKP, int NSTAGE, int MINW, int MODE = 0>
-static int launch_nt_dma(const GemmNT &g, hipStream_t st) {
-    const int MT = (int)((g.M + 127) / 128), MT8 = (MT + 7) / 8 * 8, NT = g.N / 128;
-    const size_t lds = sizeof(float) * (size_t)NSTAGE * 2 * BKP * 128 * 16 + (size_t)g_lds_pad;     // pad: lab knob limiting WGs per CU
-    auto kern = gemm_nt_dma_kernel<BKP, NSTAGE, MINW, MODE>;
-    if (lds > 64 * 1024) {
+template <int WM, int WN>
+static int launch_nt_dma2(const GemmNT &g, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int MT = (int)((g.M + BM - 1) / BM), MT8 = (MT + 7) / 8 * 8, NT = g.N / BN;
+    const size_t lds = sizeof(float) * 2 * (size_t)(BM + BN) * 16 + (size_t)g_lds_pad;
+    auto kern = gemm_nt_dma2_kernel<WM, WN>;
+    if (lds > 64 * 1024)
         UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3(MT8 * NT), dim3(256), lds, st, g.A, g.M, g.K, g.W, g.N, g.ldw, g.bias, g.R, g.C,
+    hipLaunchKernelGGL(kern, dim3(MT8 * NT), dim3(64 * WM * WN), lds, st, g.A, g.M, g.K, g.W, g.N, g.ldw, g.bias, g.R, g.C,
                        g.act_tanh, g.alpha, MT, NT, g_stagger_mode, g_stagger_cycles);
     return 0;
 }
 
-static bool nt_dma_ok(const GemmNT &g, int bkp) {
-    return !g.a_rm && !g.c_rm && !g.w_kn && g.N % 128 == 0 && g.K % (16 * bkp) == 0 && g.K >= 64 && g.ldw % 4 == 0 &&
+static bool nt_dma_ok(const GemmNT &g) {
+    return !g.a_rm && !g.c_rm && !g.w_kn && g.N % 128 == 0 && g.K % 16 == 0 && g.K >= 64 && g.ldw % 4 == 0 &&
            reinterpret_cast<uintptr_t>(g.A) % 16 == 0 && reinterpret_cast<uintptr_t>(g.W) % 16 == 0;
 }
 
@@ -639,12 +488,10 @@ int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
     const int dv = (mfma && !k32 && bn == 128) ? g_nt_dma_variant : 0;
     int dma_rc = 1;                             // 1 = not taken
     switch (dv) {
-        case 1: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4>(g, st); break;
-        case 2: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4, 1>(g, st); break;
-        case 3: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4, 2>(g, st); break;
-        case 4: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4, 3>(g, st); break;
-        case 5: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 4, 4>(g, st); break;
-        case 6: if (nt_dma_ok(g, 1)) dma_rc = launch_nt_dma<1, 2, 2, 4>(g, st); break;
+        case 1: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<2, 2>(g, st); break;
+        case 2: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<4, 2>(g, st); break;
+        case 3: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<2, 4>(g, st); break;
+        case 4: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<4, 4>(g, st); break;
         default: break;
     }
     if (dma_rc < 0) return dma_rc;
