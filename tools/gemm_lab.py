@@ -1,4 +1,6 @@
-"""Kernel lab 7: workgroup tile of the LDS-DMA gemm_nt (needs a GPU)."""
+"""Kernel lab: the register-staged gemm_nt against the LDS-DMA kernel at every workgroup tile, on the shapes of the
+training step (needs a GPU).  Earlier lab rounds (staging variants, stagger, K sweep, occupancy x priority) are
+summarised with their raw logs in profiles/r02_gemm_lab.md."""
 import ctypes as C
 import os
 import sys
@@ -9,8 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drl_urban_planning_amd import native  # noqa: E402
 from kernel_bench import P, time_ms  # noqa: E402
 
-NAMES = {0: 'register-staged 128x128', 1: 'dma 128x128 (round-2 default)', 10: 'dma2 128x128', 11: 'dma2 256x128', 12: 'dma2 128x256',
-         13: 'dma2 256x256'}
+NAMES = {0: 'register-staged 128x128', 1: 'LDS-DMA 128x128 (default)', 2: 'LDS-DMA 256x128', 3: 'LDS-DMA 128x256', 4: 'LDS-DMA 256x256'}
 
 
 def main():
@@ -30,7 +31,7 @@ def main():
         for _ in range(30):
             fn()
         ref = Cc.clone()
-        for v in (0, 1, 10, 11, 12, 13):
+        for v in (0, 1, 2, 3, 4):
             native.check(lib.upamd_tune(b'gemm_nt_dma', v))
             res = []
             for pad in (0, 12 * 1024):
@@ -45,7 +46,7 @@ def main():
         Ct0, Ct1 = torch.zeros(N // 16, Mt, 16, device=dev), torch.zeros(N // 16, Mt, 16, device=dev)
         native.check(lib.upamd_tune(b'gemm_nt_dma', 0))
         native.check(lib.upamd_gemm_nt(P(At), Mt, K, 0, 0, P(W), N, K, None, P(Rt), P(Ct0), 0, 0, 0, 1.0, st))
-        for v in (11, 12, 13):
+        for v in (1, 2, 3, 4):
             native.check(lib.upamd_tune(b'gemm_nt_dma', v))
             Ct1.zero_()
             native.check(lib.upamd_gemm_nt(P(At), Mt, K, 0, 0, P(W), N, K, None, P(Rt), P(Ct1), 0, 0, 0, 1.0, st))
