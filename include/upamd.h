@@ -7,6 +7,13 @@
  * (ctypes here) talks to.  Every entry point cites the reference code whose
  * work it replaces (paths relative to the reference repo root).
  *
+ * What sits ABOVE this ABI is the reference's Python surface, kept by drl-urban-planning_amd/{models,agent}.py:
+ * create_sgnn_model / create_mlp_model, policy_net.forward / select_action / get_log_prob_entropy, value_net(x),
+ * update_params(batch, iteration).  One deliberate difference: on a GPU module policy_net.forward(x) returns the
+ * reference's Categorical objects (same padded-slot layout, same pad constant) but built from the HIP forward's logits
+ * WITHOUT an autograd graph -- gradients flow through get_log_prob_entropy (upamd_forward / upamd_backward), which is
+ * the only route the reference's update uses (urban_planning_agent.py:363-371).
+ *
  * Conventions: plain C types, pointers and sizes only.  `*_dev` pointers are device (HBM)
  * addresses, everything else is host memory.  `stream` is a hipStream_t passed as void*
  * (NULL = default stream).  Every function returns 0 on success and a negative UPAMD_E_*

@@ -18,6 +18,7 @@ import re
 from collections import defaultdict
 
 SHORT = [      # demangled (csv output) and mangled (rocpd) spellings
+    (r'gemm_nt_dma2_kernel(<2, 2|ILi2ELi2)', 'gemm_nt_128'),          # round 2: the LDS-DMA kernel is the 128 x 128 node GEMM
     (r'gemm_nt_mfma_kernel(<128, 64, 64, false, false, 1, 32|ILi128ELi64ELi64ELb0ELb0ELi1ELi32)', 'gemm_nt_128_k32'),
     (r'gemm_nt_mfma_kernel(<128, 64, 64, false, false|ILi128ELi64ELi64ELb0ELb0)', 'gemm_nt_128'),
     (r'gemm_nt_mfma_kernel(<128, 64, 64, true|ILi128ELi64ELi64ELb1)', 'gemm_nt_128_rm'),
