@@ -215,9 +215,14 @@ def main():
     t_gen = time.time() - t_gen
     np.random.seed(seed_np)
     engine = up.attach()
-    if os.environ.get('UPAMD_GEMM_NT_DMA') is not None:          # kernel-lab A/B switch (default: the library's own choice)
+    # kernel-lab A/B switches (default: the library's own choices): UPAMD_TUNE="knob=value,knob=value"
+    tune = dict(kv.split('=') for kv in os.environ.get('UPAMD_TUNE', '').split(',') if kv)
+    if os.environ.get('UPAMD_GEMM_NT_DMA') is not None:
+        tune['gemm_nt_dma'] = os.environ['UPAMD_GEMM_NT_DMA']
+    if tune:
         from drl_urban_planning_amd import native
-        native.check(native.lib().upamd_tune(b'gemm_nt_dma', int(os.environ['UPAMD_GEMM_NT_DMA'])))
+        for knob, value in tune.items():
+            native.check(native.lib().upamd_tune(knob.encode(), int(value)), 'upamd_tune')
     t_prep = time.time()
     it = up.prepare(replay)
     torch.cuda.synchronize(dev)

@@ -274,7 +274,7 @@ class PPOUpdater:
             sched = packer.Schedule(it.packed, [r[j * h:(j + 1) * h] for r in row_lists for j in range(S)], dev)
         else:
             sched = packer.Schedule(it.packed, row_lists, dev) if nb else None
-        flat_rows = np.concatenate(row_lists) if nb else np.zeros(0, dtype=np.int64)
+        flat_rows = (np.concatenate(row_lists) if nb else np.zeros(0)).astype(np.int64)
         order_dev = torch.from_numpy(np.ascontiguousarray(flat_rows)).to(dev)
         return Epoch(sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob)
 
@@ -292,10 +292,10 @@ class PPOUpdater:
             mb, _ = ep.sched.minibatch(k)
             idx = ep.order_dev[k * B:(k + 1) * B]
             engine.forward(it.packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
-            engine.ppo_loss(B, value_b, logp_b, ent_b, it.adv[idx], it.ret[idx], it.old_logp[idx], it.exps[idx],
-                            self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
-                            dvalue, dlogp, dent, self.grads[nflt:])
-            self.grads[:nflt].zero_()
+            # gathers of the minibatch rows, the loss and zero_grad in one launch
+            engine.ppo_loss_rows(B, value_b, logp_b, ent_b, idx, it.adv, it.ret, it.old_logp, it.exps,
+                                 self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
+                                 dvalue, dlogp, dent, self.grads[nflt:], zero=self.grads[:nflt])
             engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
         else:
             S, h = self.sub_batches, B // self.sub_batches
@@ -320,20 +320,22 @@ class PPOUpdater:
                 main.wait_stream(self._streams[j])
             torch.add(self._sub_grads[0], self._sub_grads[1], out=self.grads)
         self.dist.all_reduce_sum(self.grads)              # ONE collective per optimizer step (no-op for one rank)
-        if loss_out is not None:
-            loss_out.copy_(self.grads[nflt:])
         if self.clip_pending:
             engine.clip_first_step(self.grads, self.max_grad_norm, self.scratch)
             self.clip_pending = False
         has_rows = (True, ep.land_glob[k] > 0, ep.road_glob[k] > 0)
+        steps = [0, 0, 0]
         for g in range(3):
             # torch >= 2.0: a head without rows has grad None and Adam skips it; legacy_zero_grad (torch <= 1.13): once
             # a head has had a gradient it keeps stepping with g = 0
             if has_rows[g] or (self.legacy_zero_grad and self._group_seen[g]):
                 self._group_seen[g] = True
                 self.group_steps[g] += 1
-                engine.adam_step(g, self.flat, self.grads, self.m, self.v, self.group_steps[g], self.lr,
-                                 self.betas[0], self.betas[1], self.eps, self.weight_decay)
+                steps[g] = self.group_steps[g]
+        # every group's Adam step (and the copy-out of the step's loss scalars) in one launch
+        engine.adam_groups(steps, self.flat, self.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                           self.weight_decay, loss_src=self.grads[nflt:] if loss_out is not None else None,
+                           loss_dst=loss_out)
 
     # ------------------------------------------------------------------ the reference's entry point
     def update_params(self, batch, iteration=0, tb_logger=None, max_steps=None):

@@ -14,9 +14,24 @@ extern "C" int upamd_ppo_loss(int32_t B, const float *value_dev, const float *lo
     if (!value_dev || !logp_dev || !ent_dev || !adv_dev || !ret_dev || !old_logp_dev || !exps_dev || !dvalue_dev ||
         !dlogp_dev || !dent_dev || !losses_dev)
         return fail(UPAMD_E_INVALID, "upamd_ppo_loss: null pointer");
-    return launch_ppo_loss(B, value_dev, logp_dev, ent_dev, adv_dev, ret_dev, old_logp_dev, exps_dev, clip_epsilon,
+    return launch_ppo_loss(B, value_dev, logp_dev, ent_dev, nullptr, adv_dev, ret_dev, old_logp_dev, exps_dev, clip_epsilon,
                            value_pred_coef, entropy_coef, inv_rows, inv_ind, dvalue_dev, dlogp_dev, dent_dev, losses_dev,
-                           static_cast<hipStream_t>(stream));
+                           nullptr, 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int upamd_ppo_loss_rows(int32_t B, const float *value_dev, const float *logp_dev, const float *ent_dev,
+                                   const int64_t *rows_dev, const float *adv_all_dev, const float *ret_all_dev,
+                                   const float *old_logp_all_dev, const float *exps_all_dev, float clip_epsilon,
+                                   float value_pred_coef, float entropy_coef, float inv_rows, float inv_ind,
+                                   float *dvalue_dev, float *dlogp_dev, float *dent_dev, float *losses_dev,
+                                   float *zero_dev, int64_t n_zero, void *stream) {
+    if (B <= 0 || n_zero < 0) return fail(UPAMD_E_INVALID, "upamd_ppo_loss_rows: B must be > 0, n_zero >= 0");
+    if (!value_dev || !logp_dev || !ent_dev || !rows_dev || !adv_all_dev || !ret_all_dev || !old_logp_all_dev ||
+        !exps_all_dev || !dvalue_dev || !dlogp_dev || !dent_dev || !losses_dev || (n_zero > 0 && !zero_dev))
+        return fail(UPAMD_E_INVALID, "upamd_ppo_loss_rows: null pointer");
+    return launch_ppo_loss(B, value_dev, logp_dev, ent_dev, rows_dev, adv_all_dev, ret_all_dev, old_logp_all_dev,
+                           exps_all_dev, clip_epsilon, value_pred_coef, entropy_coef, inv_rows, inv_ind, dvalue_dev,
+                           dlogp_dev, dent_dev, losses_dev, zero_dev, n_zero, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int upamd_gae(int64_t T, const float *rewards_dev, const float *masks_dev, const float *values_dev,
@@ -63,6 +78,20 @@ extern "C" int upamd_adam_step(int64_t begin, int64_t end, float *params_dev, co
                        beta2, eps, weight_decay, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int upamd_adam_groups(int32_t n_groups, const int64_t *begin, const int64_t *end, const int32_t *step,
+                                 float *params_dev, const float *grads_dev, float *m_dev, float *v_dev, double lr,
+                                 double beta1, double beta2, double eps, double weight_decay, const float *loss_src_dev,
+                                 float *loss_dst_dev, void *stream) {
+    if (n_groups < 0 || n_groups > 4 || (n_groups > 0 && (!begin || !end || !step)))
+        return fail(UPAMD_E_INVALID, "upamd_adam_groups: 0..4 groups with begin/end/step tables");
+    for (int k = 0; k < n_groups; ++k)
+        if (end[k] < begin[k] || begin[k] < 0 || step[k] < 0) return fail(UPAMD_E_INVALID, "upamd_adam_groups: bad range or step");
+    if (!params_dev || !grads_dev || !m_dev || !v_dev || ((loss_dst_dev != nullptr) != (loss_src_dev != nullptr)))
+        return fail(UPAMD_E_INVALID, "upamd_adam_groups: null pointer");
+    return launch_adam_groups(n_groups, begin, end, step, params_dev, grads_dev, m_dev, v_dev, lr, beta1, beta2, eps,
+                              weight_decay, loss_src_dev, loss_dst_dev, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int upamd_gemm_nt(const float *A_dev, int64_t M, int32_t K, int64_t lda, int32_t a_row_major, const float *W_dev,
                              int32_t N, int64_t ldw, const float *bias_dev, const float *R_dev, float *C_dev, int64_t ldc,
                              int32_t c_row_major, int32_t act_tanh, float alpha, void *stream) {
@@ -97,6 +126,7 @@ extern "C" int upamd_tune(const char *name, int32_t value) {
     if (!strcmp(name, "gemm_lds_pad")) { set_gemm_lds_pad(value); return UPAMD_OK; }
     if (!strcmp(name, "gemm_stagger_mode")) { set_gemm_stagger(value, -1); return UPAMD_OK; }
     if (!strcmp(name, "gemm_stagger_cycles")) { set_gemm_stagger(-1, value); return UPAMD_OK; }
+    if (!strcmp(name, "fold_layer1")) { set_fold_layer1(value); return UPAMD_OK; }
     return fail(UPAMD_E_INVALID, "upamd_tune: unknown knob '%s'", name);
 }
 

@@ -365,24 +365,34 @@ int launch_axpy(float *dst, const float *src, int64_t n, float alpha, hipStream_
 // inside the clip range both branches are equal and the gradient is A*ratio; outside it the
 // gradient flows only if the unclipped branch is the smaller one.
 // ------------------------------------------------------------------------------------------
+// `rows` (optional): adv / ret / old_logp / exps are whole-replay arrays and minibatch row b is replay row rows[b]
+// (saves the caller four gather launches per step).  Blocks 1.. zero `zero[0..nzero)` (the gradient buffer of the step).
 __global__ __launch_bounds__(1024) void ppo_loss_kernel(int B, const float *__restrict__ value,
                                                         const float *__restrict__ logp, const float *__restrict__ ent,
+                                                        const int64_t *__restrict__ rows,
                                                         const float *__restrict__ adv, const float *__restrict__ ret,
                                                         const float *__restrict__ old_logp, const float *__restrict__ exps,
                                                         float clip_eps, float cv, float ce, float inv_rows, float inv_ind,
                                                         float *__restrict__ dvalue, float *__restrict__ dlogp,
-                                                        float *__restrict__ dent, float *__restrict__ losses) {
+                                                        float *__restrict__ dent, float *__restrict__ losses,
+                                                        float *__restrict__ zero, int64_t nzero) {
+    if (blockIdx.x > 0) {
+        const int64_t stride = (int64_t)(gridDim.x - 1) * 1024;
+        for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < nzero; i += stride) zero[i] = 0.f;
+        return;
+    }
     __shared__ float red[3][16];
     float sv = 0.f, ss = 0.f, se = 0.f;
     const float lo = 1.f - clip_eps, hi = 1.f + clip_eps;
     for (int b = threadIdx.x; b < B; b += 1024) {
-        const float diff = value[b] - ret[b];
+        const int64_t t = rows ? rows[b] : b;
+        const float diff = value[b] - ret[t];
         sv = fmaf(diff, diff, sv);
         dvalue[b] = cv * 2.f * diff * inv_rows;
         float gl = 0.f, ge = 0.f;
-        if (exps[b] != 0.f) {
-            const float ratio = expf(logp[b] - old_logp[b]);
-            const float A = adv[b];
+        if (exps[t] != 0.f) {
+            const float ratio = expf(logp[b] - old_logp[t]);
+            const float A = adv[t];
             const float s1 = ratio * A;
             const float s2 = fminf(fmaxf(ratio, lo), hi) * A;
             ss += fminf(s1, s2);
@@ -413,11 +423,12 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(int B, const float *__re
         losses[3] = el;
     }
 }
-int launch_ppo_loss(int B, const float *value, const float *logp, const float *ent, const float *adv,
+int launch_ppo_loss(int B, const float *value, const float *logp, const float *ent, const int64_t *rows, const float *adv,
                     const float *ret, const float *old_logp, const float *exps, float clip_eps, float cv, float ce,
                     float inv_rows, float inv_ind, float *dvalue, float *dlogp, float *dent, float *losses,
-                    hipStream_t st) {
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(1024), 0, st, B, value, logp, ent, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind, dvalue, dlogp, dent, losses);
+                    float *zero, int64_t nzero, hipStream_t st) {
+    const unsigned zb = (zero && nzero > 0) ? (unsigned)std::min<int64_t>((nzero + 4095) / 4096, 512) : 0u;
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(1 + zb), dim3(1024), 0, st, B, value, logp, ent, rows, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind, dvalue, dlogp, dent, losses, zero, nzero);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }
@@ -479,6 +490,57 @@ int launch_adam(int64_t n, float *p, const float *g, float *m, float *v, int ste
     const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, (float)(lr / bc1), (float)b1,
                        (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, (float)wd, (float)sqrt(bc2));
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
+// All optimizer groups of a step in ONE launch: group q covers [begin, end) with its own bias corrections (its own
+// step count); a group with step == 0 is skipped (a head without rows: grad None in the reference).  Optionally the
+// four loss scalars behind the gradients are copied out (the caller's per-step log row).
+struct AdamGroups {
+    int64_t begin[4], end[4];
+    float step_size[4], bc2_sqrt[4];
+    int n;
+};
+__global__ void adam_groups_kernel(AdamGroups G, float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                   float *__restrict__ v, float b1, float b2, float one_m_b1, float one_m_b2, float eps,
+                                   float wd, const float *__restrict__ loss_src, float *__restrict__ loss_dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (loss_dst && i < 4) loss_dst[i] = loss_src[i];
+    int q = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < G.n && i >= G.begin[k] && i < G.end[k]) q = k;
+    if (q < 0) return;
+    float grad = g[i];
+    const float param = p[i];
+    if (wd != 0.f) grad = fmaf(wd, param, grad);
+    const float mi = m[i] + (grad - m[i]) * one_m_b1;
+    const float vi = v[i] * b2 + one_m_b2 * grad * grad;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / G.bc2_sqrt[q] + eps;
+    p[i] = param - G.step_size[q] * (mi / denom);
+}
+int launch_adam_groups(int n_groups, const int64_t *begin, const int64_t *end, const int32_t *step, float *p, const float *g,
+                       float *m, float *v, double lr, double b1, double b2, double eps, double wd, const float *loss_src,
+                       float *loss_dst, hipStream_t st) {
+    AdamGroups G;
+    G.n = 0;
+    int64_t hi = loss_dst ? 4 : 0;
+    for (int k = 0; k < n_groups; ++k) {
+        if (step[k] <= 0 || end[k] <= begin[k]) continue;
+        const double bc1 = 1.0 - pow(b1, step[k]), bc2 = 1.0 - pow(b2, step[k]);
+        G.begin[G.n] = begin[k];
+        G.end[G.n] = end[k];
+        G.step_size[G.n] = (float)(lr / bc1);
+        G.bc2_sqrt[G.n] = (float)sqrt(bc2);
+        hi = std::max(hi, end[k]);
+        ++G.n;
+    }
+    if (hi <= 0) return 0;
+    hipLaunchKernelGGL(adam_groups_kernel, dim3((unsigned)((hi + 255) / 256)), dim3(256), 0, st, G, p, g, m, v, (float)b1,
+                       (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, (float)wd, loss_src, loss_dst);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

@@ -96,15 +96,16 @@ __device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool
     return L;
 }
 
-// interleave a graph's P and Q panel slices into LDS, pre-scaled: PQ[v][c] = C2 * (P[v][c], Q[v][c])
+// interleave a graph's P and Q panel slices into LDS, pre-scaled, by column PAIRS: the 16 bytes of node v and columns
+// (c, c+1), c even, are C2 * (P_c, P_c+1, Q_c, Q_c+1) -- the order the packed two-column math of the walks consumes
 __device__ __forceinline__ void stage_pq(float2 *PQl, const float *Pg, const float *Qg, int n) {
     const float4 *p4 = reinterpret_cast<const float4 *>(Pg);
     const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
     for (int i = threadIdx.x; i < n * 4; i += EDGE_THREADS) {
         const float4 pp = p4[i], qq = q4[i];
         float4 *d = reinterpret_cast<float4 *>(PQl + i * 4);       // 4 consecutive (P,Q) pairs = 32 B
-        d[0] = make_float4(C2 * pp.x, C2 * qq.x, C2 * pp.y, C2 * qq.y);
-        d[1] = make_float4(C2 * pp.z, C2 * qq.z, C2 * pp.w, C2 * qq.w);
+        d[0] = make_float4(C2 * pp.x, C2 * pp.y, C2 * qq.x, C2 * qq.y);
+        d[1] = make_float4(C2 * pp.z, C2 * pp.w, C2 * qq.z, C2 * qq.w);
     }
 }
 
@@ -115,26 +116,30 @@ __device__ __forceinline__ void stage_pq(float2 *PQl, const float *Pg, const flo
 // all factors and products inside [2^-118, 2^118].  The function returns false otherwise and the workgroup
 // re-stages in linear form and walks with the exponentials inside the loop (same math, any magnitude).
 constexpr float EF_LIMIT = 56.f, EF_BIAS_LIMIT = 6.f;
+// The forward needs only r1 + r2 of an edge, and with t = 1 + E1, u = 1 + E2:  1/t + 1/u = (t + u) / (t u) -- ONE
+// quarter-rate v_rcp_f32 instead of two (2 FMA + mul + add + rcp + FMA per column and incidence).  t u must stay
+// finite: 2 (2 EF_LIMIT_FWD + EF_BIAS_LIMIT) < 127.
+constexpr float EF_LIMIT_FWD = 28.f;
 
 // writes the exp form of P/Q floats [4i, 4i+4) of the slice; returns the largest |C2 P|, |C2 Q| seen
 __device__ __forceinline__ float put_pq_exp(float2 *PQl, int i, const float4 &pp, const float4 &qq) {
     const float ax = C2 * pp.x, ay = C2 * pp.y, az = C2 * pp.z, aw = C2 * pp.w;
     const float bx = C2 * qq.x, by = C2 * qq.y, bz = C2 * qq.z, bw = C2 * qq.w;
     float4 *d = reinterpret_cast<float4 *>(PQl + i * 4);
-    d[0] = make_float4(__builtin_amdgcn_exp2f(ax), __builtin_amdgcn_exp2f(bx), __builtin_amdgcn_exp2f(ay),
+    d[0] = make_float4(__builtin_amdgcn_exp2f(ax), __builtin_amdgcn_exp2f(ay), __builtin_amdgcn_exp2f(bx),
                        __builtin_amdgcn_exp2f(by));
-    d[1] = make_float4(__builtin_amdgcn_exp2f(az), __builtin_amdgcn_exp2f(bz), __builtin_amdgcn_exp2f(aw),
+    d[1] = make_float4(__builtin_amdgcn_exp2f(az), __builtin_amdgcn_exp2f(aw), __builtin_amdgcn_exp2f(bz),
                        __builtin_amdgcn_exp2f(bw));
     return fmaxf(fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fmaxf(fabsf(az), fabsf(aw))),
                  fmaxf(fmaxf(fabsf(bx), fabsf(by)), fmaxf(fabsf(bz), fabsf(bw))));
 }
 
-__device__ __forceinline__ bool stage_pq_exp(float2 *PQl, const float *Pg, const float *Qg, int n) {
+__device__ __forceinline__ bool stage_pq_exp(float2 *PQl, const float *Pg, const float *Qg, int n, float limit = EF_LIMIT) {
     const float4 *p4 = reinterpret_cast<const float4 *>(Pg);
     const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
     float mx = 0.f;
     for (int i = threadIdx.x; i < n * 4; i += EDGE_THREADS) mx = fmaxf(mx, put_pq_exp(PQl, i, p4[i], q4[i]));
-    return mx <= EF_LIMIT;
+    return mx <= limit;
 }
 
 // Stage-in with ONE memory round trip: the workgroup-lifetime profile (s_memtime) showed the stage-in taking longer
@@ -148,6 +153,149 @@ __device__ __forceinline__ float rcp1p_mul(float a, float b) {      // 1 / (1 + 
 }
 
 // ------------------------------------------------------------------------------------------
+// First GCN layer folded into the stage-in (FOLD): the layer's P/Q slice is an affine function of the <= 32 raw node
+// features, PQ_1 = Xp (Wcat_1 We)^T + Wcat_1 be, and so is its input H_0 = Xp We^T + be.  Instead of reading them from
+// HBM (and a K = 32 GEMM writing them there: 1.7 GB written + 2.9 GB re-read per step at B = 2048, D = 256) the workgroup
+// computes its (graph, panel) slice with the matrix cores straight into LDS: a wave takes a 32-node tile,
+// v_mfma_f32_32x32x2_f32 with the 32 LDS floats of a node (8 column pairs x [P,P,Q,Q], or the 16 H columns) as the
+// register dimension and the nodes as the lane dimension, so a lane ends up with whole 16-byte LDS groups of ONE node.
+// Only the first 24 features can be non-zero (node_dim <= 24; column 31 of Xp is the ones column of the bias-gradient
+// trick and meets a zero weight), and the K order is free: lane half kh covers features 12 kh .. 12 kh + 11, three
+// 16-byte loads per operand and 12 MFMA steps.  The backward recomputes the same slice with the same code
+// (bit-identical to the forward's).  Everything stays within the 64 VGPRs of a two-workgroups-per-CU kernel.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16e __attribute__((ext_vector_type(16)));
+
+// Operands of one 32-node tile, all loaded up front (ONE memory round trip per tile): the node features and the weight
+// rows of either the tile's 32 P/Q floats or its 16 H_0 columns.  The bias rides along as a 13th k step (bias x 1, the
+// upper lane half contributes 0), so the epilogue has no memory access of its own.
+struct FoldOps {
+    float4 xa[3], wa[3];
+    float bias;
+};
+
+__device__ __forceinline__ void fold_load_x(const FoldArgs &fa, int64_t M, int64_t o, int n, int tile, FoldOps &ops) {
+    const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
+    const int vc = min(tile * 32 + r, n - 1);
+    // features 12 kh + 4 q .. + 3:  kh = 0: panel 0 floats 0, 4, 8;  kh = 1: panel 0 float 12, panel 1 floats 0, 4
+    const float *x0 = fa.Xp + (o + vc) * 16, *x1 = x0 + M * 16;
+    ops.xa[0] = *reinterpret_cast<const float4 *>(kh ? x0 + 12 : x0);
+    ops.xa[1] = *reinterpret_cast<const float4 *>(kh ? x1 : x0 + 4);
+    ops.xa[2] = *reinterpret_cast<const float4 *>(kh ? x1 + 4 : x0 + 8);
+}
+
+__device__ __forceinline__ void fold_load_w(const FoldArgs &fa, int p, bool h, FoldOps &ops) {
+    const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
+    // weight row behind LDS float r of a node.  P/Q tile: pair q = r / 4 holds [P_2q, P_2q+1, Q_2q, Q_2q+1] (Wcat rows
+    // in P/Q panel order: 32 p + 16 side + column); H tile: column r (< 16; the upper half of the tile is discarded)
+    const int wrow = h ? 16 * p + (r & 15) : 32 * p + 16 * ((r >> 1) & 1) + 2 * (r >> 2) + (r & 1);
+    const float4 *w4 = reinterpret_cast<const float4 *>((h ? fa.We : fa.W1c) + (int64_t)wrow * 32 + 12 * kh);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ops.wa[q] = w4[q];
+    ops.bias = (h ? fa.be : fa.b1c)[wrow];
+}
+
+// the tile's matrix chain and its write to LDS; returns the largest |C2 * value| of the P/Q floats written
+__device__ __forceinline__ float fold_mma(const FoldOps &ops, int n, int tile, bool h, float2 *PQl, float *Xl, bool expform) {
+    const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
+    f32x16e acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ops.wa[q].x, ops.xa[q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ops.wa[q].y, ops.xa[q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ops.wa[q].z, ops.xa[q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ops.wa[q].w, ops.xa[q].w, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kh ? 0.f : ops.bias, 1.0f, acc, 0, 0, 0);
+    // accumulator 4 g + t of this lane = LDS float 8 g + 4 kh + t of node tile * 32 + r
+    const int v = tile * 32 + r;
+    float mx = 0.f;
+    if (v >= n) return mx;
+    if (!h) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int q = 2 * g + kh;                  // column pair
+            const float y0 = C2 * acc[4 * g + 0], y1 = C2 * acc[4 * g + 1];
+            const float y2 = C2 * acc[4 * g + 2], y3 = C2 * acc[4 * g + 3];
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(y0), fabsf(y1))), fmaxf(fabsf(y2), fabsf(y3)));
+            float4 *d = reinterpret_cast<float4 *>(reinterpret_cast<float *>(PQl) + v * 32 + 4 * q);
+            if (expform)
+                *d = make_float4(__builtin_amdgcn_exp2f(y0), __builtin_amdgcn_exp2f(y1), __builtin_amdgcn_exp2f(y2),
+                                 __builtin_amdgcn_exp2f(y3));
+            else
+                *d = make_float4(y0, y1, y2, y3);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int c = 8 * g + 4 * kh;
+            *reinterpret_cast<float4 *>(Xl + v * 16 + c) = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+    }
+    return mx;
+}
+
+// The (graph, panel) slice of the folded first layer: P/Q (always) and H_0 (WITH_H: the forward).  Up to 512 nodes
+// (T <= 16 tiles) every wave has one trip: wave w < T takes P/Q tile w; the H tiles go to the idle waves T .. 15 first and
+// the rest to the wave that holds the same nodes' P/Q tile (its node-feature operand is reused).  Split in two so the
+// caller can commit its own in-flight loads to LDS between the operand fetch and the matrix chain.
+struct FoldRole {
+    int tile;          // < 0: this wave has no tile
+    bool h, both;      // h: the first chain is the H tile;  both: a P/Q tile followed by the same nodes' H tile
+};
+template <bool WITH_H>
+__device__ __forceinline__ FoldRole fold_begin(const FoldArgs &fa, int64_t M, int64_t o, int n, int p, FoldOps &ops) {
+    const int w = threadIdx.x >> 6;
+    const int T = (n + 31) >> 5;
+    FoldRole R{-1, false, false};
+    if (T > EDGE_WAVES) return R;                     // > 512 nodes: fold_end walks the tiles one after the other
+    if (w < T) {
+        R.tile = w;
+        R.both = WITH_H && w >= EDGE_WAVES - T;
+    } else if (WITH_H && w - T < T) {
+        R.tile = w - T;
+        R.h = true;
+    }
+    if (R.tile >= 0) {
+        fold_load_x(fa, M, o, n, R.tile, ops);
+        fold_load_w(fa, p, R.h, ops);
+    }
+    return R;
+}
+template <bool WITH_H>
+__device__ __forceinline__ float fold_end(const FoldArgs &fa, int64_t M, int64_t o, int n, int p, const FoldRole &R, FoldOps &ops,
+                                          float2 *PQl, float *Xl, bool expform) {
+    const int T = (n + 31) >> 5;
+    float mx = 0.f;
+    if (T > EDGE_WAVES) {
+        for (int it = threadIdx.x >> 6; it < (WITH_H ? 2 : 1) * T; it += EDGE_WAVES) {
+            const bool h = it >= T;
+            fold_load_x(fa, M, o, n, h ? it - T : it, ops);
+            fold_load_w(fa, p, h, ops);
+            mx = fmaxf(mx, fold_mma(ops, n, h ? it - T : it, h, PQl, Xl, expform));
+        }
+        return mx;
+    }
+    if (R.tile < 0) return mx;
+    mx = fold_mma(ops, n, R.tile, R.h, PQl, Xl, expform);
+    if (WITH_H && R.both) {
+        fold_load_w(fa, p, true, ops);
+        fold_mma(ops, n, R.tile, true, PQl, Xl, expform);
+    }
+    return mx;
+}
+// both halves back to back (re-staging in linear form, un-batched stage-in)
+template <bool WITH_H>
+__device__ __forceinline__ float fold_fill(const FoldArgs &fa, int64_t M, int64_t o, int n, int p, float2 *PQl, float *Xl,
+                                           bool expform) {
+    FoldOps ops;
+    const FoldRole R = fold_begin<WITH_H>(fa, M, o, n, p, ops);
+    return fold_end<WITH_H>(fa, M, o, n, p, R, ops, PQl, Xl, expform);
+}
+
+// ------------------------------------------------------------------------------------------
 // forward: H_out = H_in + S / (deg + 1e-6).  The last layer also emits the masked node mean, the edge
 // mean (= 1/2 sum_v S_v / e: every message is counted at both of its endpoints) and -- fused, while the
 // P/Q slices are still in LDS -- the land-use pointer-head inputs of the row's candidate edges.  The head's
@@ -155,14 +303,15 @@ __device__ __forceinline__ float rcp1p_mul(float a, float b) {      // 1 / (1 + 
 // with W1 = [Wa|Wb|Wc|Wd] that is (Wa+Wd) m + Wc (m*c) + (Wb-Wd) c, so only FE = [m ; m*c] is materialised and
 // the c-only term becomes a per-row bias.
 // ------------------------------------------------------------------------------------------
-template <bool LAST, bool STAGE>
-__global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
+template <bool LAST, bool STAGE, bool FOLD>
+__global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), amdgpu_waves_per_eu(8, 8))) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
                                                                 const float *__restrict__ PQ,
                                                                 const float *__restrict__ bias,
                                                                 const float *__restrict__ Hin, float *__restrict__ Hout,
                                                                 float *__restrict__ hbarV, float *__restrict__ hbarE,
                                                                 const float *__restrict__ Ccur, float *__restrict__ FE,
-                                                                int aux_cap, int fit) {
+                                                                int aux_cap, int fit, FoldArgs fa) {
+    static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;      // one scalar load: meta row + minibatch offsets
@@ -188,7 +337,38 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
     const uint32_t *nbg = reinterpret_cast<const uint32_t *>(pk.inc_nbr + 2 * (int64_t)m[10]);
     const uint16_t *og = pk.order + m[9];
     const uint8_t *nmg = pk.nmask + m[9];
-    if (STAGE && fits_batched(n, e)) {
+    if (FOLD) {
+        // lists first (their loads are in flight while the matrix cores build the slice), then the slice
+        const int i0 = tid, i1 = tid + EDGE_THREADS;
+        const bool lb = fits_batched(n, e);
+        uint32_t nb0 = 0, nb1 = 0, rOrd = 0, rNm = 0;
+        int rRp = 0;
+        if (lb) {
+            nb0 = nbg[i0 < e ? i0 : 0]; nb1 = nbg[i1 < e ? i1 : 0];
+            rRp = rpg[tid <= n ? tid : 0];
+            rOrd = og[tid < n ? tid : 0]; rNm = nmg[tid < n ? tid : 0];
+        }
+        FoldOps ops;
+        const FoldRole role = fold_begin<true>(fa, M, o, n, p, ops);
+        if (lb) {
+            if (i0 < e) reinterpret_cast<uint32_t *>(L.nb)[i0] = nb0;
+            if (i1 < e) reinterpret_cast<uint32_t *>(L.nb)[i1] = nb1;
+            if (tid <= n) L.rp[tid] = rRp;
+            if (tid < n) {
+                L.ord[tid] = (uint16_t)rOrd;
+                L.nm[tid] = (uint8_t)rNm;
+            }
+        } else {
+            for (int i = tid; i <= n; i += EDGE_THREADS) L.rp[i] = rpg[i];
+            for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
+            for (int i = tid; i < n; i += EDGE_THREADS) {
+                L.ord[i] = og[i];
+                L.nm[i] = nmg[i];
+            }
+        }
+        const float mx = fold_end<true>(fa, M, o, n, p, role, ops, L.PQ, L.X, true);
+        ok = mx <= EF_LIMIT_FWD && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+    } else if (STAGE && fits_batched(n, e)) {
         const float4 *p4 = reinterpret_cast<const float4 *>(Pg), *q4 = reinterpret_cast<const float4 *>(Qg);
         const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
         // (plain named registers on purpose: with small arrays the compiler parked part of them in scratch memory)
@@ -217,10 +397,10 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
             L.ord[tid] = (uint16_t)rOrd;
             L.nm[tid] = (uint8_t)rNm;
         }
-        ok = mx <= EF_LIMIT && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+        ok = mx <= EF_LIMIT_FWD && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
     } else {
         if (STAGE) {
-            ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+            ok = stage_pq_exp(L.PQ, Pg, Qg, n, EF_LIMIT_FWD) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
             const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
             for (int i = tid; i < n * 4; i += EDGE_THREADS) reinterpret_cast<float4 *>(L.X)[i] = h4[i];
         }
@@ -248,25 +428,33 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
     if (STAGE) {
         ef = !__syncthreads_or(ok ? 0 : 1);
         if (!ef) {                         // magnitudes outside the exp-form range: linear form, exponentials in the loop
-            stage_pq(L.PQ, Pg, Qg, n);
+            if (FOLD) fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, false);
+            else stage_pq(L.PQ, Pg, Qg, n);
             __syncthreads();
         }
     } else {
         __syncthreads();
     }
 
-    // (P_ca, Q_ca, P_ca+1, Q_ca+1) of node u: exp form or scaled linear form
+    // (P_ca, P_ca+1, Q_ca, Q_ca+1) of node u: exp form or scaled linear form
     auto pq4 = [&](int u) -> float4 {
         if (STAGE) return *reinterpret_cast<const float4 *>(L.PQ + u * 16 + ca);
         const float2 pp = *reinterpret_cast<const float2 *>(Pg + u * 16 + ca);
         const float2 qq = *reinterpret_cast<const float2 *>(Qg + u * 16 + ca);
-        return make_float4(C2 * pp.x, C2 * qq.x, C2 * pp.y, C2 * qq.y);
+        return make_float4(C2 * pp.x, C2 * pp.y, C2 * qq.x, C2 * qq.y);
     };
     float2 sumS = make_float2(0.f, 0.f), sumH = make_float2(0.f, 0.f);
     auto walk = [&](auto efc) {
         constexpr bool EF = decltype(efc)::value;
-        // r for an own-side value (bias folded in) and a neighbour-side value
-        auto r = [](float a, float nb) -> float { return EF ? rcp1p_mul(a, nb) : rcp1p_exp2(a + nb); };
+        // r1 + r2 of one edge and column: own-side values a1 (P side), a2 (Q side) with the bias folded in, neighbour-side
+        // values n1 (its Q), n2 (its P).  Exp form: one reciprocal for both (see EF_LIMIT_FWD).
+        auto rsum = [](float a1, float n1, float a2, float n2) -> float {
+            if (EF) {
+                const float t = fmaf(a1, n1, 1.0f), u = fmaf(a2, n2, 1.0f);
+                return (t + u) * __builtin_amdgcn_rcpf(t * u);
+            }
+            return rcp1p_exp2(a1 + n1) + rcp1p_exp2(a2 + n2);
+        };
         const float2 eb = make_float2(EF ? __builtin_amdgcn_exp2f(bc.x) : bc.x, EF ? __builtin_amdgcn_exp2f(bc.y) : bc.y);
         auto fold = [&](float x, float bb) -> float { return EF ? x * bb : x + bb; };
         const int nchunks = (n + 7) >> 3;
@@ -278,15 +466,15 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
             const bool valid = vi < n;
             const int v = L.ord[valid ? vi : n - 1];
             const float4 own = pq4(v);
-            const float pv0 = fold(own.x, eb.x), qv0 = fold(own.y, eb.x), pv1 = fold(own.z, eb.y), qv1 = fold(own.w, eb.y);
+            const float pv0 = fold(own.x, eb.x), qv0 = fold(own.z, eb.x), pv1 = fold(own.y, eb.y), qv1 = fold(own.w, eb.y);
             int k = L.rp[v];
             const int k1 = valid ? L.rp[v + 1] : k;
             const float degf = (float)(k1 - k);
             float acc0 = 0.f, acc1 = 0.f;          // sums over incidences of r1 + r2, per column
             for (; k < k1; ++k) {
                 const float4 nb = pq4(L.nb[k]);
-                acc0 += r(pv0, nb.y) + r(qv0, nb.x);
-                acc1 += r(pv1, nb.w) + r(qv1, nb.z);
+                acc0 += rsum(pv0, nb.z, qv0, nb.x);
+                acc1 += rsum(pv1, nb.w, qv1, nb.y);
             }
             if (valid) {
                 const float S0 = degf - acc0, S1 = degf - acc1;     // 1/2 sum (tanh1 + tanh2) = 1/2 (2 deg - 2 acc)
@@ -323,8 +511,8 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
                 if (cand_lds ? a_live[q] : pk.he_live[m[11] + q]) {
                     const float4 vi4 = pq4(cand_lds ? a_src[q] : pk.he_src[m[11] + q]);
                     const float4 vj4 = pq4(cand_lds ? a_dst[q] : pk.he_dst[m[11] + q]);
-                    mm.x = 1.f - (r(fold(vi4.x, eb.x), vj4.y) + r(fold(vj4.x, eb.x), vi4.y));
-                    mm.y = 1.f - (r(fold(vi4.z, eb.y), vj4.w) + r(fold(vj4.z, eb.y), vi4.w));
+                    mm.x = 1.f - rsum(fold(vi4.x, eb.x), vj4.z, fold(vj4.x, eb.x), vi4.z);
+                    mm.y = 1.f - rsum(fold(vi4.y, eb.y), vj4.w, fold(vj4.y, eb.y), vi4.w);
                 }
                 const int64_t row = q0 + q;
                 *reinterpret_cast<float2 *>(FE + ((int64_t)p * NH + row) * 16 + ca) = mm;
@@ -362,26 +550,35 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
     }
 }
 
+bool edge_fold_ok(const MbView &mb) {
+    return edge_lds_bytes(mb.max_n, mb.max_inc, false, false, true) <= LDS_LIMIT &&
+           edge_lds_bytes(mb.max_n, mb.max_inc, true, false, true) <= LDS_LIMIT;
+}
+
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
-                    hipStream_t st, Profiler *prof) {
+                    hipStream_t st, Profiler *prof, const FoldArgs *fold) {
     const int NP = D / 16;
+    const FoldArgs fa = fold ? *fold : FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (fold && (last || !edge_fold_ok(mb)))
+        return fail(UPAMD_E_LIMIT, "edge_fwd: the folded first layer needs the staged size class and a later layer behind it");
     const int began = prof_begin(prof, "edge_fwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
     // one launch of a given (stage, lds, fit) configuration
     auto go = [&](bool stage, int64_t lds, int aux_cap, int fit) -> int {
-#define UPAMD_EF(L_, S_)                                                                                              \
+#define UPAMD_EF(L_, S_, F_)                                                                                          \
     do {                                                                                                              \
         if (lds > 64 * 1024)                                                                                          \
-            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_>),                   \
+            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_>),               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-        hipLaunchKernelGGL((edge_fwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, Hout,  \
-                           hbarV, hbarE, Ccur, FE, aux_cap, fit);                                                     \
+        hipLaunchKernelGGL((edge_fwd_kernel<L_, S_, F_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin,    \
+                           Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa);                                           \
     } while (0)
-        if (last && stage) UPAMD_EF(true, true);
-        else if (last) UPAMD_EF(true, false);
-        else if (stage) UPAMD_EF(false, true);
-        else UPAMD_EF(false, false);
+        if (fold) UPAMD_EF(false, true, true);
+        else if (last && stage) UPAMD_EF(true, true, false);
+        else if (last) UPAMD_EF(true, false, false);
+        else if (stage) UPAMD_EF(false, true, false);
+        else UPAMD_EF(false, false, false);
 #undef UPAMD_EF
         UPAMD_HIP(hipGetLastError());
         return 0;
@@ -424,14 +621,16 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
 // The pointer-head term touches only the row's candidate edges: it is added from the packer's per-node
 // candidate-incidence lists after the main walk, so the main loop stays branch-free.
 // ------------------------------------------------------------------------------------------
-template <bool LAST, bool STAGE>
-__global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) void edge_bwd_kernel(PackedView pk, MbView mb, int NP,
+template <bool LAST, bool STAGE, bool FOLD>
+__global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), amdgpu_waves_per_eu(8, 8))) void edge_bwd_kernel(PackedView pk, MbView mb, int NP,
                                                                 const float *__restrict__ PQ,
                                                                 const float *__restrict__ bias,
                                                                 const float *__restrict__ G,
                                                                 const float *__restrict__ dhbarE, int ld_dhbarE,
                                                                 const float *__restrict__ dMhe, float *__restrict__ dPQ,
-                                                                float *__restrict__ dbias_part, int aux_cap, int fit) {
+                                                                float *__restrict__ dbias_part, int aux_cap, int fit,
+                                                                FoldArgs fa) {
+    static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;      // one scalar load: meta row + minibatch offsets
@@ -463,7 +662,11 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
         const bool in0 = i0 < n * 4, in1 = i1 < n * 4;
         // unconditional loads from clamped (always valid) indices, see edge_fwd_kernel
         const int c0 = in0 ? i0 : 0, c1 = in1 ? i1 : 0;
-        const float4 p0 = p4[c0], q0 = q4[c0], g0 = g4[c0], p1 = p4[c1], q1 = q4[c1], g1 = g4[c1];
+        const float4 g0 = g4[c0], g1 = g4[c1];
+        float4 p0 = z4, q0 = z4, p1 = z4, q1 = z4;
+        if (!FOLD) {
+            p0 = p4[c0]; q0 = q4[c0]; p1 = p4[c1]; q1 = q4[c1];
+        }
         const int d00 = rpg[c0 >> 2], d01 = rpg[(c0 >> 2) + 1];     // row pointers of the G rows (their degrees)
         const int d10 = rpg[c1 >> 2], d11 = rpg[(c1 >> 2) + 1];
         const uint32_t nb0 = nbg[i0 < e ? i0 : 0], nb1 = nbg[i1 < e ? i1 : 0];
@@ -475,14 +678,15 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
             ex4 = make_float4(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e, 0.5f * dh.z / (float)e, 0.5f * dh.w / (float)e);
         }
         float mx = 0.f;
+        if (FOLD) mx = fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, true);
         if (in0) {
-            mx = put_pq_exp(L.PQ, i0, p0, q0);
+            if (!FOLD) mx = put_pq_exp(L.PQ, i0, p0, q0);
             const float inv = __builtin_amdgcn_rcpf((float)(d01 - d00) + 1e-6f);
             reinterpret_cast<float4 *>(L.X)[i0] = make_float4(fmaf(g0.x, inv, ex4.x), fmaf(g0.y, inv, ex4.y),
                                                               fmaf(g0.z, inv, ex4.z), fmaf(g0.w, inv, ex4.w));
         }
         if (in1) {
-            mx = fmaxf(mx, put_pq_exp(L.PQ, i1, p1, q1));
+            if (!FOLD) mx = fmaxf(mx, put_pq_exp(L.PQ, i1, p1, q1));
             const float inv = __builtin_amdgcn_rcpf((float)(d11 - d10) + 1e-6f);
             reinterpret_cast<float4 *>(L.X)[i1] = make_float4(fmaf(g1.x, inv, ex4.x), fmaf(g1.y, inv, ex4.y),
                                                               fmaf(g1.z, inv, ex4.z), fmaf(g1.w, inv, ex4.w));
@@ -517,10 +721,14 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
     }
     bool ef = false;                       // LDS holds the exp form (workgroup-uniform), see stage_pq_exp
     if (STAGE) {
-        if (!batched) ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+        if (!batched) {
+            if (FOLD) ok = fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, true) <= EF_LIMIT && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+            else ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+        }
         ef = !__syncthreads_or(ok ? 0 : 1);
         if (!ef) {
-            stage_pq(L.PQ, Pg, Qg, n);
+            if (FOLD) fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, false);
+            else stage_pq(L.PQ, Pg, Qg, n);
             __syncthreads();
         }
     } else {
@@ -551,7 +759,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
         if (STAGE) return *reinterpret_cast<const float4 *>(L.PQ + u * 16 + ca);
         const float2 pp = *reinterpret_cast<const float2 *>(Pg + u * 16 + ca);
         const float2 qq = *reinterpret_cast<const float2 *>(Qg + u * 16 + ca);
-        return make_float4(C2 * pp.x, C2 * qq.x, C2 * pp.y, C2 * qq.y);
+        return make_float4(C2 * pp.x, C2 * pp.y, C2 * qq.x, C2 * qq.y);
     };
     auto ds2 = [&](int u) -> float2 {
         if (STAGE) return *reinterpret_cast<const float2 *>(L.X + u * 16 + ca);
@@ -577,12 +785,12 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
             int k = L.rp[v];
             const int k1 = valid ? L.rp[v + 1] : k;
             const float4 own = pq4(v);
-            const float pv0 = fold(own.x, eb.x), qv0 = fold(own.y, eb.x), pv1 = fold(own.z, eb.y), qv1 = fold(own.w, eb.y);
+            const float pv0 = fold(own.x, eb.x), qv0 = fold(own.z, eb.x), pv1 = fold(own.y, eb.y), qv1 = fold(own.w, eb.y);
             const float2 sv = ds2(v);
             // sums of dm * (r - r^2) per column; 1 - tanh^2 = 4 (r - r^2)
             float aP0 = 0.f, aQ0 = 0.f, aP1 = 0.f, aQ1 = 0.f;
             auto add = [&](const float4 &nb, float dm0, float dm1) {
-                const float r1 = r(pv0, nb.y), r2 = r(qv0, nb.x), r3 = r(pv1, nb.w), r4 = r(qv1, nb.z);
+                const float r1 = r(pv0, nb.z), r2 = r(qv0, nb.x), r3 = r(pv1, nb.w), r4 = r(qv1, nb.y);
                 aP0 = fmaf(dm0, fmaf(-r1, r1, r1), aP0);
                 aQ0 = fmaf(dm0, fmaf(-r2, r2, r2), aQ0);
                 aP1 = fmaf(dm1, fmaf(-r3, r3, r3), aP1);
@@ -647,23 +855,27 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72))) 
 
 int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
-                    float *dbias_part, hipStream_t st, Profiler *prof) {
+                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold) {
     const int NP = D / 16;
+    const FoldArgs fa = fold ? *fold : FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (fold && (last || !edge_fold_ok(mb)))
+        return fail(UPAMD_E_LIMIT, "edge_bwd: the folded first layer needs the staged size class and a later layer behind it");
     const int began = prof_begin(prof, "edge_bwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
     auto go = [&](bool stage, int64_t lds, int aux_cap, int fit) -> int {
-#define UPAMD_EB(L_, S_)                                                                                              \
+#define UPAMD_EB(L_, S_, F_)                                                                                          \
     do {                                                                                                              \
         if (lds > 64 * 1024)                                                                                          \
-            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_>),                   \
+            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_, F_>),               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-        hipLaunchKernelGGL((edge_bwd_kernel<L_, S_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G, dhbarE,  \
-                           ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit);                                           \
+        hipLaunchKernelGGL((edge_bwd_kernel<L_, S_, F_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G,      \
+                           dhbarE, ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit, fa);                               \
     } while (0)
-        if (last && stage) UPAMD_EB(true, true);
-        else if (last) UPAMD_EB(true, false);
-        else if (stage) UPAMD_EB(false, true);
-        else UPAMD_EB(false, false);
+        if (fold) UPAMD_EB(false, true, true);
+        else if (last && stage) UPAMD_EB(true, true, false);
+        else if (last) UPAMD_EB(true, false, false);
+        else if (stage) UPAMD_EB(false, true, false);
+        else UPAMD_EB(false, false, false);
 #undef UPAMD_EB
         UPAMD_HIP(hipGetLastError());
         return 0;

@@ -239,6 +239,10 @@ static int debug_sync(const char *what) {
 
 // slabs[s][I][J] = partial sums of A[rows, I](pm)^T * Bm[rows, J](pm): the tiled split-K MFMA kernel where the shape allows
 // (I % 128 == 0), otherwise one grouped-kernel launch with panel-major operands (narrow models: D = 16 ... 64)
+// tune knob "fold_layer1" (default on): first GCN layer computed inside the message-passing kernels
+static int g_fold_layer1 = 1;
+static bool fold_layer1(const MbView &mb, int L) { return g_fold_layer1 && L >= 2 && edge_fold_ok(mb); }
+
 int node_tn(const float *A, int I, const float *Bm, int J, int64_t rows, float *slabs, int *S_out, hipStream_t st, Profiler *prof) {
     if (tn_shape_mfma_ok(I, J)) return launch_gemm_tn(A, I, Bm, J, rows, slabs, S_out, st, prof);
     TnJobs tj;
@@ -274,8 +278,16 @@ int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch
     const int64_t B = mb.B, M = mb.n_nodes, NH = mb.n_he, NR = mb.n_rn;
     auto num = [&](size_t pos) { return atoi(n.c_str() + pos); };
     *kind = 0;
-    if (n[0] == 'H' && n.size() > 1 && isdigit(n[1])) { *rows = M; *cols = x.D; *kind = 1; return num(1) <= x.L ? S_H + num(1) : -1; }
-    if (n.rfind("PQ", 0) == 0) { *rows = M; *cols = 2 * x.D; *kind = 1; return (num(2) >= 1 && num(2) <= x.L) ? S_PQ + num(2) : -1; }
+    // with the first layer folded into the message-passing kernels H0 and PQ1 are never materialised
+    const bool folded = !x.mlp && fold_layer1(make_mb(mb), x.L);
+    if (n[0] == 'H' && n.size() > 1 && isdigit(n[1])) {
+        *rows = M; *cols = x.D; *kind = 1;
+        return (num(1) <= x.L && !(folded && num(1) == 0)) ? S_H + num(1) : -1;
+    }
+    if (n.rfind("PQ", 0) == 0) {
+        *rows = M; *cols = 2 * x.D; *kind = 1;
+        return (num(2) >= 1 && num(2) <= x.L && !(folded && num(2) == 1)) ? S_PQ + num(2) : -1;
+    }
     if (n == "dPQ") { *rows = M; *cols = 2 * x.D; *kind = 1; return S_DPQ; }
     if (n == "G0" || n == "G1") { *rows = M; *cols = x.D; *kind = 1; return n == "G0" ? S_G0 : S_G1; }
     if (n == "Xp") { *rows = M; *cols = 32; *kind = 1; return S_XP; }
@@ -328,6 +340,8 @@ int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch
 }
 
 }  // namespace
+
+void upamd::set_fold_layer1(int on) { g_fold_layer1 = on ? 1 : 0; }
 
 extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
     if (!out) return fail(UPAMD_E_INVALID, "upamd_engine_create: out is null");
@@ -546,15 +560,20 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     // ---- 4. node encoder on all nodes (state_encoder.py:189-190) and the GCN layers (state_encoder.py:194-197).
     // Layer 1 reads its P/Q straight from the raw node features:
     // PQ_1 = H_0 Wcat_1^T = Xp (Wcat_1 We)^T + Wcat_1 be  (K = 32 instead of D: saves one full-size node GEMM)
-    CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_WE_PAD), D, PR(P.node_b), nullptr, W(S_H + 0), 0, st, prof));
+    // With the fold (default) neither H_0 nor PQ_1 ever exists in HBM: the layer-1 message-passing workgroups build
+    // their slices from Xp in LDS (edge.hip: fold_fill); otherwise two K = 32 GEMMs write them out.
+    const bool fold = fold_layer1(mb, x.L);
+    const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
+    if (!fold) CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_WE_PAD), D, PR(P.node_b), nullptr, W(S_H + 0), 0, st, prof));
     for (int l = 1; l <= x.L; ++l) {
-        if (l == 1)
-            CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_W1C), 2 * D, W(S_B1C), nullptr, W(S_PQ + 1), 0, st, prof));
-        else
+        if (l == 1) {
+            if (!fold) CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_W1C), 2 * D, W(S_B1C), nullptr, W(S_PQ + 1), 0, st, prof));
+        } else {
             CK(launch_gemm_nt(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), 2 * D, nullptr, nullptr, W(S_PQ + l), 0, st, prof));
+        }
         // the last layer also writes the land-use pointer-head inputs FE (needs C, computed above)
         CK(launch_edge_fwd(pk, mb, D, l == x.L, W(S_PQ + l), PR(P.edge_b[l - 1]), W(S_H + l - 1), W(S_H + l), W(S_HBARV), W(S_HBARE),
-                           W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, prof));
+                           W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, prof, (l == 1 && fold) ? &fa : nullptr));
     }
     // ---- 5. attention core, then the per-sample chain after it (out-projection, state_value, value head)
     CK(launch_attn_fwd(pk, mb, D, x.heads, W(S_H + x.L), W(S_R), W(S_ALPHA), W(S_S), st));
@@ -782,10 +801,12 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_chain_bwd_pre(a, st));
     }
     // ---- 5. GCN layers, last to first
+    const bool fold = fold_layer1(mb, x.L);      // the forward's decision (same minibatch): PQ_1 was never written
+    const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
     for (int l = x.L; l >= 1; --l) {
         const bool last = (l == x.L);
         CK(launch_edge_bwd(pk, mb, D, last, W(S_PQ + l), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp, (last && land) ? W(S_DMHE) : nullptr,
-                           W(S_DPQ), W(S_DBIAS + l), st, prof));
+                           W(S_DPQ), W(S_DBIAS + l), st, prof, (l == 1 && fold) ? &fa : nullptr));
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
         CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
         if (l > 1) {

@@ -93,12 +93,20 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
 int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st);
 __host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage);
 int launch_gather_rows(const PackedView &pk, const MbView &mb, int32_t *rows, hipStream_t st);
+// First GCN layer folded into the message-passing stage-in (edge.hip: fold_fill): the workgroup computes its P/Q (and
+// H_0) slice from the raw node features.  Xp: panel-major [2][M][16]; W1c = Wcat_1 We [2D][32] (rows in P/Q panel
+// order), b1c [2D]; We (zero-padded) [D][32], be [D].
+struct FoldArgs {
+    const float *Xp, *W1c, *b1c, *We, *be;
+};
+bool edge_fold_ok(const MbView &mb);
+void set_fold_layer1(int on);              // tune knob: compute the first GCN layer inside the message-passing kernels       // every graph of the minibatch fits the staged (LDS-resident) size classes
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
-                    hipStream_t st, Profiler *prof);
+                    hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr);
 int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
-                    float *dbias_part, hipStream_t st, Profiler *prof);
+                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr);
 int launch_attn_fwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     float *alpha, float *s, hipStream_t st);
 int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
@@ -234,14 +242,17 @@ int launch_prep_land_head(const float *W1, int D, int h0, float *W1f, float *Wbd
 int launch_land_head_w_scatter(const float *dW1f, const float *dWbd, int D, int h0, float *gW1, hipStream_t st);
 int launch_add_p_panels(float *dst, const float *src, int D, hipStream_t st);   // dst[D] += P half of src[2D] (P/Q panel order)
 int launch_scale(float *dst, int64_t n, float alpha, hipStream_t st);                     // dst *= alpha
-int launch_ppo_loss(int B, const float *value, const float *logp, const float *ent, const float *adv,
+int launch_ppo_loss(int B, const float *value, const float *logp, const float *ent, const int64_t *rows, const float *adv,
                     const float *ret, const float *old_logp, const float *exps, float clip_eps, float cv, float ce,
                     float inv_rows, float inv_ind, float *dvalue, float *dlogp, float *dent, float *losses,
-                    hipStream_t st);
+                    float *zero, int64_t nzero, hipStream_t st);
 int launch_gae(int64_t T, const float *rewards, const float *masks, const float *values, double gamma, double tau,
                float *adv, float *ret, hipStream_t st);
 int launch_adam(int64_t n, float *p, const float *g, float *m, float *v, int step, double lr, double b1, double b2,
                 double eps, double wd, hipStream_t st);
+int launch_adam_groups(int n_groups, const int64_t *begin, const int64_t *end, const int32_t *step, float *p, const float *g,
+                       float *m, float *v, double lr, double b1, double b2, double eps, double wd, const float *loss_src,
+                       float *loss_dst, hipStream_t st);
 int launch_sumsq(const float *x, int64_t n, float *scratch, float *out_accum, hipStream_t st);
 int launch_clip_scale(float *g, int64_t n, const float *sumsq, float max_norm, hipStream_t st);
 

@@ -151,6 +151,18 @@ class NativeEngine:
                                                  _ptr(dvalue), _ptr(dlogp), _ptr(dent), _ptr(losses), self._st()),
                          'upamd_ppo_loss')
 
+    def ppo_loss_rows(self, B, value, logp, ent, rows, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind,
+                      dvalue, dlogp, dent, losses, zero=None):
+        """loss of the minibatch whose replay rows are `rows` (int64, device) + zeroing of `zero` in the same launch"""
+        assert rows.dtype == torch.int64 and rows.is_contiguous()
+        with self._on_device():
+            native.check(self.lib.upamd_ppo_loss_rows(B, _ptr(value), _ptr(logp), _ptr(ent), _ptr(rows), _ptr(adv),
+                                                      _ptr(ret), _ptr(old_logp), _ptr(exps), clip_eps, cv, ce, inv_rows,
+                                                      inv_ind, _ptr(dvalue), _ptr(dlogp), _ptr(dent), _ptr(losses),
+                                                      _ptr(zero) if zero is not None else None,
+                                                      zero.numel() if zero is not None else 0, self._st()),
+                         'upamd_ppo_loss_rows')
+
     def gae(self, rewards, masks, values, gamma, tau, adv, ret):
         with self._on_device():
             native.check(self.lib.upamd_gae(rewards.numel(), _ptr(rewards), _ptr(masks), _ptr(values), float(gamma),
@@ -167,6 +179,19 @@ class NativeEngine:
             native.check(self.lib.upamd_adam_step(b, e, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), int(step),
                                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                                   self._st()), 'upamd_adam_step')
+
+    def adam_groups(self, steps, params, grads, m, v, lr, beta1, beta2, eps, weight_decay, loss_src=None, loss_dst=None):
+        """all optimizer groups in one launch; steps[g] = that group's 1-based step count, 0 = skip the group"""
+        n = len(self.groups)
+        b = (C.c_int64 * n)(*[g[0] for g in self.groups])
+        e = (C.c_int64 * n)(*[g[1] for g in self.groups])
+        st = (C.c_int32 * n)(*[int(x) for x in steps])
+        with self._on_device():
+            native.check(self.lib.upamd_adam_groups(n, b, e, st, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), float(lr),
+                                                    float(beta1), float(beta2), float(eps), float(weight_decay),
+                                                    _ptr(loss_src) if loss_src is not None else None,
+                                                    _ptr(loss_dst) if loss_dst is not None else None, self._st()),
+                         'upamd_adam_groups')
 
     # ---- profiling
     def profile(self, on):

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libupamd.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_MLP = 4
 META_STRIDE = 16
 NODE_PAD = 24
@@ -65,10 +65,14 @@ SYMBOLS = {
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     'upamd_ppo_loss': (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_float, _P, _P, _P, _P, _P]),
+    'upamd_ppo_loss_rows': (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float,
+                                      C.c_float, C.c_float, _P, _P, _P, _P, _P, C.c_int64, _P]),
     'upamd_gae': (C.c_int, [C.c_int64, _P, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
     'upamd_clip_first_step': (C.c_int, [C.POINTER(ModelDesc), _P, C.c_float, _P, _P]),
     'upamd_adam_step': (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_double, C.c_double, C.c_double,
                                   C.c_double, C.c_double, _P]),
+    'upamd_adam_groups': (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, _P, _P, _P]),
     'upamd_gemm_nt': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int64,
                                 C.c_int32, C.c_int32, C.c_float, _P]),
     'upamd_gemm_tn_scratch_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),

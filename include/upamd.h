@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define UPAMD_ABI_VERSION 2
+#define UPAMD_ABI_VERSION 3
 
 #define UPAMD_OK 0
 #define UPAMD_E_INVALID (-1)   /* bad argument / unsupported configuration            */
@@ -206,6 +206,17 @@ int upamd_ppo_loss(int32_t B, const float *value_dev, const float *logp_dev, con
                    float inv_rows, float inv_ind, float *dvalue_dev, float *dlogp_dev, float *dent_dev,
                    float *losses_dev, void *stream);
 
+/* The same loss for a minibatch given as ROW INDICES into the replay-wide arrays (what the reference's
+ * `advantages[ind]`, `returns[ind]`, `fixed_log_probs[ind]`, `exps[ind]` gathers do, urban_planning_agent.py:316-321),
+ * and -- fused, it is the launch in front of the backward -- the zeroing of the step's gradient buffer
+ * (optimizer.zero_grad(), :335): zero_dev[0 .. n_zero) = 0.  rows_dev: int64[B]. */
+int upamd_ppo_loss_rows(int32_t B, const float *value_dev, const float *logp_dev, const float *ent_dev,
+                        const int64_t *rows_dev, const float *adv_all_dev, const float *ret_all_dev,
+                        const float *old_logp_all_dev, const float *exps_all_dev, float clip_epsilon,
+                        float value_pred_coef, float entropy_coef, float inv_rows, float inv_ind,
+                        float *dvalue_dev, float *dlogp_dev, float *dent_dev, float *losses_dev,
+                        float *zero_dev, int64_t n_zero, void *stream);
+
 /* Generalised advantage estimation, bit-exact with the reference's Python loop
  * (khrylib/rl/core/common.py:5-26): trajectories are concatenated, masks[t]==0 ends an episode. */
 int upamd_gae(int64_t T, const float *rewards_dev, const float *masks_dev, const float *values_dev,
@@ -223,6 +234,15 @@ int upamd_clip_first_step(const upamd_model_desc *desc, float *grads_dev, float 
 int upamd_adam_step(int64_t begin, int64_t end, float *params_dev, const float *grads_dev, float *m_dev,
                     float *v_dev, int32_t step, double lr, double beta1, double beta2, double eps,
                     double weight_decay, void *stream);
+
+/* optimizer.step() for all groups of a step in one launch (same arithmetic as upamd_adam_step per group):
+ * host tables begin/end/step[n_groups <= 4]; step[k] == 0 skips group k (a head without rows in the minibatch has
+ * grad None in the reference and torch's Adam skips it).  loss_src_dev/loss_dst_dev (both or neither): the four loss
+ * scalars are copied out by the same launch (the caller's per-step log row). */
+int upamd_adam_groups(int32_t n_groups, const int64_t *begin, const int64_t *end, const int32_t *step,
+                      float *params_dev, const float *grads_dev, float *m_dev, float *v_dev, double lr,
+                      double beta1, double beta2, double eps, double weight_decay, const float *loss_src_dev,
+                      float *loss_dst_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * The two fp32-MFMA GEMM building blocks of the engine, exposed for kernel-level parity tests and
