@@ -100,6 +100,16 @@ extern "C" int upamd_gemm_nt(const float *A_dev, int64_t M, int32_t K, int64_t l
     return launch_gemm_nt_ex(g, static_cast<hipStream_t>(stream), nullptr);
 }
 
+extern "C" int64_t upamd_gemm_nt_split_scratch_bytes(int32_t N, int32_t K) { return gemm_nt_split_scratch_bytes(N, K); }
+
+extern "C" int upamd_gemm_nt_split(const float *A_dev, int64_t M, int32_t K, const float *W_dev, int32_t N, int64_t ldw,
+                                   const float *bias_dev, const float *R_dev, float *C_dev, int32_t act_tanh, float alpha,
+                                   int32_t n_products, void *scratch_dev, void *stream) {
+    if (!A_dev || !W_dev || !C_dev || M <= 0 || K <= 0 || N <= 0) return fail(UPAMD_E_INVALID, "upamd_gemm_nt_split: bad argument");
+    GemmNT g{A_dev, M, K, 0, false, W_dev, N, ldw, bias_dev, R_dev, C_dev, 0, false, act_tanh, alpha};
+    return launch_gemm_nt_split(g, scratch_dev, n_products, static_cast<hipStream_t>(stream), nullptr);
+}
+
 // lab hook: one wave samples (shader clock, 100 MHz wall clock) pairs while other streams run kernels; the ratio of the
 // differences is the effective shader clock under that load
 __global__ void clock_probe_kernel(long long *out, int samples, int gap_ticks) {

@@ -18,6 +18,8 @@
 //
 // Replaces the autograd of the reference's nn.Sequential / nn.Linear / nn.MultiheadAttention projections on [B, .]
 // tensors (urban_planning/models/state_encoder.py:35-57,150-161,187-191,204-205; value.py:15-39).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace upamd {
@@ -227,7 +229,9 @@ __device__ __forceinline__ void lin_rows(const float *__restrict__ Mat, int ld, 
             for (int r = 0; r < R; ++r) acc[r] = b;
             const float *mp = Mat + n;
             int k = 0;
-            for (; k + 16 <= K; k += 16) {          // 16 independent (coalesced) weight loads in flight, then the FMAs
+            // 16 independent (coalesced) weight loads in flight, then the FMAs.  (Deeper batches were measured: 32 and 64
+            // loads in flight make two of the four chain kernels slower -- 64 exceeds what the 6-bit vmcnt counter tracks.)
+            for (; k + 16 <= K; k += 16) {
                 float w[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) w[u] = mp[(int64_t)(k + u) * ld];

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "kernels.h"
@@ -39,7 +40,8 @@ enum Slot : int {
     S_CS = S_PQ + MAXL + 1,               // + l (1 .. L): column sums of dP | dQ
     S_DBIAS = S_CS + MAXL + 1,            // + l (1 .. L): per-graph partial sums of dP | dQ
     S_SLAB_W = S_DBIAS + MAXL + 1,        // + l (2 .. L): split-K slabs of the layer's weight gradient
-    S_WNT = S_SLAB_W + MAXL + 1,          // + i: transposed numerical-encoder weights
+    S_DPQL = S_SLAB_W + MAXL + 1,         // + l (1 .. L): per-layer dP | dQ, only when the node-level products are deferred
+    S_WNT = S_DPQL + MAXL + 1,            // + i: transposed numerical-encoder weights
     S_WVT = S_WNT + UPAMD_MAX_MLP,        // + i: transposed value-head weights
     S_U = S_WVT + UPAMD_MAX_MLP,          // + i (0 .. n_num)
     S_V = S_U + UPAMD_MAX_MLP + 1,        // + i (1 .. n_value - 1)
@@ -99,6 +101,11 @@ const char *slot_name_table(int s, char *buf) {      // inverse of slot_of_name 
     return "";
 }
 
+// Models whose node-level weight-gradient shapes are too small for the tiled MFMA kernel (D < 32: the reference's
+// shipped D = 16) are launch-bound: their five dY^T X products per step become jobs of the one grouped launch that
+// already computes the per-sample weight gradients.
+static bool defer_node_tn(int D) { return !tn_shape_mfma_ok(2 * D, D); }
+
 void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_minibatch &mb, Plan *pl) {
     const Dims x = dims_of(d);
     const int64_t B = mb.B, M = std::max<int64_t>(mb.n_nodes, 1), NH = std::max<int64_t>(mb.n_he, 1),
@@ -154,6 +161,10 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     add(S_DZ_HE, NH); add(S_DZ_RN, NR); add(S_DPREL, NH * x.h0l); add(S_DFE, NH * 2 * D); add(S_DMHE, NH * D);
     add(S_DPRER, NR * x.h0r); add(S_DXR, NR * D);
     add(S_G0, M * D); add(S_G1, M * D); add(S_DPQ, M * 2 * D);
+    // small models (no MFMA-tiled weight-gradient shapes): the node-level dY^T X products join the step's one grouped
+    // launch at the end, so every layer's dP | dQ has to survive until then
+    if (defer_node_tn(D))
+        for (int l = 1; l <= x.L; ++l) add(S_DPQL + l, M * 2 * D);
     // split-K slabs: every weight-gradient product keeps its own region until the step's final reduction
     auto slab_floats = [](int I, int J, int64_t rows) {
         return (int64_t)(tn_shape_mfma_ok(I, J) ? tn_splits(I, J, rows) : tn_job_splits(rows)) * I * J;
@@ -638,8 +649,24 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     const bool land = mb.Nhe > 0, road = mb.Nrn > 0;
     const ChainDims cd = chain_dims(d, x, B);
     Reducer red1, red2;             // reduction #1: everything independent; #2: what must follow the collapsed-product gradients
+    // the step's ONE grouped dY^T X launch (per-sample weight gradients, and the node-level products of small models);
+    // the reductions of its slabs are queued after it has been launched
+    TnJobs tj;
+    std::vector<std::function<int()>> after_gtn;
+    const bool defer = defer_node_tn(x.D);
+    // slabs = A[rows, I]^T Bm[rows, J] (panel-major operands) followed by red_add(S) -- at once, or as a grouped job
+    auto node_tn_red = [&](const float *A, int I, const float *Bm, int J, int64_t rows, float *slabs,
+                           std::function<int(int)> red_add) -> int {
+        int Sn = 1;
+        if (defer && !tn_shape_mfma_ok(I, J) && tj.n < TN_MAX_JOBS / 4) {
+            CK(tn_add(&tj, A, 0, I, Bm, 0, J, rows, slabs, &Sn, 1, 1));
+            after_gtn.push_back([red_add, Sn]() { return red_add(Sn); });
+            return 0;
+        }
+        CK(node_tn(A, I, Bm, J, rows, slabs, &Sn, st, prof));
+        return red_add(Sn);
+    };
     red1.st = st; red2.st = st;
-    int S = 1;
 
     if (x.mlp) {
         // ===== rl-mlp encoder: value head / numerical encoder -> pooled means + pointer heads -> node encoder
@@ -664,8 +691,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             CK(red1.add(W(S_CSP0), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
             CK(launch_colsum_pm_part(W(S_DPREL), mb.Nhe, x.h0l, nullptr, W(S_CSP1), &nb, st));
             CK(red1.add(W(S_CSP1), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
-            CK(node_tn(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), &S, st, prof));
-            CK(red1.add(W(S_SLAB_FE), S, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+            CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
+                return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
+            }));
             CK(launch_he_segsum(pk, mb, x.h0l, W(S_DPREL), W(S_DCONST), st));
             CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
             // a candidate that is not a live edge has the bias as its embedding: its gradient is kept (-> dbe)
@@ -680,8 +708,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             CK(red1.add(W(S_CSP2), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
             CK(launch_colsum_pm_part(W(S_DPRER), mb.Nrn, x.h0r, nullptr, W(S_CSP3), &nb, st));
             CK(red1.add(W(S_CSP3), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
-            CK(node_tn(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), &S, st, prof));
-            CK(red1.add(W(S_SLAB_XR), S, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D));
+            CK(node_tn_red(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), [&](int Sn) {
+                return red1.add(W(S_SLAB_XR), Sn, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D);
+            }));
             CK(launch_gemm_nt(W(S_DPRER), mb.Nrn, x.h0r, W(S_R1T), D, nullptr, nullptr, W(S_DXR), 0, st, prof));
             CK(launch_road_scatter_add(pk, mb, D, W(S_DXR), G0, st));
         }
@@ -694,10 +723,10 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             CK(launch_chain_bwd_pre(a, st));
         }
         // node encoder on all nodes: dWe += G^0^T X, dbe += colsum(G^0) (Xp's column of ones)
-        CK(node_tn(G0, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), &S, st, prof));
-        CK(red1.add(W(S_SLAB_XP2), S, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b)));
+        CK(node_tn_red(G0, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), [&](int Sn) {
+            return red1.add(W(S_SLAB_XP2), Sn, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b));
+        }));
         {
-            TnJobs tj;
             float *slab = W(S_SLAB_SMALL);
             int64_t used = 0;
             struct Pending { Reducer *rd; const float *slab; int S, N, K; float *dst; int ldd, overwrite; };
@@ -732,6 +761,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             CK(job(red2, W(S_DC), D, D, nullptr, 0, 1, 3LL * B, GR(P.node_b), 1, 0));
             CK(launch_gtn(tj, st));
             for (const Pending &q : pending) CK(q.rd->add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
+            for (auto &f : after_gtn) CK(f());
         }
         CK(red1.flush());
         if (land) {
@@ -772,8 +802,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_colsum_pm_part(W(S_DPREL), mb.Nhe, x.h0l, nullptr, W(S_CSP1), &nb, st));         // db1 = sum dpre
         CK(red1.add(W(S_CSP1), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
         // dW1f = dpre^T FE (mapped back onto [Wa|Wb|Wc|Wd] after the reduction, together with dWbd = dconst^T C)
-        CK(node_tn(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), &S, st, prof));
-        CK(red1.add(W(S_SLAB_FE), S, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+        CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
+            return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
+        }));
         CK(launch_he_segsum(pk, mb, x.h0l, W(S_DPREL), W(S_DCONST), st));
         // dFE = dpre W1f, then the feature backward (dMhe for the last GCN layer, dC from the m*c term)
         CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
@@ -785,8 +816,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(red1.add(W(S_CSP2), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
         CK(launch_colsum_pm_part(W(S_DPRER), mb.Nrn, x.h0r, nullptr, W(S_CSP3), &nb, st));
         CK(red1.add(W(S_CSP3), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
-        CK(node_tn(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), &S, st, prof));
-        CK(red1.add(W(S_SLAB_XR), S, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D));
+        CK(node_tn_red(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), [&](int Sn) {
+            return red1.add(W(S_SLAB_XR), Sn, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D);
+        }));
         CK(launch_gemm_nt(W(S_DPRER), mb.Nrn, x.h0r, W(S_R1T), D, nullptr, nullptr, W(S_DXR), 0, st, prof));
         CK(launch_road_scatter_add(pk, mb, D, W(S_DXR), G, st));
     }
@@ -805,30 +837,33 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
     for (int l = x.L; l >= 1; --l) {
         const bool last = (l == x.L);
+        float *dPQ = defer ? W(S_DPQL + l) : W(S_DPQ);
         CK(launch_edge_bwd(pk, mb, D, last, W(S_PQ + l), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp, (last && land) ? W(S_DMHE) : nullptr,
-                           W(S_DPQ), W(S_DBIAS + l), st, prof, (l == 1 && fold) ? &fa : nullptr));
+                           dPQ, W(S_DBIAS + l), st, prof, (l == 1 && fold) ? &fa : nullptr));
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
         CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
         if (l > 1) {
-            CK(node_tn(W(S_DPQ), 2 * D, W(S_H + l - 1), D, mb.M, W(S_SLAB_W + l), &S, st, prof));
-            CK(red1.add(W(S_SLAB_W + l), S, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D));
-            CK(launch_gemm_nt(W(S_DPQ), mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
+            CK(node_tn_red(dPQ, 2 * D, W(S_H + l - 1), D, mb.M, W(S_SLAB_W + l), [&, l](int Sn) {
+                return red1.add(W(S_SLAB_W + l), Sn, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D);
+            }));
+            CK(launch_gemm_nt(dPQ, mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
             std::swap(G, Gn);
         } else {
             // layer 1: H_0 = Xp We^T + be, so dWcat_1 = dPQ_1^T H_0 = (dPQ_1^T Xp) We^T + colsum(dPQ_1) (x) be --
             // a J = 32 reduction over the nodes instead of a full-size weight-gradient GEMM.  Tn = dPQ_1^T Xp
-            CK(node_tn(W(S_DPQ), 2 * D, W(S_XP), 32, mb.M, W(S_SLAB_XP1), &S, st, prof));
-            CK(red1.add(W(S_SLAB_XP1), S, 2LL * D * 32, 2 * D, 32, 0, 32, W(S_TN), 32, nullptr, 1));
+            CK(node_tn_red(dPQ, 2 * D, W(S_XP), 32, mb.M, W(S_SLAB_XP1), [&](int Sn) {
+                return red1.add(W(S_SLAB_XP1), Sn, 2LL * D * 32, 2 * D, 32, 0, 32, W(S_TN), 32, nullptr, 1);
+            }));
         }
     }
     // ---- 6. node encoder.  G^0 = G^1 + dPQ_1 Wcat_1 is never formed (it is only needed for the encoder's own
     // gradients): dWe = G^0^T X = G^1^T X + Wcat_1^T (dPQ_1^T X),  dbe = colsum(G^1) + Wcat_1^T colsum(dPQ_1).
     // G holds G^1 here.  Xp's column 31 is all ones, so column 31 of G^1^T Xp is colsum(G^1): straight into dbe
-    CK(node_tn(G, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), &S, st, prof));
-    CK(red1.add(W(S_SLAB_XP2), S, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b)));
+    CK(node_tn_red(G, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), [&](int Sn) {
+        return red1.add(W(S_SLAB_XP2), Sn, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b));
+    }));
     // ---- 7. every per-sample weight gradient dY^T X in ONE grouped MFMA launch
     {
-        TnJobs tj;
         float *slab = W(S_SLAB_SMALL);
         int64_t used = 0;
         struct Pending { Reducer *rd; const float *slab; int S, N, K; float *dst; int ldd, overwrite; };
@@ -876,6 +911,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(job(red2, W(S_DC), D, D, nullptr, 0, 1, GR(P.node_b), 1, 0));
         CK(launch_gtn(tj, st));
         for (const Pending &q : pending) CK(q.rd->add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
+        for (auto &f : after_gtn) CK(f());
     }
     // ---- 8. reduction #1: every split-K slab / partial sum of the step, fixed order
     CK(red1.flush());

@@ -75,6 +75,9 @@ SYMBOLS = {
                                     C.c_double, C.c_double, _P, _P, _P]),
     'upamd_gemm_nt': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int64,
                                 C.c_int32, C.c_int32, C.c_float, _P]),
+    'upamd_gemm_nt_split_scratch_bytes': (C.c_int64, [C.c_int32, C.c_int32]),
+    'upamd_gemm_nt_split': (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int32, C.c_float,
+                                      C.c_int32, _P, _P]),
     'upamd_gemm_tn_scratch_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     'upamd_gemm_tn': (C.c_int, [_P, C.c_int32, C.c_int64, _P, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P]),
     'upamd_tune': (C.c_int, [C.c_char_p, C.c_int32]),

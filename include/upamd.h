@@ -254,6 +254,15 @@ int upamd_adam_groups(int32_t n_groups, const int64_t *begin, const int64_t *end
 int upamd_gemm_nt(const float *A_dev, int64_t M, int32_t K, int64_t lda, int32_t a_row_major, const float *W_dev,
                   int32_t N, int64_t ldw, const float *bias_dev, const float *R_dev, float *C_dev, int64_t ldc,
                   int32_t c_row_major, int32_t act_tanh, float alpha, void *stream);
+
+/* OPT-IN variant of upamd_gemm_nt for panel-major operands (not used by upamd_forward / upamd_backward): the same fp32
+ * product computed on the bf16 matrix pipe from an exact three-way bf16 split of both operands, n_products = 6 (terms
+ * below 2^-26 relative dropped) or 9 (all partial products); fp32 accumulation.  scratch_dev: device buffer of
+ * upamd_gemm_nt_split_scratch_bytes(N, K) bytes for the split weight planes.  N % 128 == 0, K % 32 == 0. */
+int64_t upamd_gemm_nt_split_scratch_bytes(int32_t N, int32_t K);
+int upamd_gemm_nt_split(const float *A_dev, int64_t M, int32_t K, const float *W_dev, int32_t N, int64_t ldw,
+                        const float *bias_dev, const float *R_dev, float *C_dev, int32_t act_tanh, float alpha,
+                        int32_t n_products, void *scratch_dev, void *stream);
 /* out[I,J] (row-major, overwritten) = A[M,I]^T * B[M,J], deterministic split-K through scratch_dev
  * (upamd_gemm_tn_scratch_floats(I, J, M) floats) */
 int64_t upamd_gemm_tn_scratch_floats(int32_t I, int32_t J, int64_t M);

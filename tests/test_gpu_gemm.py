@@ -68,3 +68,58 @@ def test_gemm_tn(M, I, J, rm):
     torch.cuda.synchronize()
     scale = float(ref.abs().max())
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize('M,K,N', [(4099, 256, 512), (777, 512, 256), (130, 16, 128), (1500, 48, 128)])
+@pytest.mark.parametrize('nprod', [6, 9])
+def test_gemm_nt_split_has_fp32_accuracy(M, K, N, nprod):
+    """The opt-in split-bf16 product (csrc/gemm_split.hip: fp32 operands as three bf16 terms on the bf16 matrix pipe,
+    fp32 accumulation) against a float64 product, next to the exact-fp32 MFMA kernel on the same inputs: its error must
+    not exceed the fp32 kernel's on benign data (the dropped terms are below one fp32 rounding) and stays within a small
+    factor of it on wide-dynamic-range data, with the fused bias / residual / tanh epilogue."""
+    lib = native.lib()
+    g = torch.Generator(device='cpu').manual_seed(M + K + N + nprod)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scratch = torch.zeros(int(lib.upamd_gemm_nt_split_scratch_bytes(N, K)), dtype=torch.uint8, device=DEV)
+    for wide in (False, True):
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * 0.1
+        if wide:
+            A = A * torch.pow(10.0, torch.rand(M, K, generator=g) * 6 - 3)
+            W = W * torch.pow(10.0, torch.rand(N, K, generator=g) * 4 - 2)
+        A, W = A.to(DEV), W.to(DEV)
+        bias = torch.randn(N, generator=g).to(DEV)
+        R = torch.randn(M, N, generator=g).to(DEV)
+        for act in (0, 1):
+            pre = A.double() @ W.double().t() + bias.double() + R.double()
+            ref = 0.5 * (torch.tanh(pre) if act else pre)
+            A_in, R_in = to_pm(A), to_pm(R)
+            c_exact, c_split = torch.zeros(M * N, device=DEV), torch.zeros(M * N, device=DEV)
+            native.check(lib.upamd_gemm_nt(P(A_in), M, K, K, 0, P(W), N, K, P(bias), P(R_in), P(c_exact), N, 0, act, 0.5, st))
+            native.check(lib.upamd_gemm_nt_split(P(A_in), M, K, P(W), N, K, P(bias), P(R_in), P(c_split), act, 0.5, nprod,
+                                                 P(scratch), st))
+            torch.cuda.synchronize()
+            e_exact = (from_pm(c_exact, M, N).double() - ref).abs()
+            e_split = (from_pm(c_split, M, N).double() - ref).abs()
+            scale = float(ref.abs().max())
+            rms_exact, rms_split = float(e_exact.pow(2).mean().sqrt()), float(e_split.pow(2).mean().sqrt())
+            # benign data: not worse than the exact-fp32 kernel.  Six decades of dynamic range and a short K (little
+            # accumulation noise to hide behind): the dropped 2^-26 terms show, the error stays within 2.5x / 3x
+            slack = 2.5 if wide else 1.1
+            assert rms_split <= slack * rms_exact + 1e-9 * scale, (wide, act, rms_split, rms_exact)
+            if not wide:      # (the maximum over heavy cancellations is dominated by single outliers of either kernel)
+                assert float(e_split.max()) <= 2.0 * float(e_exact.max()) + 1e-7 * scale, (act, float(e_split.max()), float(e_exact.max()))
+            if not wide:      # (with six decades of dynamic range the cancellation noise of ANY fp32 product exceeds this)
+                np.testing.assert_allclose(from_pm(c_split, M, N).cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5,
+                                           atol=1e-5 * max(1.0, scale))
+
+
+def test_gemm_nt_split_rejects_unsupported_shapes():
+    lib = native.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    A, W, Cc = torch.zeros(1, 64, 16, device=DEV), torch.zeros(96, 16, device=DEV), torch.zeros(6, 64, 16, device=DEV)
+    scratch = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
+    assert lib.upamd_gemm_nt_split(P(A), 64, 16, P(W), 96, 16, None, None, P(Cc), 0, 1.0, 6, P(scratch), st) != 0     # N % 128
+    W2 = torch.zeros(128, 16, device=DEV)
+    assert lib.upamd_gemm_nt_split(P(A), 64, 16, P(W2), 128, 16, None, None, P(Cc), 0, 1.0, 7, P(scratch), st) != 0    # products
+    assert lib.upamd_gemm_nt_split(P(A), 64, 16, P(W2), 128, 16, None, None, P(Cc), 0, 1.0, 6, None, st) != 0          # scratch
