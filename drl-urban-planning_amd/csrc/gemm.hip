@@ -359,6 +359,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma2_kernel(const float 
 // defaults = the best configuration of the kernel lab (tools/gemm_lab*.py, profiles/r02_gemm_lab.md): LDS-DMA staging,
 // three workgroups per CU (12 KB of LDS padding), first-residency-round stagger
 static int g_nt_dma_variant = 1, g_stagger_mode = 1, g_stagger_cycles = 37000, g_lds_pad = 12 * 1024;
+static int g_nt_split = 0;                      // 0 | 6 | 9, see launch_gemm_nt_ex
+static void *g_split_scratch = nullptr;
+static int64_t g_split_scratch_bytes = 0;
+void set_gemm_nt_split(int nprod) { g_nt_split = (nprod == 6 || nprod == 9) ? nprod : 0; }
 void set_gemm_lds_pad(int bytes) { g_lds_pad = bytes; }
 void set_gemm_nt_dma_variant(int v) { g_nt_dma_variant = v; }
 void set_gemm_stagger(int mode, int cycles) {
@@ -487,12 +491,26 @@ int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
     if (began < 0) return fail(UPAMD_E_HIP, "hipEventCreate failed");
     const int dv = (mfma && !k32 && bn == 128) ? g_nt_dma_variant : 0;
     int dma_rc = 1;                             // 1 = not taken
-    switch (dv) {
-        case 1: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<2, 2>(g, st); break;
-        case 2: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<4, 2>(g, st); break;
-        case 3: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<2, 4>(g, st); break;
-        case 4: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<4, 4>(g, st); break;
-        default: break;
+    // opt-in (tune knob "gemm_split" = 6 | 9, default 0 = exact fp32 MFMA): the K >= 64 panel-major products on the bf16
+    // matrix pipe from a three-way bf16 split of both operands (gemm_split.hip); everything else is unchanged
+    if (g_nt_split && dv != 0 && gemm_nt_split_ok(g)) {
+        const int64_t need = gemm_nt_split_scratch_bytes(g.N, g.K);
+        if (need > g_split_scratch_bytes) {      // lab knob: one lazily grown device buffer (launches are stream-ordered)
+            if (g_split_scratch) (void)hipFree(g_split_scratch);
+            g_split_scratch = nullptr;
+            g_split_scratch_bytes = 0;
+            UPAMD_HIP(hipMalloc(&g_split_scratch, (size_t)need));
+            g_split_scratch_bytes = need;
+        }
+        dma_rc = launch_gemm_nt_split(g, g_split_scratch, g_nt_split, st, nullptr);
+    } else {
+        switch (dv) {
+            case 1: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<2, 2>(g, st); break;
+            case 2: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<4, 2>(g, st); break;
+            case 3: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<2, 4>(g, st); break;
+            case 4: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<4, 4>(g, st); break;
+            default: break;
+        }
     }
     if (dma_rc < 0) return dma_rc;
     if (dma_rc == 0) {

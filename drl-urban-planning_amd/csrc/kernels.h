@@ -72,6 +72,7 @@ void set_gemm_stagger(int mode, int cycles);
 void set_gemm_lds_pad(int bytes);   // first-residency-round stagger of the GEMM workgroups (-1 = keep)       // kernel-lab knob: LDS-DMA configuration of the plain panel-major launches
 int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof);
 // opt-in: the same product on the bf16 matrix pipe by exact 3-way operand splitting (gemm_split.hip)
+void set_gemm_nt_split(int nprod);          // tune knob: 0 (default, exact fp32 MFMA) | 6 | 9 partial products
 bool gemm_nt_split_ok(const GemmNT &g);
 int64_t gemm_nt_split_scratch_bytes(int N, int K);
 int launch_gemm_nt_split(const GemmNT &g, void *planes, int nprod, hipStream_t st, Profiler *prof);

@@ -68,7 +68,7 @@ def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
 def tune():
     """set native tune knobs for one test; every knob is put back to its default afterwards"""
     from drl_urban_planning_amd import native
-    defaults = {'fold_layer1': 1}
+    defaults = {'fold_layer1': 1, 'gemm_split': 0}
     touched = []
 
     def _set(name, value):
@@ -345,6 +345,16 @@ def test_wide_model_matches_oracle(D, L, heads, n_range, T):
     cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
                                    int(5.55 * n_range[1]) + 10, seed=21, road_fraction=0.3, n_range=n_range)
     _check_against_oracle(cfg, sd, replay, heads, T)
+
+
+@pytest.mark.parametrize('nprod', [6, 9])
+def test_wide_model_with_split_gemm_matches_oracle(nprod, tune):
+    """The opt-in split-bf16 node GEMMs (tune knob gemm_split, csrc/gemm_split.hip) under the SAME oracle tolerances as the
+    exact-fp32 default: values, log-probs, entropies, losses and every gradient at the BASELINE dims."""
+    tune('gemm_split', nprod)
+    cfg, sd, replay = _random_case(256, 3, 1, (64, 16), (32, 1), (32, 1), (32, 32, 1), 5, 350, int(5.55 * 345) + 10, seed=21,
+                                   road_fraction=0.3, n_range=(200, 345))
+    _check_against_oracle(cfg, sd, replay, 1, 5)
 
 
 @pytest.mark.parametrize('gain,bias', [(40.0, 0.0), (1.0, 3.0), (400.0, 0.5)])

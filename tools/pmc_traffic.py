@@ -29,6 +29,8 @@ SHORT = [      # demangled (csv output) and mangled (rocpd) spellings
     (r'gemm_tn_mfma_kernel(<128|ILi128)', 'gemm_tn_128_rm'),
     (r'gemm_tn_mfma_kernel(<32, 32, 32, false|ILi32ELi32ELi32ELb0)', 'gemm_tn_32'),
     (r'gemm_tn_mfma_kernel(<32|ILi32)', 'gemm_tn_32_rm'),
+    (r'edge_fwd_kernel(<false, true, true|ILb0ELb1ELb1)', 'edge_fwd_layer1_folded'),
+    (r'edge_bwd_kernel(<false, true, true|ILb0ELb1ELb1)', 'edge_bwd_layer1_folded'),
     (r'edge_fwd_kernel(<false|ILb0)', 'edge_fwd'),
     (r'edge_fwd_kernel(<true|ILb1)', 'edge_fwd_last'),
     (r'edge_bwd_kernel(<false|ILb0)', 'edge_bwd'),
