@@ -177,8 +177,9 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     // per-sample weight gradients (grouped dY^T X): <= 16 row splits of every per-sample weight (+ the collapsed ones)
     pl->small_slab_floats = 16LL * (P.n_floats + 4LL * D * D + 2LL * D * x.h0l + 4096);
     add(S_SLAB_SMALL, pl->small_slab_floats);
-    const int64_t maxrows = std::max(NH, NR);
-    for (int k = 0; k < 4; ++k) add(S_CSP0 + k, (int64_t)colsum_pm_blocks(maxrows) * std::max(std::max(x.h0l, x.h0r), 16));
+    // per-row sums of the pointer heads' backward (pointer_bwd2): [B][h0] each, reduced over the rows afterwards;
+    // 0: land dz*hid, 1: (free), 2: road dz*hid, 3: road dpre  (the land dpre sums are S_DCONST)
+    for (int k = 0; k < 4; ++k) add(S_CSP0 + k, B * std::max(std::max(x.h0l, x.h0r), 16));
     pl->total = off;
 }
 
@@ -684,17 +685,15 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         const float *dSVm = W(S_DSV);
         float *G0 = W(S_G0);
         CK(launch_pointer_bwd2(pk, mb, W(S_Z_HE), W(S_Z_RN), W(S_P_HE), W(S_P_RN), W(S_ENTK), W(S_LSE), dlogp_dev, dent_dev, W(S_HIDL),
-                               PR(P.land_w[1]), x.h0l, W(S_HIDR), PR(P.road_w[1]), x.h0r, W(S_DZ_HE), W(S_DZ_RN), W(S_DPREL), W(S_DPRER), st));
+                               PR(P.land_w[1]), x.h0l, W(S_HIDR), PR(P.road_w[1]), x.h0r, W(S_DZ_HE), W(S_DZ_RN), W(S_DPREL), W(S_DPRER),
+                               land ? W(S_CSP0) : nullptr, land ? W(S_DCONST) : nullptr, road ? W(S_CSP2) : nullptr, road ? W(S_CSP3) : nullptr, st));
         if (land) {
-            int nb = 0;
-            CK(launch_colsum_pm_part(W(S_HIDL), mb.Nhe, x.h0l, W(S_DZ_HE), W(S_CSP0), &nb, st));
-            CK(red1.add(W(S_CSP0), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
-            CK(launch_colsum_pm_part(W(S_DPREL), mb.Nhe, x.h0l, nullptr, W(S_CSP1), &nb, st));
-            CK(red1.add(W(S_CSP1), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
+            // dw2 = sum_rows (sum_k dz hid), db1 = sum_rows dconst: the row sums come out of pointer_bwd2
+            CK(red1.add(W(S_CSP0), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
+            CK(red1.add(W(S_DCONST), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
             CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
                 return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
             }));
-            CK(launch_he_segsum(pk, mb, x.h0l, W(S_DPREL), W(S_DCONST), st));
             CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
             // a candidate that is not a live edge has the bias as its embedding: its gradient is kept (-> dbe)
             CK(launch_he_feat_bwd(pk, mb, D, W(S_FE), W(S_C), W(S_DFE), W(S_DMHE), W(S_DC_HEAD), st, 1));
@@ -703,11 +702,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         // job = the per-graph sums of the non-live candidates' dM (bias only: their X rows are zero)
         CK(launch_mlp_pool_bwd(pk, mb, D, dSVm + x.S_last, x.Wp, land ? W(S_DMHE) : nullptr, G0, W(S_DC) + 2LL * B * D, st));
         if (road) {
-            int nb = 0;
-            CK(launch_colsum_pm_part(W(S_HIDR), mb.Nrn, x.h0r, W(S_DZ_RN), W(S_CSP2), &nb, st));
-            CK(red1.add(W(S_CSP2), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
-            CK(launch_colsum_pm_part(W(S_DPRER), mb.Nrn, x.h0r, nullptr, W(S_CSP3), &nb, st));
-            CK(red1.add(W(S_CSP3), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
+            CK(red1.add(W(S_CSP2), B, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
+            CK(red1.add(W(S_CSP3), B, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
             CK(node_tn_red(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), [&](int Sn) {
                 return red1.add(W(S_SLAB_XR), Sn, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D);
             }));
@@ -794,28 +790,23 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W(S_R), W(S_ALPHA), W(S_S), W(S_DS), dhbarV, x.Wp, G, W(S_DR), st));
     // ---- 3. pointer heads: softmax backward + second-Linear backward fused
     CK(launch_pointer_bwd2(pk, mb, W(S_Z_HE), W(S_Z_RN), W(S_P_HE), W(S_P_RN), W(S_ENTK), W(S_LSE), dlogp_dev, dent_dev, W(S_HIDL),
-                           PR(P.land_w[1]), x.h0l, W(S_HIDR), PR(P.road_w[1]), x.h0r, W(S_DZ_HE), W(S_DZ_RN), W(S_DPREL), W(S_DPRER), st));
+                           PR(P.land_w[1]), x.h0l, W(S_HIDR), PR(P.road_w[1]), x.h0r, W(S_DZ_HE), W(S_DZ_RN), W(S_DPREL), W(S_DPRER),
+                               land ? W(S_CSP0) : nullptr, land ? W(S_DCONST) : nullptr, road ? W(S_CSP2) : nullptr, road ? W(S_CSP3) : nullptr, st));
     if (land) {
-        int nb = 0;
-        CK(launch_colsum_pm_part(W(S_HIDL), mb.Nhe, x.h0l, W(S_DZ_HE), W(S_CSP0), &nb, st));        // dw2 = sum dz * hid
-        CK(red1.add(W(S_CSP0), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
-        CK(launch_colsum_pm_part(W(S_DPREL), mb.Nhe, x.h0l, nullptr, W(S_CSP1), &nb, st));         // db1 = sum dpre
-        CK(red1.add(W(S_CSP1), nb, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
+        // dw2 = sum_rows (sum_k dz hid), db1 = sum_rows dconst: the row sums come out of pointer_bwd2
+        CK(red1.add(W(S_CSP0), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
+        CK(red1.add(W(S_DCONST), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
         // dW1f = dpre^T FE (mapped back onto [Wa|Wb|Wc|Wd] after the reduction, together with dWbd = dconst^T C)
         CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
             return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
         }));
-        CK(launch_he_segsum(pk, mb, x.h0l, W(S_DPREL), W(S_DCONST), st));
         // dFE = dpre W1f, then the feature backward (dMhe for the last GCN layer, dC from the m*c term)
         CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
         CK(launch_he_feat_bwd(pk, mb, D, W(S_FE), W(S_C), W(S_DFE), W(S_DMHE), W(S_DC_HEAD), st));
     }
     if (road) {
-        int nb = 0;
-        CK(launch_colsum_pm_part(W(S_HIDR), mb.Nrn, x.h0r, W(S_DZ_RN), W(S_CSP2), &nb, st));
-        CK(red1.add(W(S_CSP2), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
-        CK(launch_colsum_pm_part(W(S_DPRER), mb.Nrn, x.h0r, nullptr, W(S_CSP3), &nb, st));
-        CK(red1.add(W(S_CSP3), nb, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
+        CK(red1.add(W(S_CSP2), B, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
+        CK(red1.add(W(S_CSP3), B, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
         CK(node_tn_red(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), [&](int Sn) {
             return red1.add(W(S_SLAB_XR), Sn, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D);
         }));

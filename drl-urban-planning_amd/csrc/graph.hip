@@ -13,53 +13,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 constexpr int64_t LDS_LIMIT = 160 * 1024;
 
-// ------------------------------------------------------------------------------------------
-// inputs of a minibatch: node features -> panel-major (K padded to 32), numerical + current node
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_inputs_kernel(PackedView pk, MbView mb, float *__restrict__ Xp,
-                                                            float *__restrict__ U0, float *__restrict__ curg) {
-    const int b = blockIdx.x;
-    const int t = mb.idx[b];
-    const int32_t *m = META(t);
-    const int n = m[0];
-    const int64_t src0 = m[9], o = mb.node_off[b], M = mb.M;
-    // 8 threads per node row: thread q copies floats [4q, 4q+4) of the 32-wide padded row
-    for (int i = threadIdx.x; i < n * 8; i += 256) {
-        const int v = i >> 3, q = i & 7;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < 6) val = *reinterpret_cast<const float4 *>(pk.X + (src0 + v) * UPAMD_NODE_PAD + q * 4);
-        if (q == 7) val.w = 1.0f;      // column 31 = 1: a weight-gradient GEMM against Xp also yields the column sums
-                                       // (the forward weights of that column are zero padding)
-        const int panel = q >> 2, c4 = (q & 3) * 4;
-        *reinterpret_cast<float4 *>(Xp + ((int64_t)panel * M + o + v) * 16 + c4) = val;
-    }
-    for (int i = threadIdx.x; i < pk.Fn; i += 256) U0[(int64_t)b * pk.Fn + i] = pk.numerical[(int64_t)t * pk.Fn + i];
-    if (threadIdx.x < UPAMD_NODE_PAD) curg[(int64_t)b * UPAMD_NODE_PAD + threadIdx.x] = pk.cur[(int64_t)t * UPAMD_NODE_PAD + threadIdx.x];
-}
 
-// row descriptors of the minibatch (MbView::rows)
-__global__ void gather_rows_kernel(PackedView pk, MbView mb, int32_t *__restrict__ rows) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= mb.B * UPAMD_META_STRIDE) return;
-    const int b = g / UPAMD_META_STRIDE, c = g % UPAMD_META_STRIDE;
-    int32_t v;
-    if (c == 14) v = mb.node_off[b];
-    else if (c == 15) v = mb.he_off[b];
-    else v = pk.meta[(int64_t)mb.idx[b] * UPAMD_META_STRIDE + c];
-    rows[g] = v;
-}
-int launch_gather_rows(const PackedView &pk, const MbView &mb, int32_t *rows, hipStream_t st) {
-    const int tot = mb.B * UPAMD_META_STRIDE;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, pk, mb, rows);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
-}
 
-int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st) {
-    hipLaunchKernelGGL(gather_inputs_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, Xp, U0, curg);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
-}
 
 // ------------------------------------------------------------------------------------------
 // Single-query attention over a graph's node_mask nodes (state_encoder.py:150-161 with the
@@ -478,34 +433,6 @@ int launch_he_bias_rows(const PackedView &pk, const MbView &mb, int h0, const fl
     return 0;
 }
 
-// dconst[b][k] = sum over the row's candidates of dpre(pm)[row][k]   (fixed order, one workgroup per graph)
-__global__ __launch_bounds__(256) void he_segsum_kernel(PackedView pk, MbView mb, int h0,
-                                                        const float *__restrict__ dpre, float *__restrict__ dconst) {
-    __shared__ float part[256];
-    const int b = blockIdx.x, t = mb.idx[b];
-    const int nh = META(t)[2];
-    const int64_t q0 = mb.he_off[b], NH = mb.Nhe;
-    const int c = threadIdx.x & 15, qg = threadIdx.x >> 4;
-    for (int p = 0; p < h0 / 16; ++p) {
-        float acc = 0.f;
-        for (int q = qg; q < nh; q += 16) acc += dpre[((int64_t)p * NH + q0 + q) * 16 + c];
-        __syncthreads();
-        part[qg * 16 + c] = acc;
-        __syncthreads();
-        if (threadIdx.x < 16) {
-            float tot = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) tot += part[q * 16 + threadIdx.x];
-            dconst[(int64_t)b * h0 + p * 16 + threadIdx.x] = tot;
-        }
-    }
-}
-int launch_he_segsum(const PackedView &pk, const MbView &mb, int h0, const float *dpre, float *dconst, hipStream_t st) {
-    hipLaunchKernelGGL(he_segsum_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, h0, dpre, dconst);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
-}
-
 // backward of FE = [m ; m*c]:  dMhe(pm)[row][d] = live * (g1 + g2 * c),  dC_head[b][d] = sum_rows g2 * m
 __global__ __launch_bounds__(256) void he_feat_bwd_kernel(PackedView pk, MbView mb, int NP,
                                                           const float *__restrict__ FE, const float *__restrict__ C,
@@ -598,94 +525,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void pointer_fwd_kernel(PackedView pk, MbView mb, const float *__restrict__ z_he,
-                                                          const float *__restrict__ z_rn, float *__restrict__ p_he,
-                                                          float *__restrict__ p_rn, float *__restrict__ logp,
-                                                          float *__restrict__ ent, float *__restrict__ lse_out) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= mb.B) return;
-    const int lane = threadIdx.x & 63;
-    const int32_t *m = META(mb.idx[b]);
-    const int stage = m[4];
-    if (stage > 1) {
-        if (lane == 0) { logp[b] = 0.f; ent[b] = 0.f; lse_out[b] = 0.f; }
-        return;
-    }
-    const int cnt = stage == 0 ? m[2] : m[3];
-    const int64_t off = stage == 0 ? mb.he_off[b] : mb.rn_off[b];
-    const float *z = (stage == 0 ? z_he : z_rn) + off;
-    float *pp = (stage == 0 ? p_he : p_rn) + off;
-    if (cnt == 0) {
-        // no valid candidate: every logit is the pad constant -2^32+1; in fp32 its logsumexp over the padded row
-        // is absorbed (|pad| >> log N), so the reference's normalised logits are all 0: log_prob = 0, entropy = 0
-        if (lane == 0) { logp[b] = 0.f; ent[b] = 0.f; lse_out[b] = 0.f; }
-        return;
-    }
-    float mx = -INFINITY;
-    for (int i = lane; i < cnt; i += 64) mx = fmaxf(mx, z[i]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int i = lane; i < cnt; i += 64) sum += expf(z[i] - mx);
-    sum = wave_sum(sum);
-    const float lse = mx + logf(sum);
-    float pz = 0.f;
-    for (int i = lane; i < cnt; i += 64) {
-        const float lp = z[i] - lse;
-        const float p = expf(lp);
-        pp[i] = p;
-        pz += p * lp;
-    }
-    pz = wave_sum(pz);
-    if (lane == 0) {
-        const int a = m[5];
-        logp[b] = (a >= 0 ? z[a] : -4294967296.0f) - lse;
-        ent[b] = -pz;
-        lse_out[b] = lse;
-    }
-}
 
-int launch_pointer_fwd(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn, float *p_he,
-                       float *p_rn, float *logp, float *ent, float *lse, hipStream_t st) {
-    hipLaunchKernelGGL(pointer_fwd_kernel, dim3((mb.B + 3) / 4), dim3(256), 0, st, pk, mb, z_he, z_rn, p_he, p_rn, logp, ent, lse);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
-}
 
-// dz_k = dlogp (delta_ka - p_k) - dent p_k (log p_k + H)
-__global__ __launch_bounds__(256) void pointer_bwd_kernel(PackedView pk, MbView mb, const float *__restrict__ z_he,
-                                                          const float *__restrict__ z_rn, const float *__restrict__ p_he,
-                                                          const float *__restrict__ p_rn, const float *__restrict__ ent,
-                                                          const float *__restrict__ lse, const float *__restrict__ dlogp,
-                                                          const float *__restrict__ dent, float *__restrict__ dz_he,
-                                                          float *__restrict__ dz_rn) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= mb.B) return;
-    const int lane = threadIdx.x & 63;
-    const int32_t *m = META(mb.idx[b]);
-    const int stage = m[4];
-    if (stage > 1) return;
-    const int cnt = stage == 0 ? m[2] : m[3];
-    const int64_t off = stage == 0 ? mb.he_off[b] : mb.rn_off[b];
-    const float *z = (stage == 0 ? z_he : z_rn) + off;
-    const float *pp = (stage == 0 ? p_he : p_rn) + off;
-    float *dz = (stage == 0 ? dz_he : dz_rn) + off;
-    const float gl = dlogp[b], ge = dent[b], H = ent[b], ls = lse[b];
-    const int a = m[5];
-    for (int i = lane; i < cnt; i += 64) {
-        const float p = pp[i];
-        float v = -gl * p - ge * p * ((z[i] - ls) + H);
-        if (i == a) v += gl;
-        dz[i] = v;
-    }
-}
 
-int launch_pointer_bwd(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn,
-                       const float *p_he, const float *p_rn, const float *ent, const float *lse, const float *dlogp,
-                       const float *dent, float *dz_he, float *dz_rn, hipStream_t st) {
-    hipLaunchKernelGGL(pointer_bwd_kernel, dim3((mb.B + 3) / 4), dim3(256), 0, st, pk, mb, z_he, z_rn, p_he, p_rn, ent, lse, dlogp, dent, dz_he, dz_rn);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
-}
 
 // ------------------------------------------------------------------------------------------
 // rl-mlp encoder (MLPStateEncoder, state_encoder.py:217-308): no message passing.  h_nodes = node_encoder(x) (H^0);
@@ -861,8 +703,13 @@ int launch_pointer_fwd2(const PackedView &pk, const MbView &mb, const float *hid
     return 0;
 }
 
-// dz_k = dlogp (delta_ka - p_k) - dent p_k (log p_k + H);  dpre[k'] = dz * w2[k'] * (1 - hid[k']^2)  (panel-major, in place
-// of the separate rowdot-backward pass)
+// Backward of the pointer heads' tail (second Linear + masked softmax + log-prob / entropy), one workgroup per row:
+//   dz_k = dlogp (delta_ka - p_k) - dent p_k (log p_k + H);   dpre[k][j] = dz_k * w2[j] * (1 - hid[k][j]^2)   (panel-major)
+// and, in the same launch, the per-row sums every weight / bias gradient of the head is reduced from afterwards:
+//   rs_dzh[b][j] = sum_k dz_k hid[k][j]   (-> dw2),     rs_dpre[b][j] = sum_k dpre[k][j]   (-> db1; for the land-use head
+//   it is also the row's dconst, the gradient of the head's per-row bias term).
+// A row writes the sums of its own head and zeros into the other head's (and a stage-2 row zeros into both).
+// (Replaces four column-sum launches and the candidate segment sum of round 1.)
 __global__ __launch_bounds__(256) void pointer_bwd2_kernel(PackedView pk, MbView mb, const float *__restrict__ z_he,
                                                            const float *__restrict__ z_rn, const float *__restrict__ p_he,
                                                            const float *__restrict__ p_rn, const float *__restrict__ ent,
@@ -871,14 +718,18 @@ __global__ __launch_bounds__(256) void pointer_bwd2_kernel(PackedView pk, MbView
                                                            const float *__restrict__ w2l, int h0l,
                                                            const float *__restrict__ hidr, const float *__restrict__ w2r,
                                                            int h0r, float *__restrict__ dz_he, float *__restrict__ dz_rn,
-                                                           float *__restrict__ dprel, float *__restrict__ dprer) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= mb.B) return;
-    const int lane = threadIdx.x & 63;
+                                                           float *__restrict__ dprel, float *__restrict__ dprer,
+                                                           float *__restrict__ rs_dzh_l, float *__restrict__ rs_dpre_l,
+                                                           float *__restrict__ rs_dzh_r, float *__restrict__ rs_dpre_r) {
+    __shared__ float part1[256], part2[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int32_t *m = META(mb.idx[b]);
     const int stage = m[4];
-    if (stage > 1) return;
-    const bool land = stage == 0;
+    const bool land = stage == 0, active = stage <= 1;
+    // the other head's row sums (and both, for a row without a head) are zero
+    if (rs_dzh_l && !(active && land) && tid < h0l) { rs_dzh_l[(int64_t)b * h0l + tid] = 0.f; rs_dpre_l[(int64_t)b * h0l + tid] = 0.f; }
+    if (rs_dzh_r && !(active && !land) && tid < h0r) { rs_dzh_r[(int64_t)b * h0r + tid] = 0.f; rs_dpre_r[(int64_t)b * h0r + tid] = 0.f; }
+    if (!active) return;
     const int cnt = land ? m[2] : m[3];
     const int64_t off = land ? mb.he_off[b] : mb.rn_off[b];
     const int64_t NC = land ? mb.Nhe : mb.Nrn;
@@ -891,10 +742,14 @@ __global__ __launch_bounds__(256) void pointer_bwd2_kernel(PackedView pk, MbView
     const int h0 = land ? h0l : h0r;
     const float gl = dlogp[b], ge = dent[b], H = ent[b], ls = lse[b];
     const int a = m[5];
-    for (int i = lane; i < cnt; i += 64) {
+    auto dz_of = [&](int i) -> float {
         const float p = pp[i];
         float v = -gl * p - ge * p * ((z[i] - ls) + H);
         if (i == a) v += gl;
+        return v;
+    };
+    for (int i = tid; i < cnt; i += 256) {
+        const float v = dz_of(i);
         dz[i] = v;
         for (int pnl = 0; pnl < h0 / 16; ++pnl) {
             const int64_t o = ((int64_t)pnl * NC + off + i) * 16;
@@ -909,14 +764,44 @@ __global__ __launch_bounds__(256) void pointer_bwd2_kernel(PackedView pk, MbView
             }
         }
     }
+    // row sums: thread (group g, hidden unit j) walks the candidates g, g + G, ... in order; the G partial sums are
+    // combined in a fixed order (bit-reproducible)
+    float *rs_dzh = land ? rs_dzh_l : rs_dzh_r, *rs_dpre = land ? rs_dpre_l : rs_dpre_r;
+    if (!rs_dzh) return;
+    int hp = 16;
+    while (hp < h0) hp <<= 1;
+    const int G = 256 / hp;
+    const int j = tid % hp, g = tid / hp;
+    float a1 = 0.f, a2 = 0.f;
+    if (j < h0) {
+        const float wj = w2[j];
+        const float *hj = hid + ((int64_t)(j >> 4) * NC + off) * 16 + (j & 15);
+#pragma unroll 4
+        for (int i = g; i < cnt; i += G) {
+            const float v = dz_of(i), h = hj[(int64_t)i * 16];
+            a1 = fmaf(v * wj, 1.f - h * h, a1);
+            a2 = fmaf(v, h, a2);
+        }
+    }
+    part1[g * hp + j] = a1;
+    part2[g * hp + j] = a2;
+    __syncthreads();
+    if (tid < h0) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int q = 0; q < G; ++q) { t1 += part1[q * hp + tid]; t2 += part2[q * hp + tid]; }
+        rs_dpre[(int64_t)b * h0 + tid] = t1;
+        rs_dzh[(int64_t)b * h0 + tid] = t2;
+    }
 }
 
 int launch_pointer_bwd2(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn, const float *p_he,
                         const float *p_rn, const float *ent, const float *lse, const float *dlogp, const float *dent,
                         const float *hidl, const float *w2l, int h0l, const float *hidr, const float *w2r, int h0r, float *dz_he,
-                        float *dz_rn, float *dprel, float *dprer, hipStream_t st) {
-    hipLaunchKernelGGL(pointer_bwd2_kernel, dim3((mb.B + 3) / 4), dim3(256), 0, st, pk, mb, z_he, z_rn, p_he, p_rn, ent, lse, dlogp,
-                       dent, hidl, w2l, h0l, hidr, w2r, h0r, dz_he, dz_rn, dprel, dprer);
+                        float *dz_rn, float *dprel, float *dprer, float *rs_dzh_l, float *rs_dpre_l, float *rs_dzh_r,
+                        float *rs_dpre_r, hipStream_t st) {
+    if (h0l > 256 || h0r > 256) return fail(UPAMD_E_LIMIT, "pointer heads: hidden width > 256 is not supported");
+    hipLaunchKernelGGL(pointer_bwd2_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, z_he, z_rn, p_he, p_rn, ent, lse, dlogp, dent, hidl,
+                       w2l, h0l, hidr, w2r, h0r, dz_he, dz_rn, dprel, dprer, rs_dzh_l, rs_dpre_l, rs_dzh_r, rs_dpre_r);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

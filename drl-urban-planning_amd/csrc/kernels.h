@@ -95,9 +95,7 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
                         hipStream_t st, float *last_col_dst = nullptr);
 
 // ---- graph.hip -------------------------------------------------------------------------
-int launch_gather_inputs(const PackedView &pk, const MbView &mb, float *Xp, float *U0, float *curg, hipStream_t st);
 __host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage);
-int launch_gather_rows(const PackedView &pk, const MbView &mb, int32_t *rows, hipStream_t st);
 // First GCN layer folded into the message-passing stage-in (edge.hip: fold_fill): the workgroup computes its P/Q (and
 // H_0) slice from the raw node features.  Xp: panel-major [2][M][16]; W1c = Wcat_1 We [2D][32] (rows in P/Q panel
 // order), b1c [2D]; We (zero-padded) [D][32], be [D].
@@ -127,15 +125,9 @@ int launch_mlp_pool_fwd(const PackedView &pk, const MbView &mb, int D, const flo
 int launch_mlp_pool_bwd(const PackedView &pk, const MbView &mb, int D, const float *dhbarV, int ld, const float *dMhe, float *G0,
                         float *dbe_extra, hipStream_t st);
 int launch_he_bias_rows(const PackedView &pk, const MbView &mb, int h0, const float *constb, float *hid, hipStream_t st);
-int launch_he_segsum(const PackedView &pk, const MbView &mb, int h0, const float *dpre, float *dconst, hipStream_t st);
 int launch_road_gather(const PackedView &pk, const MbView &mb, int D, const float *HL, float *XR, hipStream_t st);
 int launch_road_scatter_add(const PackedView &pk, const MbView &mb, int D, const float *dXR, float *GL, hipStream_t st);
 // masked softmax over each row's candidate list: logp, entropy (+ probabilities kept for backward)
-int launch_pointer_fwd(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn, float *p_he,
-                       float *p_rn, float *logp, float *ent, float *lse, hipStream_t st);
-int launch_pointer_bwd(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn,
-                       const float *p_he, const float *p_rn, const float *ent, const float *lse, const float *dlogp,
-                       const float *dent, float *dz_he, float *dz_rn, hipStream_t st);
 
 // ---- chain.hip: fused small kernels (job tables are passed BY VALUE as kernel arguments, <= 4 KB each) ---------------
 enum { PERM_PAD_COLS = 0, PERM_TRANSPOSE, PERM_WCAT, PERM_LAND_HEAD, PERM_LAND_SCATTER };
@@ -213,40 +205,10 @@ int launch_pointer_fwd2(const PackedView &pk, const MbView &mb, const float *hid
 int launch_pointer_bwd2(const PackedView &pk, const MbView &mb, const float *z_he, const float *z_rn, const float *p_he,
                         const float *p_rn, const float *ent, const float *lse, const float *dlogp, const float *dent,
                         const float *hidl, const float *w2l, int h0l, const float *hidr, const float *w2r, int h0r, float *dz_he,
-                        float *dz_rn, float *dprel, float *dprer, hipStream_t st);
+                        float *dz_rn, float *dprel, float *dprer, float *rs_dzh_l, float *rs_dpre_l, float *rs_dzh_r,
+                        float *rs_dpre_r, hipStream_t st);
 
 // ---- dense.hip -------------------------------------------------------------------------
-int launch_colsum_pm_part(const float *X, int64_t rows, int cols, const float *w, float *part, int *nblk_out, hipStream_t st);
-// C[i*ldc + j] (=|+=) act( sum_k A[i*sa0 + k*sa1] * B[k*sb0 + j*sb1] + bias[j] ) * out_scale
-int launch_smm(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, const float *B, int64_t sb0,
-               int64_t sb1, const float *bias, float *C, int64_t ldc, int accumulate, int act_tanh, float out_scale,
-               hipStream_t st);
-int smm_splits(int K);
-int launch_smm_splitk(int I, int J, int K, const float *A, int64_t sa0, int64_t sa1, const float *B, int64_t sb0,
-                      int64_t sb1, float *slabs, int *S_out, hipStream_t st);
-// dst[j] += sum_i X[i*ld + j]   (row-major), deterministic
-int launch_colsum_rm(const float *X, int rows, int cols, int64_t ld, float *dst, hipStream_t st);
-// part[blk][col] = sum_{rows of blk} (w ? w[row] : 1) * X(pm)[row][col];  then dst[col] += sum_blk
-int colsum_pm_blocks(int64_t rows);
-int launch_colsum_pm(const float *X, int64_t rows, int cols, const float *w, float *part, float *dst, hipStream_t st);
-int launch_reduce_rows_add(const float *part, int nrows, int cols, float *dst, hipStream_t st);
-// z[row] = sum_col X(pm)[row][col] * w[col]
-int launch_rowdot_pm(const float *X, int64_t rows, int cols, const float *w, float *z, hipStream_t st);
-// dpre(pm)[row][col] = dz[row] * w[col] * (1 - X[row][col]^2)
-int launch_rowdot_bwd_pm(const float *X, int64_t rows, int cols, const float *w, const float *dz, float *dpre,
-                         hipStream_t st);
-// dz[i] *= 1 - y[i]^2 (row-major, same shape)
-int launch_tanh_bwd(float *dz, const float *y, int64_t n, hipStream_t st);
-int launch_assemble_sv(const PackedView &pk, const MbView &mb, int D, int S_last, const float *Ulast,
-                       const float *hbarV, const float *hbarE, const float *att, float *SV, int ld, hipStream_t st);
-int launch_prep_wcat(const float *W, int D, float *Wcat, float *WcatT, hipStream_t st);
-int launch_pad_cols(const float *W, int rows, int cols, int cols_pad, float *out, hipStream_t st);
-int launch_transpose(const float *W, int rows, int cols, float *out, hipStream_t st);
-int launch_axpy(float *dst, const float *src, int64_t n, float alpha, hipStream_t st);   // dst += alpha*src
-int launch_prep_land_head(const float *W1, int D, int h0, float *W1f, float *Wbd, hipStream_t st);
-int launch_land_head_w_scatter(const float *dW1f, const float *dWbd, int D, int h0, float *gW1, hipStream_t st);
-int launch_add_p_panels(float *dst, const float *src, int D, hipStream_t st);   // dst[D] += P half of src[2D] (P/Q panel order)
-int launch_scale(float *dst, int64_t n, float alpha, hipStream_t st);                     // dst *= alpha
 int launch_ppo_loss(int B, const float *value, const float *logp, const float *ent, const int64_t *rows, const float *adv,
                     const float *ret, const float *old_logp, const float *exps, float clip_eps, float cv, float ce,
                     float inv_rows, float inv_ind, float *dvalue, float *dlogp, float *dent, float *losses,
