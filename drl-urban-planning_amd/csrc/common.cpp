@@ -25,6 +25,8 @@ int validate_desc(const upamd_model_desc *d) {
     const bool mlp = d->encoder == UPAMD_ENCODER_MLP;
     if (!mlp && (d->L <= 0 || d->L > 16)) return fail(UPAMD_E_INVALID, "num_gcn_layers must be in [1,16]");
     if (mlp && d->L != 0) return fail(UPAMD_E_INVALID, "the rl-mlp encoder has no GCN layers (L must be 0)");
+    if (d->edge_fc_layers < 0 || d->edge_fc_layers > UPAMD_MAX_EDGE_FC)
+        return fail(UPAMD_E_INVALID, "num_edge_fc_layers must be in [1,%d] (got %d)", UPAMD_MAX_EDGE_FC, d->edge_fc_layers);
     if (d->heads <= 0 || d->D % d->heads != 0) return fail(UPAMD_E_INVALID, "gcn_node_dim must be divisible by num_attention_heads");
     auto chk = [&](int n, const int32_t *h, const char *what, bool last_one, bool mult16) -> int {
         if (n <= 0 || n > UPAMD_MAX_MLP) return fail(UPAMD_E_INVALID, "%s: between 1 and %d layers supported", what, UPAMD_MAX_MLP);
@@ -73,6 +75,14 @@ int build_param_layout(const upamd_model_desc *d, ParamLayout *out) {
     for (int l = 0; l < d->L; ++l) {
         P.edge_w.push_back(add(e + "edge_fc_layers." + std::to_string(l) + ".linear_0.weight", D, 2 * D, 0));
         P.edge_b.push_back(add(e + "edge_fc_layers." + std::to_string(l) + ".linear_0.bias", D, 1, 0));
+        // sub-layers behind the first one (state_encoder.py:59-82), only when num_edge_fc_layers > 1
+        P.edge_wk.emplace_back();
+        P.edge_bk.emplace_back();
+        for (int k = 1; k < edge_fc_layers(*d); ++k) {
+            const std::string s = e + "edge_fc_layers." + std::to_string(l) + ".linear_" + std::to_string(k);
+            P.edge_wk.back().push_back(add(s + ".weight", D, D, 0));
+            P.edge_bk.back().push_back(add(s + ".bias", D, 1, 0));
+        }
     }
     if (!mlp) {
     P.inproj_w = add(e + "attention_layer.in_proj_weight", 3 * D, D, 0);

@@ -23,6 +23,8 @@ struct upamd_engine {
 namespace {
 
 constexpr int MAXL = 16;
+constexpr int MAXK = UPAMD_MAX_EDGE_FC;
+static inline int LK(int l, int k) { return (l - 1) * (MAXK + 1) + k; }      // l = 1 .. L, k = 0 .. MAXK
 
 // workspace slots (float offsets computed by make_plan); "+l" / "+i" ranges are indexed by layer / MLP depth
 enum Slot : int {
@@ -47,7 +49,14 @@ enum Slot : int {
     S_V = S_U + UPAMD_MAX_MLP + 1,        // + i (1 .. n_value - 1)
     S_DAV = S_V + UPAMD_MAX_MLP + 1,      // + i
     S_DAN = S_DAV + UPAMD_MAX_MLP,        // + i
-    S_COUNT = S_DAN + UPAMD_MAX_MLP
+    // ---- edge MLPs with K > 1 sub-layers (deep_edge.hip); "+ lk" = (l - 1) * MAXK + k
+    S_EIDX = S_DAN + UPAMD_MAX_MLP,       // int32: gsrc | gdst | grev [NI] each, then cand_inc [NH]
+    S_EDA, S_EDB,                         // [NI, D] ping-pong of the backward through the sub-layers
+    S_EA,                                 // + lk, k = 1 .. K: the sub-layer activations A_k [NI, D] (kept for the backward)
+    S_EWT = S_EA + MAXL * (MAXK + 1),     // + lk, k = 1 .. K-1: W_k^T
+    S_EBP = S_EWT + MAXL * (MAXK + 1),    // + lk, k = 1 .. K-1: per-graph column sums of dpre_k+1 [B, D] (bias gradient of linear_k)
+    S_ESLAB = S_EBP + MAXL * (MAXK + 1),  // + lk, k = 1 .. K-1: split-K slabs of dW_k
+    S_COUNT = S_ESLAB + MAXL * (MAXK + 1)
 };
 
 struct Plan {
@@ -63,12 +72,14 @@ struct Dims {
     int h0l, h0r;                            // hidden sizes of the two pointer heads
     int maxnum, maxval, maxdim;
     bool mlp;                                // rl-mlp encoder (UPAMD_ENCODER_MLP)
+    int K;                                   // num_edge_fc_layers (sub-layers of every edge MLP)
 };
 
 Dims dims_of(const upamd_model_desc &d) {
     Dims x;
     x.D = d.D; x.L = d.L; x.heads = d.heads; x.dh = d.D / d.heads; x.F = d.node_dim; x.Fn = d.numerical_dim;
     x.mlp = d.encoder == UPAMD_ENCODER_MLP;
+    x.K = x.mlp ? 1 : edge_fc_layers(d);
     x.S_last = d.num_hidden[d.n_num - 1];
     x.W = (x.mlp ? 2 : 3) * d.D + x.S_last + 3;
     x.Wp = (x.W + 15) / 16 * 16;
@@ -177,6 +188,20 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     // per-sample weight gradients (grouped dY^T X): <= 16 row splits of every per-sample weight (+ the collapsed ones)
     pl->small_slab_floats = 16LL * (P.n_floats + 4LL * D * D + 2LL * D * x.h0l + 4096);
     add(S_SLAB_SMALL, pl->small_slab_floats);
+    // edge MLPs with K > 1 sub-layers: one row per edge direction (incidence) behind the first Linear
+    if (x.K > 1) {
+        const int64_t NI = std::max<int64_t>(mb.n_inc, 1);
+        add(S_EIDX, 3 * NI + NH);
+        add(S_EDA, NI * D); add(S_EDB, NI * D);
+        for (int l = 1; l <= x.L; ++l) {
+            for (int k = 1; k <= x.K; ++k) add(S_EA + LK(l, k), NI * D);
+            for (int k = 1; k < x.K; ++k) {
+                add(S_EWT + LK(l, k), (int64_t)D * D);
+                add(S_EBP + LK(l, k), B * D);
+                add(S_ESLAB + LK(l, k), slab_floats(D, D, NI));
+            }
+        }
+    }
     // per-row sums of the pointer heads' backward (pointer_bwd2): [B][h0] each, reduced over the rows afterwards;
     // 0: land dz*hid, 1: (free), 2: road dz*hid, 3: road dpre  (the land dpre sums are S_DCONST)
     for (int k = 0; k < 4; ++k) add(S_CSP0 + k, B * std::max(std::max(x.h0l, x.h0r), 16));
@@ -211,6 +236,7 @@ MbView make_mb(const upamd_minibatch &mb) {
     MbView v;
     v.B = mb.B; v.M = mb.n_nodes; v.Nhe = mb.n_he; v.Nrn = mb.n_rn; v.max_n = mb.max_n; v.max_inc = mb.max_inc;
     v.idx = mb.idx_dev; v.node_off = mb.node_off_dev; v.he_off = mb.he_off_dev; v.rn_off = mb.rn_off_dev;
+    v.NI = mb.n_inc; v.inc_off = mb.inc_off_dev;
     v.rows = nullptr;
     return v;
 }
@@ -223,6 +249,8 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
     if (layout->node_dim != eng->d.node_dim || layout->numerical_dim != eng->d.numerical_dim)
         return fail(UPAMD_E_INVALID, "packed replay feature sizes (%d,%d) do not match the model (%d,%d)", layout->node_dim,
                     layout->numerical_dim, eng->d.node_dim, eng->d.numerical_dim);
+    if (eng->d.encoder == UPAMD_ENCODER_SGNN && edge_fc_layers(eng->d) > 1 && (!mb->inc_off_dev || mb->n_inc < 0))
+        return fail(UPAMD_E_INVALID, "num_edge_fc_layers > 1 needs the minibatch's incidence offsets (inc_off_dev, n_inc)");
     if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return fail(UPAMD_E_INVALID, "workspace must be 256-byte aligned");
     make_plan(eng->d, eng->P, *mb, pl);
     if (pl->total * 4 > ws_bytes) return fail(UPAMD_E_WORKSPACE, "workspace too small: need %lld bytes, got %lld", (long long)pl->total * 4, (long long)ws_bytes);
@@ -253,7 +281,7 @@ static int debug_sync(const char *what) {
 // (I % 128 == 0), otherwise one grouped-kernel launch with panel-major operands (narrow models: D = 16 ... 64)
 // tune knob "fold_layer1" (default on): first GCN layer computed inside the message-passing kernels
 static int g_fold_layer1 = 1;
-static bool fold_layer1(const MbView &mb, int L) { return g_fold_layer1 && L >= 2 && edge_fold_ok(mb); }
+static bool fold_layer1(const MbView &mb, int L, int K) { return g_fold_layer1 && K == 1 && L >= 2 && edge_fold_ok(mb); }
 
 int node_tn(const float *A, int I, const float *Bm, int J, int64_t rows, float *slabs, int *S_out, hipStream_t st, Profiler *prof) {
     if (tn_shape_mfma_ok(I, J)) return launch_gemm_tn(A, I, Bm, J, rows, slabs, S_out, st, prof);
@@ -291,7 +319,7 @@ int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch
     auto num = [&](size_t pos) { return atoi(n.c_str() + pos); };
     *kind = 0;
     // with the first layer folded into the message-passing kernels H0 and PQ1 are never materialised
-    const bool folded = !x.mlp && fold_layer1(make_mb(mb), x.L);
+    const bool folded = !x.mlp && fold_layer1(make_mb(mb), x.L, x.K);
     if (n[0] == 'H' && n.size() > 1 && isdigit(n[1])) {
         *rows = M; *cols = x.D; *kind = 1;
         return (num(1) <= x.L && !(folded && num(1) == 0)) ? S_H + num(1) : -1;
@@ -301,6 +329,11 @@ int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch
         return (num(2) >= 1 && num(2) <= x.L && !(folded && num(2) == 1)) ? S_PQ + num(2) : -1;
     }
     if (n == "dPQ") { *rows = M; *cols = 2 * x.D; *kind = 1; return S_DPQ; }
+    if (n.rfind("EA", 0) == 0 && n.size() >= 5 && n.find('_') != std::string::npos) {      // "EA<l>_<k>": sub-layer activation A_k of layer l
+        const int l = num(2), k = atoi(n.c_str() + n.find('_') + 1);
+        *rows = mb.n_inc; *cols = x.D; *kind = 1;
+        return (x.K > 1 && l >= 1 && l <= x.L && k >= 1 && k <= x.K) ? S_EA + LK(l, k) : -1;
+    }
     if (n == "G0" || n == "G1") { *rows = M; *cols = x.D; *kind = 1; return n == "G0" ? S_G0 : S_G1; }
     if (n == "Xp") { *rows = M; *cols = 32; *kind = 1; return S_XP; }
     if (n == "FE" || n == "dFE") { *rows = NH; *cols = 2 * x.D; *kind = 1; return n == "FE" ? S_FE : S_DFE; }
@@ -574,14 +607,45 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     // PQ_1 = H_0 Wcat_1^T = Xp (Wcat_1 We)^T + Wcat_1 be  (K = 32 instead of D: saves one full-size node GEMM)
     // With the fold (default) neither H_0 nor PQ_1 ever exists in HBM: the layer-1 message-passing workgroups build
     // their slices from Xp in LDS (edge.hip: fold_fill); otherwise two K = 32 GEMMs write them out.
-    const bool fold = fold_layer1(mb, x.L);
+    const bool fold = fold_layer1(mb, x.L, x.K);
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
     if (!fold) CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_WE_PAD), D, PR(P.node_b), nullptr, W(S_H + 0), 0, st, prof));
+    // num_edge_fc_layers > 1 (deep_edge.hip): the sub-layers behind the first Linear act on one row per edge direction;
+    // index tables (endpoints, opposite direction, candidate -> incidence) once per forward, W_k^T for the backward
+    const int64_t NIp = std::max<int64_t>(mb.NI, 1);
+    int32_t *gsrc = x.K > 1 ? reinterpret_cast<int32_t *>(W(S_EIDX)) : nullptr;
+    int32_t *gdst = gsrc + NIp, *grev = gsrc + 2 * NIp, *cand_inc = gsrc + 3 * NIp;
+    if (x.K > 1) {
+        CK(launch_inc_index(pk, mb, gsrc, gdst, grev, cand_inc, st));
+        PermJobs pj;
+        int blocks = 0;
+        for (int l = 1; l <= x.L; ++l)
+            for (int k = 1; k < x.K; ++k) {
+                if (pj.n >= PERM_MAX_JOBS) {
+                    CK(launch_permute(pj, blocks, st));
+                    pj.n = 0;
+                    blocks = 0;
+                }
+                CK(perm_add(&pj, &blocks, PERM_TRANSPOSE, PR(P.edge_wk[l - 1][k - 1]), nullptr, W(S_EWT + LK(l, k)), nullptr, nullptr,
+                            nullptr, D, D, 0));
+            }
+        CK(launch_permute(pj, blocks, st));
+    }
     for (int l = 1; l <= x.L; ++l) {
         if (l == 1) {
             if (!fold) CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_W1C), 2 * D, W(S_B1C), nullptr, W(S_PQ + 1), 0, st, prof));
         } else {
             CK(launch_gemm_nt(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), 2 * D, nullptr, nullptr, W(S_PQ + l), 0, st, prof));
+        }
+        if (x.K > 1) {
+            // A_1 = tanh(P_src + Q_dst + b_0) per edge direction, A_k+1 = tanh(A_k W_k^T + b_k), then the node segment sum
+            CK(launch_inc_gather_fwd(mb, D, W(S_PQ + l), PR(P.edge_b[l - 1]), gsrc, gdst, W(S_EA + LK(l, 1)), st));
+            for (int k = 1; k < x.K; ++k)
+                CK(launch_gemm_nt(W(S_EA + LK(l, k)), mb.NI, D, PR(P.edge_wk[l - 1][k - 1]), D, PR(P.edge_bk[l - 1][k - 1]), nullptr,
+                                  W(S_EA + LK(l, k + 1)), 1, st, prof));
+            CK(launch_inc_scatter_fwd(pk, mb, D, l == x.L, W(S_EA + LK(l, x.K)), grev, cand_inc, W(S_H + l - 1), W(S_H + l), W(S_HBARV),
+                                      W(S_HBARE), W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st));
+            continue;
         }
         // the last layer also writes the land-use pointer-head inputs FE (needs C, computed above)
         CK(launch_edge_fwd(pk, mb, D, l == x.L, W(S_PQ + l), PR(P.edge_b[l - 1]), W(S_H + l - 1), W(S_H + l), W(S_HBARV), W(S_HBARE),
@@ -824,11 +888,31 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_chain_bwd_pre(a, st));
     }
     // ---- 5. GCN layers, last to first
-    const bool fold = fold_layer1(mb, x.L);      // the forward's decision (same minibatch): PQ_1 was never written
+    const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
     for (int l = x.L; l >= 1; --l) {
         const bool last = (l == x.L);
         float *dPQ = defer ? W(S_DPQL + l) : W(S_DPQ);
+        if (x.K > 1) {
+            // backward through the sub-layers on the per-incidence rows (deep_edge.hip), top to bottom:
+            //   dpre_K = 1/2 (dS_src + dS_dst [+ head term]) (1 - A_K^2);  for j = K-1 .. 1 (linear_j: A_j -> A_j+1):
+            //   db_j = colsum dpre_j+1,  dW_j = dpre_j+1^T A_j,  dpre_j = (dpre_j+1 W_j) (1 - A_j^2);  then dP | dQ per node
+            const int64_t NIp = std::max<int64_t>(mb.NI, 1);
+            const int32_t *grev = reinterpret_cast<const int32_t *>(W(S_EIDX)) + 2 * NIp;
+            float *cur = W(S_EDA), *other = W(S_EDB);
+            CK(launch_inc_seed_bwd(pk, mb, D, last, W(S_EA + LK(l, x.K)), G, dhbarE, x.Wp, (last && land) ? W(S_DMHE) : nullptr, cur,
+                                   W(S_EBP + LK(l, x.K - 1)), st));
+            for (int j = x.K - 1; j >= 1; --j) {
+                CK(red1.add(W(S_EBP + LK(l, j)), B, D, 1, D, 0, D, GR(P.edge_bk[l - 1][j - 1]), D));
+                int Sn = 1;
+                CK(node_tn(cur, D, W(S_EA + LK(l, j)), D, mb.NI, W(S_ESLAB + LK(l, j)), &Sn, st, prof));
+                CK(red1.add(W(S_ESLAB + LK(l, j)), Sn, (int64_t)D * D, D, D, 0, D, GR(P.edge_wk[l - 1][j - 1]), D));
+                CK(launch_gemm_nt(cur, mb.NI, D, W(S_EWT + LK(l, j)), D, nullptr, nullptr, other, 0, st, prof));
+                CK(launch_inc_tanh_bwd(pk, mb, D, W(S_EA + LK(l, j)), other, j > 1 ? W(S_EBP + LK(l, j - 1)) : nullptr, st));
+                std::swap(cur, other);
+            }
+            CK(launch_inc_scatter_bwd(pk, mb, D, cur, grev, dPQ, W(S_DBIAS + l), st));
+        } else
         CK(launch_edge_bwd(pk, mb, D, last, W(S_PQ + l), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp, (last && land) ? W(S_DMHE) : nullptr,
                            dPQ, W(S_DBIAS + l), st, prof, (l == 1 && fold) ? &fa : nullptr));
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half

@@ -34,6 +34,8 @@ struct MbView {       // one minibatch (device schedule arrays)
     int64_t M, Nhe, Nrn;
     int max_n, max_inc;
     const int32_t *idx, *node_off, *he_off, *rn_off;
+    int64_t NI;                 // incidences (edge directions) of the minibatch; only used when num_edge_fc_layers > 1
+    const int32_t *inc_off;     // [B+1] prefix sums of 2e (may be null when K = 1)
     // [B][16] row descriptors gathered once per forward: columns 0..13 = the state's meta row, 14 = node_off[b],
     // 15 = he_off[b].  One scalar load per workgroup instead of the idx -> meta -> offsets chain.
     const int32_t *rows;
@@ -128,6 +130,20 @@ int launch_he_bias_rows(const PackedView &pk, const MbView &mb, int h0, const fl
 int launch_road_gather(const PackedView &pk, const MbView &mb, int D, const float *HL, float *XR, hipStream_t st);
 int launch_road_scatter_add(const PackedView &pk, const MbView &mb, int D, const float *dXR, float *GL, hipStream_t st);
 // masked softmax over each row's candidate list: logp, entropy (+ probabilities kept for backward)
+
+// ---- deep_edge.hip: edge MLPs with K > 1 sub-layers (per-incidence tensors, panel-major [D/16][NI][16]) -----------------
+int launch_inc_index(const PackedView &pk, const MbView &mb, int32_t *gsrc, int32_t *gdst, int32_t *grev, int32_t *cand_inc,
+                     hipStream_t st);
+int launch_inc_gather_fwd(const MbView &mb, int D, const float *PQ, const float *bias, const int32_t *gsrc, const int32_t *gdst,
+                          float *A1, hipStream_t st);
+int launch_inc_scatter_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *AK, const int32_t *grev,
+                           const int32_t *cand_inc, const float *Hin, float *Hout, float *hbarV, float *hbarE,
+                           const float *Ccur, float *FE, hipStream_t st);
+int launch_inc_seed_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *AK, const float *G,
+                        const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dpre, float *dbpart, hipStream_t st);
+int launch_inc_tanh_bwd(const PackedView &pk, const MbView &mb, int D, const float *A, float *dA, float *dbpart, hipStream_t st);
+int launch_inc_scatter_bwd(const PackedView &pk, const MbView &mb, int D, const float *dpre1, const int32_t *grev, float *dPQ,
+                           float *dbias_part, hipStream_t st);
 
 // ---- chain.hip: fused small kernels (job tables are passed BY VALUE as kernel arguments, <= 4 KB each) ---------------
 enum { PERM_PAD_COLS = 0, PERM_TRANSPOSE, PERM_WCAT, PERM_LAND_HEAD, PERM_LAND_SCATTER };

@@ -35,7 +35,8 @@ struct ParamLayout {
     // indices into `tensors`
     std::vector<int> num_w, num_b;            // numerical encoder
     int node_w = -1, node_b = -1;
-    std::vector<int> edge_w, edge_b;          // per GCN layer
+    std::vector<int> edge_w, edge_b;          // per GCN layer: first sub-layer (linear_0, [D, 2D])
+    std::vector<std::vector<int>> edge_wk, edge_bk;   // [layer][k - 1]: sub-layers k = 1 .. K-1 (linear_k, [D, D]); empty when K = 1
     int inproj_w = -1, inproj_b = -1, outproj_w = -1, outproj_b = -1;
     int q_w = -1, q_b = -1, k_w = -1, k_b = -1, v_w = -1, v_b = -1;
     std::vector<int> value_w, value_b;
@@ -45,6 +46,7 @@ struct ParamLayout {
 };
 
 int validate_desc(const upamd_model_desc *d);
+inline int edge_fc_layers(const upamd_model_desc &d) { return d.edge_fc_layers <= 0 ? 1 : d.edge_fc_layers; }
 int build_param_layout(const upamd_model_desc *d, ParamLayout *out);
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

@@ -11,8 +11,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libupamd.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_MLP = 4
+MAX_EDGE_FC = 4
 META_STRIDE = 16
 NODE_PAD = 24
 
@@ -23,7 +24,8 @@ class ModelDesc(C.Structure):
                 ('n_num', C.c_int32), ('num_hidden', C.c_int32 * MAX_MLP),
                 ('n_land', C.c_int32), ('land_hidden', C.c_int32 * MAX_MLP),
                 ('n_road', C.c_int32), ('road_hidden', C.c_int32 * MAX_MLP),
-                ('n_value', C.c_int32), ('value_hidden', C.c_int32 * MAX_MLP), ('encoder', C.c_int32)]
+                ('n_value', C.c_int32), ('value_hidden', C.c_int32 * MAX_MLP), ('encoder', C.c_int32),
+                ('edge_fc_layers', C.c_int32)]
 
 
 class PackLayout(C.Structure):
@@ -40,7 +42,8 @@ class PackLayout(C.Structure):
 class Minibatch(C.Structure):
     _fields_ = [('B', C.c_int32), ('n_nodes', C.c_int64), ('n_he', C.c_int64), ('n_rn', C.c_int64),
                 ('max_n', C.c_int32), ('max_inc', C.c_int32), ('idx_dev', C.c_void_p), ('node_off_dev', C.c_void_p),
-                ('he_off_dev', C.c_void_p), ('rn_off_dev', C.c_void_p)]
+                ('he_off_dev', C.c_void_p), ('rn_off_dev', C.c_void_p),
+                ('n_inc', C.c_int64), ('inc_off_dev', C.c_void_p)]
 
 
 # every symbol include/upamd.h declares: (restype, argtypes)
@@ -143,10 +146,11 @@ ENCODER_SGNN, ENCODER_MLP = 0, 1
 
 def make_desc(state_encoder_specs, policy_specs, value_specs, node_dim, numerical_dim, encoder=ENCODER_SGNN):
     """Model description from the reference's three spec dicts (hlg.yaml:21-33)."""
-    if encoder == ENCODER_SGNN and state_encoder_specs.get('num_edge_fc_layers', 1) != 1:
-        raise NotImplementedError('num_edge_fc_layers > 1 is not supported by the HIP path '
-                                  '(every shipped config uses 1)')
+    n_fc = int(state_encoder_specs.get('num_edge_fc_layers', 1)) if encoder == ENCODER_SGNN else 1
+    if not 1 <= n_fc <= MAX_EDGE_FC:
+        raise NotImplementedError('num_edge_fc_layers must be between 1 and %d (got %d)' % (MAX_EDGE_FC, n_fc))
     d = ModelDesc()
+    d.edge_fc_layers = n_fc
     d.node_dim, d.numerical_dim = int(node_dim), int(numerical_dim)
     d.encoder = int(encoder)
     d.D = int(state_encoder_specs['gcn_node_dim'])

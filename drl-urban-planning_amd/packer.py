@@ -242,7 +242,7 @@ class Schedule:
     """Device-side index arrays of a sequence of minibatches (uploaded once per epoch).
 
     For minibatch k with rows ``rows_k`` (state ids): ``idx`` and the prefix sums of n / head-edge /
-    road-node counts in minibatch order, plus the host-side totals the engine needs.
+    road-node / incidence (2 e) counts in minibatch order, plus the host-side totals the engine needs.
     """
 
     def __init__(self, packed, row_lists, device):
@@ -255,15 +255,17 @@ class Schedule:
             n = meta[rows, M_N].astype(np.int64)
             nh = meta[rows, M_NH].astype(np.int64)
             nr = meta[rows, M_NR].astype(np.int64)
-            arr = np.zeros(B + 3 * (B + 1), dtype=np.int32)
+            ninc = 2 * meta[rows, M_E].astype(np.int64)      # incidences (edge directions) per graph
+            arr = np.zeros(B + 4 * (B + 1), dtype=np.int32)
             arr[:B] = rows
             arr[B + 1:2 * B + 1] = np.cumsum(n)
             arr[2 * B + 2:3 * B + 2] = np.cumsum(nh)
             arr[3 * B + 3:4 * B + 3] = np.cumsum(nr)
+            arr[4 * B + 4:5 * B + 4] = np.cumsum(ninc)
             pad = (-arr.size) % 64            # keep every minibatch's arrays 256-byte aligned
             chunks.append(np.concatenate([arr, np.zeros(pad, dtype=np.int32)]))
             self.items.append(dict(B=int(B), n_nodes=int(n.sum()), n_he=int(nh.sum()), n_rn=int(nr.sum()),
-                                   max_n=int(n.max()), max_inc=int(2 * meta[rows, M_E].max()), base=cursor,
+                                   max_n=int(n.max()), max_inc=int(ninc.max()), n_inc=int(ninc.sum()), base=cursor,
                                    n_land=int((meta[rows, M_STAGE] == 0).sum()),
                                    n_road=int((meta[rows, M_STAGE] == 1).sum())))
             cursor += arr.size + pad
@@ -281,4 +283,5 @@ class Schedule:
         mb.node_off_dev = base + 4 * B
         mb.he_off_dev = base + 4 * (2 * B + 1)
         mb.rn_off_dev = base + 4 * (3 * B + 2)
+        mb.n_inc, mb.inc_off_dev = it['n_inc'], base + 4 * (4 * B + 3)
         return mb, it

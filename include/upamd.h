@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define UPAMD_ABI_VERSION 3
+#define UPAMD_ABI_VERSION 4
 
 #define UPAMD_OK 0
 #define UPAMD_E_INVALID (-1)   /* bad argument / unsupported configuration            */
@@ -45,6 +45,7 @@ extern "C" {
 #define UPAMD_MAX_MLP 4        /* max depth of each small MLP (hidden-size lists)      */
 #define UPAMD_META_STRIDE 16   /* int32 words per state in the meta table              */
 #define UPAMD_NODE_PAD 24      /* packed node-feature row width (node_dim <= 24)       */
+#define UPAMD_MAX_EDGE_FC 4     /* max num_edge_fc_layers (sub-layers of one edge MLP)  */
 
 int upamd_abi_version(void);
 const char *upamd_last_error(void);
@@ -52,8 +53,8 @@ const char *upamd_last_error(void);
 /* ------------------------------------------------------------------------------------------
  * Model description == the reference's YAML specs (urban_planning/cfg/exp_cfg/real/hlg.yaml:21-33)
  * read by create_sgnn_model (urban_planning/models/model.py:8-19).
- * Constraints of this build: D % 16 == 0, D % heads == 0, num_edge_fc_layers == 1 (all shipped
- * configs), node_dim <= 24, policy-head hidden sizes are multiples of 16 and end in 1.
+ * Constraints of this build: D % 16 == 0, D % heads == 0, num_edge_fc_layers <= UPAMD_MAX_EDGE_FC,
+ * node_dim <= 24, policy-head hidden sizes are multiples of 16 and end in 1.
  * ------------------------------------------------------------------------------------------ */
 #define UPAMD_ENCODER_SGNN 0   /* SGNNStateEncoder  (urban_planning/models/state_encoder.py:7-214,   --agent rl-sgnn) */
 #define UPAMD_ENCODER_MLP 1    /* MLPStateEncoder   (urban_planning/models/state_encoder.py:217-308, --agent rl-mlp): no
@@ -76,6 +77,9 @@ typedef struct upamd_model_desc {
     int32_t n_value;                         /* len(value_head_hidden_size), last == 1            */
     int32_t value_hidden[UPAMD_MAX_MLP];
     int32_t encoder;                         /* UPAMD_ENCODER_SGNN | UPAMD_ENCODER_MLP             */
+    int32_t edge_fc_layers;                  /* num_edge_fc_layers (state_encoder.py:59-82); 0 is read as 1.  1 (every shipped
+                                                config): the factorised P/Q message passing.  > 1: the sub-layers behind the
+                                                first one act on per-incidence tensors (one row per edge direction)     */
 } upamd_model_desc;
 
 /* Flat fp32 parameter buffer layout.  Tensor names are the reference's de-duplicated
@@ -164,6 +168,9 @@ typedef struct upamd_minibatch {
     const int32_t *node_off_dev;  /* [B+1] prefix sums of n in minibatch order                     */
     const int32_t *he_off_dev;    /* [B+1]                                                         */
     const int32_t *rn_off_dev;    /* [B+1]                                                         */
+    /* only read when the model has edge_fc_layers > 1 (may be 0 / NULL otherwise): */
+    int64_t n_inc;                /* sum of 2*e over the rows (incidences = edge directions)           */
+    const int32_t *inc_off_dev;   /* [B+1] prefix sums of 2*e in minibatch order                       */
 } upamd_minibatch;
 
 int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out);

@@ -1,6 +1,6 @@
 """Generate the committed golden vectors by running the REAL reference (build container only).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case ...]
 
 Imports /root/reference's own hot-path modules (oracle/ref_import.py recipe), builds the
 reference's ``policy_net``/``value_net`` with seeded weights, feeds them seeded quirky
@@ -54,12 +54,18 @@ CASES = {
                    max_nodes=40, max_edges=96, T=24, B=8, epochs=2, seed=13, road_fraction=0.3,
                    hyper=dict(lr=4e-4, eps=1e-5, weight_decay=1e-4, gamma=0.99, tau=0.95, clip_epsilon=0.2,
                               value_pred_coef=0.5, entropy_coef=0.01)),
+    # num_edge_fc_layers = 2 (urban_planning/models/state_encoder.py:59-82): a second Linear + tanh behind the first one
+    'case_k': dict(model=dict(D=32, L=2, K=2, S=(64, 16), heads=2, land_head=(32, 1), road_head=(16, 1),
+                              value_head=(32, 32, 1)), dead_candidate=True,
+                   max_nodes=40, max_edges=96, T=24, B=8, epochs=2, seed=17, road_fraction=0.3,
+                   hyper=dict(lr=4e-4, eps=1e-5, weight_decay=1e-4, gamma=0.99, tau=0.95, clip_epsilon=0.2,
+                              value_pred_coef=0.5, entropy_coef=0.01)),
 }
 
 
 def build(ref, spec):
     m = spec['model']
-    cfg = ref_import.DuckCfg(D=m['D'], L=m['L'], S=m['S'], heads=m['heads'], max_nodes=spec['max_nodes'],
+    cfg = ref_import.DuckCfg(D=m['D'], L=m['L'], K=m.get('K', 1), S=m['S'], heads=m['heads'], max_nodes=spec['max_nodes'],
                              max_edges=spec['max_edges'], land_head=m['land_head'], road_head=m['road_head'],
                              value_head=m['value_head'])
     torch.manual_seed(spec['seed'])
@@ -74,7 +80,10 @@ def build(ref, spec):
 
 def main():
     ref = ref_import.load_reference()
+    only = sys.argv[1:]                          # optional: the cases to (re)generate; default all
     for name, spec in CASES.items():
+        if only and name not in only:
+            continue
         cfg, policy_net, value_net = build(ref, spec)
         ac = ref.ActorCritic(policy_net, value_net)
         out = {}

@@ -19,15 +19,18 @@ CASE_MODEL = {
                    max_nodes=30, max_edges=64),
     'case_m': dict(D=32, L=0, S=(64, 16), heads=1, land_head=(32, 1), road_head=(16, 1), value_head=(32, 32, 1),
                    max_nodes=40, max_edges=96),
+    # num_edge_fc_layers = 2: the edge MLP has a second Linear behind the factorisable one (state_encoder.py:59-82)
+    'case_k': dict(D=32, L=2, K=2, S=(64, 16), heads=2, land_head=(32, 1), road_head=(16, 1), value_head=(32, 32, 1),
+                   max_nodes=40, max_edges=96),
 }
 MLP_CASES = ('case_m',)       # built with create_mlp_model (the rl-mlp encoder)
 
 
 def make_cfg(D=16, L=2, S=(64, 16), heads=1, land_head=(32, 1), road_head=(32, 1), value_head=(32, 32, 1),
-             max_nodes=1000, max_edges=3000):
+             max_nodes=1000, max_edges=3000, K=1):
     cfg = types.SimpleNamespace()
     cfg.state_encoder_specs = dict(state_encoder_hidden_size=list(S), gcn_node_dim=D, num_gcn_layers=L,
-                                   num_edge_fc_layers=1, max_num_nodes=max_nodes, max_num_edges=max_edges,
+                                   num_edge_fc_layers=K, max_num_nodes=max_nodes, max_num_edges=max_edges,
                                    num_attention_heads=heads)
     cfg.policy_specs = dict(policy_land_use_head_hidden_size=list(land_head),
                             policy_road_head_hidden_size=list(road_head))

@@ -11,7 +11,7 @@ import helpers
 from drl_urban_planning_amd import native
 
 
-@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_m'])
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_m', 'case_k'])
 def test_state_dict_keys_and_shapes_match_reference(name):
     z, sd, _ = helpers.load_case(name)
     cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
@@ -23,7 +23,7 @@ def test_state_dict_keys_and_shapes_match_reference(name):
     ac.load_state_dict(sd)          # a reference checkpoint loads
 
 
-@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m'])
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m', 'case_k'])
 def test_cpu_rollout_path_matches_reference(name):
     z, sd, states = helpers.load_case(name)
     cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
@@ -102,6 +102,54 @@ def test_unsupported_configs_fail_loudly():
     with pytest.raises(RuntimeError, match='multiple of 16'):
         native.param_table(native.make_desc(cfg.state_encoder_specs, cfg.policy_specs, cfg.value_specs, 23, 52))
     cfg = helpers.make_cfg()
-    cfg.state_encoder_specs['num_edge_fc_layers'] = 2
+    cfg.state_encoder_specs['num_edge_fc_layers'] = 5
     with pytest.raises(NotImplementedError):
         native.make_desc(cfg.state_encoder_specs, cfg.policy_specs, cfg.value_specs, 23, 52)
+
+
+def test_param_table_lists_the_edge_mlp_sublayers():
+    # num_edge_fc_layers > 1 (state_encoder.py:59-82): linear_1 .. linear_K-1 are [D, D] tensors of the shared group,
+    # named like the reference's state_dict keys; K = 1 keeps the old table
+    cfg = helpers.make_cfg(D=32, L=2, K=3)
+    table, n_floats, groups = native.param_table(native.make_desc(cfg.state_encoder_specs, cfg.policy_specs, cfg.value_specs, 23, 52))
+    shapes = dict((t[0], (t[2], t[3], t[4])) for t in table)
+    for l in range(2):
+        assert shapes['shared_net.edge_fc_layers.%d.linear_0.weight' % l] == (32, 64, 0)
+        for k in (1, 2):
+            assert shapes['shared_net.edge_fc_layers.%d.linear_%d.weight' % (l, k)] == (32, 32, 0)
+            assert shapes['shared_net.edge_fc_layers.%d.linear_%d.bias' % (l, k)] == (32, 1, 0)
+    _, _, ac = helpers.build_product(cfg)
+    names = set(k.split('.', 1)[1] for k in ac.state_dict() if 'shared_net' in k)
+    assert set(n for n in shapes if n.startswith('shared_net.')) == names
+    cfg1 = helpers.make_cfg(D=32, L=2)
+    table1, n1, _ = native.param_table(native.make_desc(cfg1.state_encoder_specs, cfg1.policy_specs, cfg1.value_specs, 23, 52))
+    assert n_floats - n1 == 2 * 2 * (32 * 32 + 32) and not any('linear_1' in t[0] and 'edge_fc' in t[0] for t in table1)
+
+
+def test_workspace_plan_of_a_deep_edge_mlp_model():
+    # host-side only (no launch): a K > 1 model plans the per-incidence tensors from the minibatch's n_inc, names the
+    # sub-layer activations for the stage tests, and K = 1 models ignore n_inc
+    import ctypes as C
+    L = native.lib()
+
+    def plan(K, n_inc, name=None):
+        cfg = helpers.make_cfg(D=32, L=2, K=K)
+        d = native.make_desc(cfg.state_encoder_specs, cfg.policy_specs, cfg.value_specs, 23, 52)
+        h = C.c_void_p()
+        native.check(L.upamd_engine_create(C.byref(d), C.byref(h)), 'upamd_engine_create')
+        mb = native.Minibatch()
+        mb.B, mb.n_nodes, mb.n_he, mb.n_rn, mb.max_n, mb.max_inc, mb.n_inc = 4, 100, 50, 20, 30, 120, n_inc
+        b = C.c_int64()
+        native.check(L.upamd_workspace_bytes(h, C.byref(mb), 1, C.byref(b)), 'upamd_workspace_bytes')
+        out = [b.value]
+        if name:
+            off, r, c, k = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+            out.append(L.upamd_ws_tensor(h, C.byref(mb), name.encode(), C.byref(off), C.byref(r), C.byref(c), C.byref(k)))
+            out += [r.value, c.value, k.value]
+        L.upamd_engine_destroy(h)
+        return out
+    assert plan(1, 400) == plan(1, 0)
+    two = plan(2, 400, 'EA2_2')
+    assert two[0] > plan(1, 400)[0] and two[1:] == [0, 400, 32, 1]
+    assert plan(2, 4000)[0] - two[0] >= 3600 * 32 * 4 * (2 * 2 + 2)      # A_k of both layers + the backward ping-pong
+    assert plan(2, 400, 'EA2_3')[1] != 0 and plan(3, 400, 'EA2_3')[1] == 0

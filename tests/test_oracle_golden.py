@@ -10,10 +10,10 @@ import cases
 from oracle import sgnn_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASE_HEADS = {'case_a': 1, 'case_b': 2, 'case_c': 1, 'case_m': 1}
-CASE_B = {'case_a': 8, 'case_b': 5, 'case_c': 6, 'case_m': 8}
-CASE_EPOCHS = {'case_a': 2, 'case_b': 2, 'case_c': 1, 'case_m': 2}
-CASE_SEED = {'case_a': 3, 'case_b': 5, 'case_c': 9, 'case_m': 13}
+CASE_HEADS = {'case_a': 1, 'case_b': 2, 'case_c': 1, 'case_m': 1, 'case_k': 2}
+CASE_B = {'case_a': 8, 'case_b': 5, 'case_c': 6, 'case_m': 8, 'case_k': 8}
+CASE_EPOCHS = {'case_a': 2, 'case_b': 2, 'case_c': 1, 'case_m': 2, 'case_k': 2}
+CASE_SEED = {'case_a': 3, 'case_b': 5, 'case_c': 9, 'case_m': 13, 'case_k': 17}
 CASE_HYPER = {
     'case_a': dict(lr=4e-4, eps=1e-5, weight_decay=0.0, gamma=1.0, tau=0.0, clip_epsilon=0.2,
                    value_pred_coef=0.5, entropy_coef=0.01),
@@ -23,6 +23,9 @@ CASE_HYPER = {
                    value_pred_coef=0.5, entropy_coef=0.01),
     # the rl-mlp ablation encoder (state_encoder.py:217-308), generated with the reference's create_mlp_model
     'case_m': dict(lr=4e-4, eps=1e-5, weight_decay=1e-4, gamma=0.99, tau=0.95, clip_epsilon=0.2,
+                   value_pred_coef=0.5, entropy_coef=0.01),
+    # num_edge_fc_layers = 2 (state_encoder.py:59-82)
+    'case_k': dict(lr=4e-4, eps=1e-5, weight_decay=1e-4, gamma=0.99, tau=0.95, clip_epsilon=0.2,
                    value_pred_coef=0.5, entropy_coef=0.01),
 }
 
@@ -34,7 +37,7 @@ def load_case(name):
     return z, sd, states
 
 
-@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m'])
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m', 'case_k'])
 def test_forward_matches_reference(name):
     z, sd, states = load_case(name)
     P = orc.leaf_params(orc.split_actor_critic_state_dict(sd), requires_grad=False)
@@ -54,7 +57,7 @@ def test_forward_matches_reference(name):
     np.testing.assert_allclose(keep['h_edges_%d' % L].numpy(), z['fwd/h_edges_last'], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m'])
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m', 'case_k'])
 def test_minibatch_losses_and_grads_match_reference(name):
     z, sd, states = load_case(name)
     P = orc.leaf_params(orc.split_actor_critic_state_dict(sd))
@@ -85,7 +88,7 @@ def test_gae_matches_reference(name):
         assert np.array_equal(ret.numpy(), z['gae/%s_ret' % tag])
 
 
-@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m'])
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_m', 'case_k'])
 def test_update_params_matches_reference(name):
     """Full update_params: permutation schedule, tail drop, first-step double clip, Adam."""
     z, sd, states = load_case(name)
