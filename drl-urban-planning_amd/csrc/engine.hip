@@ -758,9 +758,13 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
                 return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
             }));
-            CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
             // a candidate that is not a live edge has the bias as its embedding: its gradient is kept (-> dbe)
-            CK(launch_he_feat_bwd(pk, mb, D, W(S_FE), W(S_C), W(S_DFE), W(S_DMHE), W(S_DC_HEAD), st, 1));
+            if (he_feat_bwd_fused_ok(D, x.h0l)) {
+                CK(launch_he_feat_bwd_fused(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_W1FT), W(S_DMHE), W(S_DC_HEAD), st, 1));
+            } else {
+                CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
+                CK(launch_he_feat_bwd(pk, mb, D, W(S_FE), W(S_C), W(S_DFE), W(S_DMHE), W(S_DC_HEAD), st, 1));
+            }
         }
         // G^0 = the node mean's share + every candidate's dM at its selected endpoint; rows [2B, 3B) of the node-encoder
         // job = the per-graph sums of the non-live candidates' dM (bias only: their X rows are zero)
@@ -864,9 +868,14 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
             return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
         }));
-        // dFE = dpre W1f, then the feature backward (dMhe for the last GCN layer, dC from the m*c term)
-        CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
-        CK(launch_he_feat_bwd(pk, mb, D, W(S_FE), W(S_C), W(S_DFE), W(S_DMHE), W(S_DC_HEAD), st));
+        // dFE = dpre W1f, then the feature backward (dMhe for the last GCN layer, dC from the m*c term); with the shipped
+        // head width (h0 = 32) one kernel does both and dFE never exists in HBM
+        if (he_feat_bwd_fused_ok(D, x.h0l)) {
+            CK(launch_he_feat_bwd_fused(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_W1FT), W(S_DMHE), W(S_DC_HEAD), st));
+        } else {
+            CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
+            CK(launch_he_feat_bwd(pk, mb, D, W(S_FE), W(S_C), W(S_DFE), W(S_DMHE), W(S_DC_HEAD), st));
+        }
     }
     if (road) {
         CK(red1.add(W(S_CSP2), B, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));

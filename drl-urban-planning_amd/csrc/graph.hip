@@ -472,6 +472,110 @@ int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const floa
     return 0;
 }
 
+// The same backward with dFE = dpre W1f (K = h0 = 32) computed on the matrix cores inside the kernel: dFE ([candidates, 2D],
+// 0.8 GB at B = 2048, D = 256) is neither written by a GEMM nor read back.  One workgroup per (graph, group of four 32-feature
+// tiles), one tile per wave: v_mfma_f32_32x32x2_f32 with the FEATURES as the register dimension (A = W1f^T rows) and the
+// candidates as the lane dimension (B = dpre rows), so lane (r, kh) ends up with features 8g + 4kh + t (g, t < 4) of candidate
+// r -- whole 16-byte groups of the panel-major FE / dMhe rows.  The K order is free: lane half kh covers k = 16 kh .. 16 kh + 15
+// (one 64-byte dpre panel row per lane).  dC_head = sum over the graph's candidates of g2 * m in a fixed order (per lane over
+// its candidates, then a butterfly over the 32 lanes).
+typedef float f32x16g __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void he_feat_bwd_fused_kernel(PackedView pk, MbView mb, int NP, const float *__restrict__ FE,
+                                                                const float *__restrict__ C, const float *__restrict__ dprel,
+                                                                const float *__restrict__ W1fT, float *__restrict__ dMhe,
+                                                                float *__restrict__ dC_head, int keep_dead) {
+    const int b = blockIdx.x, t = mb.idx[b];
+    const int32_t *m = META(t);
+    const int nh = m[2];
+    const int D = NP * 16;
+    const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
+    const int ft = blockIdx.y * 4 + (threadIdx.x >> 6);            // this wave's 32-feature tile
+    if (ft >= D / 32) return;
+    const int64_t q0 = mb.he_off[b], NH = mb.Nhe;
+    float4 wa[4], wc[4], cc[4];
+    {
+        const float4 *pa = reinterpret_cast<const float4 *>(W1fT + (int64_t)(32 * ft + r) * 32 + 16 * kh);
+        const float4 *pc = reinterpret_cast<const float4 *>(W1fT + (int64_t)(D + 32 * ft + r) * 32 + 16 * kh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wa[q] = pa[q];
+            wc[q] = pc[q];
+            cc[q] = *reinterpret_cast<const float4 *>(C + (int64_t)b * D + 32 * ft + 8 * q + 4 * kh);
+        }
+    }
+    f32x16g sum2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum2[i] = 0.f;
+    for (int q = 0; q < nh; q += 32) {
+        const int row = q + r;
+        const bool in = row < nh;
+        const int rc = in ? row : nh - 1;                          // clamped: loads stay unconditional
+        const int64_t grow = q0 + rc;
+        const float4 *pd = reinterpret_cast<const float4 *>(dprel + ((int64_t)kh * NH + grow) * 16);
+        const float4 x0 = pd[0], x1 = pd[1], x2 = pd[2], x3 = pd[3];
+        float4 mm[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            mm[g] = *reinterpret_cast<const float4 *>(FE + ((int64_t)(2 * ft + (g >> 1)) * NH + grow) * 16 + 8 * (g & 1) + 4 * kh);
+        const float live = (keep_dead || pk.he_live[m[11] + rc]) ? 1.f : 0.f;
+        f32x16g a1, a2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a1[i] = 0.f; a2[i] = 0.f; }
+#define UPAMD_HF_STEP(W_, X_)                                                      \
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[W_].x, X_.x, a1, 0, 0, 0);    \
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[W_].x, X_.x, a2, 0, 0, 0);    \
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[W_].y, X_.y, a1, 0, 0, 0);    \
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[W_].y, X_.y, a2, 0, 0, 0);    \
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[W_].z, X_.z, a1, 0, 0, 0);    \
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[W_].z, X_.z, a2, 0, 0, 0);    \
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[W_].w, X_.w, a1, 0, 0, 0);    \
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[W_].w, X_.w, a2, 0, 0, 0);
+        UPAMD_HF_STEP(0, x0)
+        UPAMD_HF_STEP(1, x1)
+        UPAMD_HF_STEP(2, x2)
+        UPAMD_HF_STEP(3, x3)
+#undef UPAMD_HF_STEP
+        if (in) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // accumulators 4g .. 4g+3 = features 32 ft + 8g + 4kh + (0..3) of candidate `row`
+                const float4 out = make_float4(live * fmaf(a2[4 * g + 0], cc[g].x, a1[4 * g + 0]), live * fmaf(a2[4 * g + 1], cc[g].y, a1[4 * g + 1]),
+                                               live * fmaf(a2[4 * g + 2], cc[g].z, a1[4 * g + 2]), live * fmaf(a2[4 * g + 3], cc[g].w, a1[4 * g + 3]));
+                *reinterpret_cast<float4 *>(dMhe + ((int64_t)(2 * ft + (g >> 1)) * NH + grow) * 16 + 8 * (g & 1) + 4 * kh) = out;
+                sum2[4 * g + 0] = fmaf(a2[4 * g + 0], mm[g].x, sum2[4 * g + 0]);
+                sum2[4 * g + 1] = fmaf(a2[4 * g + 1], mm[g].y, sum2[4 * g + 1]);
+                sum2[4 * g + 2] = fmaf(a2[4 * g + 2], mm[g].z, sum2[4 * g + 2]);
+                sum2[4 * g + 3] = fmaf(a2[4 * g + 3], mm[g].w, sum2[4 * g + 3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = sum2[i];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        sum2[i] = v;
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(dC_head + (int64_t)b * D + 32 * ft + 8 * g + 4 * kh) =
+                make_float4(sum2[4 * g + 0], sum2[4 * g + 1], sum2[4 * g + 2], sum2[4 * g + 3]);
+    }
+}
+
+static int g_he_fused = 1;
+void set_he_feat_fused(int on) { g_he_fused = on ? 1 : 0; }
+bool he_feat_bwd_fused_ok(int D, int h0) { return g_he_fused && h0 == 32 && D % 32 == 0; }
+int launch_he_feat_bwd_fused(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C, const float *dprel,
+                             const float *W1fT, float *dMhe, float *dC_head, hipStream_t st, int keep_dead) {
+    const int tiles = D / 32;
+    hipLaunchKernelGGL(he_feat_bwd_fused_kernel, dim3(mb.B, (tiles + 3) / 4), dim3(256), 0, st, pk, mb, D / 16, FE, C, dprel, W1fT, dMhe,
+                       dC_head, keep_dead);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
 // road head input: rows of H^L of the road_mask candidates (stage-1 rows), policy.py:58
 __global__ __launch_bounds__(256) void road_gather_kernel(PackedView pk, MbView mb, int NP, const float *__restrict__ HL,
                                                           float *__restrict__ XR) {

@@ -119,6 +119,11 @@ int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, co
                     hipStream_t st);
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
                        const float *dFE, float *dMhe, float *dC_head, hipStream_t st, int keep_dead = 0);
+// the same with dFE = dpre W1f (h0 == 32) computed inside the kernel on the matrix cores: no dFE tensor in HBM
+bool he_feat_bwd_fused_ok(int D, int h0);
+void set_he_feat_fused(int on);            // tune knob "he_fused" (default on)
+int launch_he_feat_bwd_fused(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C, const float *dprel,
+                             const float *W1fT, float *dMhe, float *dC_head, hipStream_t st, int keep_dead = 0);
 // rl-mlp encoder (state_encoder.py:284-308): masked node mean of H^0 and the land-use head inputs gathered from H^0 rows
 int launch_mlp_pool_fwd(const PackedView &pk, const MbView &mb, int D, const float *H0, const float *be, const float *C,
                         float *hbarV, float *FE, hipStream_t st);

@@ -68,7 +68,7 @@ def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
 def tune():
     """set native tune knobs for one test; every knob is put back to its default afterwards"""
     from drl_urban_planning_amd import native
-    defaults = {'fold_layer1': 1, 'gemm_split': 0}
+    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1}
     touched = []
 
     def _set(name, value):
@@ -345,6 +345,15 @@ def test_wide_model_matches_oracle(D, L, heads, n_range, T):
     cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
                                    int(5.55 * n_range[1]) + 10, seed=21, road_fraction=0.3, n_range=n_range)
     _check_against_oracle(cfg, sd, replay, heads, T)
+
+
+def test_wide_model_with_unfused_head_backward_matches_oracle(tune):
+    """The land-use head's feature backward as two launches (K = 32 GEMM writing dFE + he_feat_bwd) -- the path of head
+    widths other than 32 -- instead of the default fused kernel (tune knob he_fused)."""
+    tune('he_fused', 0)
+    cfg, sd, replay = _random_case(128, 2, 4, (64, 16), (32, 1), (32, 1), (32, 32, 1), 6, 95, int(5.55 * 90) + 10, seed=21,
+                                   road_fraction=0.3, n_range=(40, 90))
+    _check_against_oracle(cfg, sd, replay, 4, 6)
 
 
 @pytest.mark.parametrize('nprod', [6, 9])
