@@ -216,9 +216,11 @@ int launch_gsmm(const SmmJobs &P, int blocks, hipStream_t st) {
 // one thread per output column n, Mat read coalesced over n.  Narrow layers (N < 128) split the K range over
 // 256 / npad thread groups and combine the partial sums in a fixed order.
 constexpr int CH_R = 8;
+constexpr int CH_PART = 1024;      // floats per row of the partial-sum scratch: `part` is [CH_PART][R] (32 KB)
 
-__device__ __forceinline__ void lin_rows(const float *__restrict__ Mat, int ld, int K, int N, const float *in,
-                                         const float *__restrict__ bias, float *out, int act, float scale, float *part) {
+// Scalar form (any N, ld): one thread per output column, full K range per thread (narrow layers split K over thread groups).
+__device__ __forceinline__ void lin_rows_scalar(const float *__restrict__ Mat, int ld, int K, int N, const float *in,
+                                                const float *__restrict__ bias, float *out, int act, float scale, float *part) {
     constexpr int R = CH_R;
     const int tid = threadIdx.x;
     if (N >= 128) {
@@ -295,6 +297,81 @@ __device__ __forceinline__ void lin_rows(const float *__restrict__ Mat, int ld, 
     __syncthreads();
 }
 
+// The chains are latency-bound: with a column per thread a D x D layer is a serial run of K / 16 weight-load round trips
+// (16 x ~1 us at D = 256), and a step runs ~12 of them back to back in four launches -- 0.27 ms of a 2.7 ms step at 256
+// rows per GPU (the strong-scaling point), unchanged at 2048.  Vector form (N, ld multiples of 4, N <= 1024): a thread owns
+// FOUR adjacent columns (one 16-byte weight load per k, coalesced over the group) and the K range is split over the
+// G = 256 / tpg thread groups, so a thread's serial run is K / (16 G) round trips (4 instead of 16 at D = 256); the group
+// partials go through `part` as [g][r][n] (conflict-free both ways) and are combined in the fixed order g = 0 .. G-1.
+__device__ __forceinline__ void lin_rows(const float *__restrict__ Mat, int ld, int K, int N, const float *in,
+                                         const float *__restrict__ bias, float *out, int act, float scale, float *part) {
+    constexpr int R = CH_R;
+    if ((N & 3) || (ld & 3) || N > CH_PART || (reinterpret_cast<uintptr_t>(Mat) & 15)) {
+        lin_rows_scalar(Mat, ld, K, N, in, bias, out, act, scale, part);
+        return;
+    }
+    const int tid = threadIdx.x;
+    int tpg = 1;                                   // threads per K group: the next power of two >= N / 4
+    while (tpg * 4 < N) tpg <<= 1;
+    const int G = 256 / tpg, g = tid / tpg, c0 = 4 * (tid % tpg);
+    const int kc = (K + G - 1) / G;
+    const int k0 = min(K, g * kc), k1 = min(K, k0 + kc);
+    float acc[4][R];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[c][r] = 0.f;
+    if (c0 < N) {
+        const float *mp = Mat + c0;
+        int k = k0;
+        for (; k + 16 <= k1; k += 16) {
+            float4 w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = *reinterpret_cast<const float4 *>(mp + (int64_t)(k + u) * ld);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float4 i0 = *reinterpret_cast<const float4 *>(in + (k + u) * R), i1 = *reinterpret_cast<const float4 *>(in + (k + u) * R + 4);
+                const float iv[R] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[0][r] = fmaf(w[u].x, iv[r], acc[0][r]);
+                    acc[1][r] = fmaf(w[u].y, iv[r], acc[1][r]);
+                    acc[2][r] = fmaf(w[u].z, iv[r], acc[2][r]);
+                    acc[3][r] = fmaf(w[u].w, iv[r], acc[3][r]);
+                }
+                // keep the scheduler from hoisting all 16 x 8 activation reads above the FMAs (128 extra live registers)
+                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        for (; k < k1; ++k) {
+            const float4 w = *reinterpret_cast<const float4 *>(mp + (int64_t)k * ld);
+            const float4 i0 = *reinterpret_cast<const float4 *>(in + k * R), i1 = *reinterpret_cast<const float4 *>(in + k * R + 4);
+            const float iv[R] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[0][r] = fmaf(w.x, iv[r], acc[0][r]);
+                acc[1][r] = fmaf(w.y, iv[r], acc[1][r]);
+                acc[2][r] = fmaf(w.z, iv[r], acc[2][r]);
+                acc[3][r] = fmaf(w.w, iv[r], acc[3][r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            *reinterpret_cast<float4 *>(part + ((int64_t)g * R + r) * N + c0) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += 256) {
+        const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float tot = b;
+            for (int q = 0; q < G; ++q) tot += part[((int64_t)q * R + r) * N + n];
+            out[n * R + r] = (act ? tanh_c(tot) : tot) * scale;
+        }
+    }
+    __syncthreads();
+}
+
 // global row-major [B][ld] <-> LDS [N][R]
 __device__ __forceinline__ void rows_load(const float *__restrict__ g, int64_t ld, int N, int b0, int nr, float *lds) {
     for (int i = threadIdx.x; i < N * CH_R; i += 256) {
@@ -348,7 +425,7 @@ __global__ __launch_bounds__(256) void chain_fwd_pre_kernel(ChainFwdPre a) {
     float *q1 = q0 + d.D * R;
     float *rr = q1 + d.D * R;                       // [heads * D][R]
     float *cb = rr + d.heads * d.D * R;             // [h0l][R]
-    float *part = cb + d.h0l * R;                   // [256][R]
+    float *part = cb + d.h0l * R;                   // [CH_PART][R]
     // row descriptors (MbView::rows): meta row of the state + minibatch offsets
     for (int i = tid; i < nr * UPAMD_META_STRIDE; i += 256) {
         const int b = b0 + i / UPAMD_META_STRIDE, c = i % UPAMD_META_STRIDE;
@@ -412,22 +489,9 @@ __global__ __launch_bounds__(256) void chain_fwd_pre_kernel(ChainFwdPre a) {
     rows_store(a.q0, d.D, d.D, b0, nr, q0);
     lin_rows(a.WiqT, d.D, d.D, d.D, q0, a.biq, q1, 0, d.scale, part);
     rows_store(a.q1, d.D, d.D, b0, nr, q1);
-    // r[h][j] = sum_{i in head h} q1[i] Wkk[i][j]
-    for (int o = tid; o < d.heads * d.D; o += 256) {
-        const int h = o / d.D, j = o % d.D;
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        for (int i = 0; i < d.dh; ++i) {
-            const int row = h * d.dh + i;
-            const float w = a.Wkk[(int64_t)row * d.D + j];
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fmaf(w, q1[row * R + r], acc[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) rr[o * R + r] = acc[r];
-    }
-    __syncthreads();
+    // r[h][j] = sum_{i in head h} q1[i] Wkk[i][j]: per head a [dh] x [D] product on the head's rows of Wkk
+    for (int h = 0; h < d.heads; ++h)
+        lin_rows(a.Wkk + (int64_t)h * d.dh * d.D, d.D, d.dh, d.D, q1 + h * d.dh * R, nullptr, rr + h * d.D * R, 0, 1.f, part);
     rows_store(a.r, (int64_t)d.heads * d.D, d.heads * d.D, b0, nr, rr);
     // land-use head: the c-only part of the first Linear becomes a per-row bias (policy.py:19-43, factorised)
     if (a.constb) {
@@ -437,7 +501,7 @@ __global__ __launch_bounds__(256) void chain_fwd_pre_kernel(ChainFwdPre a) {
 }
 
 int64_t chain_fwd_pre_lds(const ChainDims &d) {
-    return sizeof(float) * (int64_t)CH_R * (2 * d.maxnum + UPAMD_NODE_PAD + 3 * d.D + d.heads * d.D + d.h0l + 256);
+    return sizeof(float) * (int64_t)CH_R * (2 * d.maxnum + UPAMD_NODE_PAD + 3 * d.D + d.heads * d.D + d.h0l + CH_PART);
 }
 
 // ---- forward, after the attention: o = Wvv s + bvv, out-projection, state_value, value head
@@ -454,27 +518,12 @@ __global__ __launch_bounds__(256) void chain_fwd_post_kernel(ChainFwdPost a) {
     float *sv = att + d.D * R;                      // [Wp][R]
     float *v1 = sv + d.Wp * R;                      // [maxval][R]
     float *v2 = v1 + d.maxval * R;
-    float *part = v2 + d.maxval * R;                // [256][R]
+    float *part = v2 + d.maxval * R;                // [CH_PART][R]
     if (!d.mlp) rows_load(a.s, (int64_t)d.heads * d.D, d.heads * d.D, b0, nr, ss);
     __syncthreads();
-    // o[i] = bvv[i] + sum_j s[h(i)][j] Wvv[i][j]      (WvvT[j][i])
-    for (int i = tid; !d.mlp && i < d.D; i += 256) {
-        const int h = i / d.dh;
-        float acc[R];
-        const float b = a.bvv[i];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = b;
-#pragma unroll 4
-        for (int j = 0; j < d.D; ++j) {
-            const float w = a.WvvT[(int64_t)j * d.D + i];
-            const float *sj = ss + (h * d.D + j) * R;
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fmaf(w, sj[r], acc[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) oo[i * R + r] = acc[r];
-    }
-    __syncthreads();
+    // o[i] = bvv[i] + sum_j s[h(i)][j] Wvv[i][j]      (WvvT[j][i]): per head the head's dh output columns
+    for (int h = 0; !d.mlp && h < d.heads; ++h)
+        lin_rows(a.WvvT + h * d.dh, d.D, d.D, d.dh, ss + h * d.D * R, a.bvv + h * d.dh, oo + h * d.dh * R, 0, 1.f, part);
     if (!d.mlp) {
         rows_store(a.o, d.D, d.D, b0, nr, oo);
         lin_rows(a.WoT, d.D, d.D, d.D, oo, a.bo, att, 0, 1.f, part);
@@ -519,7 +568,7 @@ __global__ __launch_bounds__(256) void chain_fwd_post_kernel(ChainFwdPost a) {
 }
 
 int64_t chain_fwd_post_lds(const ChainDims &d) {
-    return sizeof(float) * (int64_t)CH_R * (d.heads * d.D + 2 * d.D + d.Wp + 2 * d.maxval + 256);
+    return sizeof(float) * (int64_t)CH_R * (d.heads * d.D + 2 * d.D + d.Wp + 2 * d.maxval + CH_PART);
 }
 
 // ---- backward, the part after the attention in forward order: value head, numerical encoder, out-projection, Wvv.
@@ -587,23 +636,15 @@ __global__ __launch_bounds__(256) void chain_bwd_post_kernel(ChainBwdPost a) {
     rows_store(a.datt, d.D, d.D, b0, nr, datt);
     lin_rows(a.Wo, d.D, d.D, d.D, datt, nullptr, dd, 0, 1.f, part);
     rows_store(a.dov, d.D, d.D, b0, nr, dd);
-    for (int o = tid; o < d.heads * d.D; o += 256) {
-        const int h = o / d.D, j = o % d.D;
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        for (int i = 0; i < d.dh; ++i) {
-            const int row = h * d.dh + i;
-            const float w = a.Wvv[(int64_t)row * d.D + j];
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fmaf(w, dd[row * R + r], acc[r]);
-        }
-        for (int r = 0; r < nr; ++r) a.ds[(int64_t)(b0 + r) * d.heads * d.D + o] = acc[r];
+    for (int h = 0; h < d.heads; ++h) {            // ds[h][j] = sum_{i in head h} do[i] Wvv[i][j]   (yy is free here)
+        lin_rows(a.Wvv + (int64_t)h * d.dh * d.D, d.D, d.dh, d.D, dd + h * d.dh * R, nullptr, yy, 0, 1.f, part);
+        rows_store(a.ds + h * d.D, (int64_t)d.heads * d.D, d.D, b0, nr, yy);
+        __syncthreads();
     }
 }
 
 int64_t chain_bwd_post_lds(const ChainDims &d) {
-    return sizeof(float) * (int64_t)CH_R * (2 * d.Wp + d.maxdim + d.D + 2 * d.maxnum + 256);
+    return sizeof(float) * (int64_t)CH_R * (2 * d.Wp + d.maxdim + d.D + 2 * d.maxnum + CH_PART);
 }
 
 // ---- backward, the part before the graph in forward order: dr -> dq1 -> dq0 -> dC (+ the pointer head's terms)
@@ -642,22 +683,8 @@ __global__ __launch_bounds__(256) void chain_bwd_pre_kernel(ChainBwdPre a) {
         return;
     }
     // dq1[i] = scale * sum_j dr[h(i)][j] Wkk[i][j]      (WkkT[j][i])
-    for (int i = tid; i < d.D; i += 256) {
-        const int h = i / d.dh;
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.f;
-#pragma unroll 4
-        for (int j = 0; j < d.D; ++j) {
-            const float w = a.WkkT[(int64_t)j * d.D + i];
-            const float *dj = drr + (h * d.D + j) * R;
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fmaf(w, dj[r], acc[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) g1[i * R + r] = acc[r] * d.scale;
-    }
-    __syncthreads();
+    for (int h = 0; h < d.heads; ++h)
+        lin_rows(a.WkkT + h * d.dh, d.D, d.D, d.dh, drr + h * d.D * R, nullptr, g1 + h * d.dh * R, 0, d.scale, part);
     rows_store(a.dq1, d.D, d.D, b0, nr, g1);
     lin_rows(a.Wiq, d.D, d.D, d.D, g1, nullptr, g0, 0, 1.f, part);
     rows_store(a.dq0, d.D, d.D, b0, nr, g0);
@@ -676,7 +703,7 @@ __global__ __launch_bounds__(256) void chain_bwd_pre_kernel(ChainBwdPre a) {
 }
 
 int64_t chain_bwd_pre_lds(const ChainDims &d) {
-    return sizeof(float) * (int64_t)CH_R * (d.heads * d.D + 3 * d.D + d.h0l + 256);
+    return sizeof(float) * (int64_t)CH_R * (d.heads * d.D + 3 * d.D + d.h0l + CH_PART);
 }
 
 template <typename A>
