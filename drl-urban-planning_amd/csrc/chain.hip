@@ -306,7 +306,8 @@ __device__ __forceinline__ void lin_rows_scalar(const float *__restrict__ Mat, i
 __device__ __forceinline__ void lin_rows(const float *__restrict__ Mat, int ld, int K, int N, const float *in,
                                          const float *__restrict__ bias, float *out, int act, float scale, float *part) {
     constexpr int R = CH_R;
-    if ((N & 3) || (ld & 3) || N > CH_PART || (reinterpret_cast<uintptr_t>(Mat) & 15)) {
+    // narrow layers (N < 128) already split K in the scalar form, and their many small groups would only lengthen the combine
+    if (N < 128 || (N & 3) || (ld & 3) || N > CH_PART || (reinterpret_cast<uintptr_t>(Mat) & 15)) {
         lin_rows_scalar(Mat, ld, K, N, in, bias, out, act, scale, part);
         return;
     }
@@ -822,8 +823,17 @@ __global__ __launch_bounds__(1024) void greduce_kernel(RedJobs P) {
     const int ij = ((int)blockIdx.x - J.blk_begin) * 64 + e;
     const bool in = ij < J.I * J.J;
     float acc = 0.f;
-    if (in)
-        for (int s = g; s < J.S; s += 16) acc += J.slab[(int64_t)s * J.sstride + ij];
+    if (in) {
+        // eight slab loads in flight per thread (clamped, unconditional); one at a time left the reduction at ~1 TB/s
+        for (int s0 = g; s0 < J.S; s0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = J.slab[(int64_t)min(s0 + 16 * u, J.S - 1) * J.sstride + ij];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + 16 * u < J.S) acc += v[u];
+        }
+    }
     part[g][e] = acc;
     __syncthreads();
     if (g != 0 || !in) return;

@@ -161,7 +161,9 @@ __global__ __launch_bounds__(256) void attn_fwd16_kernel(PackedView pk, MbView m
         }
         float mrun = -INFINITY, lrun = 0.f;
         for (int j = slot; j < n; j += 16) {
-            if (!nmask[j]) continue;
+            // the mask byte and the node's row are fetched TOGETHER (the row unconditionally, its dot product in front of the
+            // branch): with the branch first every trip was two dependent memory round trips, and the kernel is latency-bound
+            const bool live = nmask[j] != 0;
             float hv[NP];
 #pragma unroll
             for (int p = 0; p < NP; ++p) hv[p] = Hg[((int64_t)p * M + j) * 16 + c];
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_kernel(PackedView pk, MbView m
 #pragma unroll
             for (int p = 0; p < NP; ++p) dot = fmaf(hv[p], vec[p], dot);
             dot = reduce16(dot);
+            if (!live) continue;
             if (c == 0) sc[j] = dot;
             const float mnew = fmaxf(mrun, dot);
             const float keep = fast_exp(mrun - mnew), w = fast_exp(dot - mnew);
@@ -241,14 +244,16 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(PackedView pk, MbView m
         float Tpart = 0.f;
         for (int j = slot; j < n; j += 16) {
             const float a = alpha[(int64_t)h * M + o + j];
+            const bool live = nmask[j] != 0;
             float t = 0.f;
-            if (nmask[j]) {
-                float hv[NP];
+            float hv[NP];                          // fetched with the mask byte, not behind it (see attn_fwd16_kernel)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) hv[p] = Hg[((int64_t)p * M + j) * 16 + c];
+            for (int p = 0; p < NP; ++p) hv[p] = Hg[((int64_t)p * M + j) * 16 + c];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) t = fmaf(hv[p], vec[p], t);
-                t = reduce16(t);
+            for (int p = 0; p < NP; ++p) t = fmaf(hv[p], vec[p], t);
+            t = reduce16(t);
+            if (!live) t = 0.f;
+            if (live) {
                 const float wgt = a * t;
                 Tpart += wgt;
 #pragma unroll
