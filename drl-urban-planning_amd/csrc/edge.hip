@@ -118,8 +118,7 @@ __device__ __forceinline__ void stage_pq(float2 *PQl, const float *Pg, const flo
 constexpr float EF_LIMIT = 56.f, EF_BIAS_LIMIT = 6.f;
 // The forward needs only r1 + r2 of an edge, and with t = 1 + E1, u = 1 + E2:  1/t + 1/u = (t + u) / (t u) -- ONE
 // quarter-rate v_rcp_f32 instead of two (2 FMA + mul + add + rcp + FMA per column and incidence).  t u must stay
-// finite: 2 (2 EF_LIMIT_FWD + EF_BIAS_LIMIT) < 127.  The backward takes both reciprocals from 1 / (t u) as well and uses
-// the same limit.
+// finite: 2 (2 EF_LIMIT_FWD + EF_BIAS_LIMIT) < 127.
 constexpr float EF_LIMIT_FWD = 28.f;
 
 // writes the exp form of P/Q floats [4i, 4i+4) of the slice; returns the largest |C2 P|, |C2 Q| seen
@@ -166,7 +165,6 @@ __device__ __forceinline__ float rcp1p_mul(float a, float b) {      // 1 / (1 + 
 // (bit-identical to the forward's).  Everything stays within the 64 VGPRs of a two-workgroups-per-CU kernel.
 // ------------------------------------------------------------------------------------------
 typedef float f32x16e __attribute__((ext_vector_type(16)));
-typedef float f32x2e __attribute__((ext_vector_type(2)));
 
 // Operands of one 32-node tile, all loaded up front (ONE memory round trip per tile): the node features and the weight
 // rows of either the tile's 32 P/Q floats or its 16 H_0 columns.  The bias rides along as a 13th k step (bias x 1, the
@@ -697,7 +695,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         if (i1 < e) reinterpret_cast<uint32_t *>(L.nb)[i1] = nb1;
         if (tid <= n) L.rp[tid] = rRp;
         if (tid < n) L.ord[tid] = (uint16_t)rOrd;
-        ok = mx <= EF_LIMIT_FWD && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+        ok = mx <= EF_LIMIT && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
     } else {
         for (int i = tid; i <= n; i += EDGE_THREADS) L.rp[i] = rpg[i];
         for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
@@ -724,8 +722,8 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     bool ef = false;                       // LDS holds the exp form (workgroup-uniform), see stage_pq_exp
     if (STAGE) {
         if (!batched) {
-            if (FOLD) ok = fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, true) <= EF_LIMIT_FWD && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
-            else ok = stage_pq_exp(L.PQ, Pg, Qg, n, EF_LIMIT_FWD) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+            if (FOLD) ok = fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, true) <= EF_LIMIT && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+            else ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
         }
         ef = !__syncthreads_or(ok ? 0 : 1);
         if (!ef) {
@@ -773,6 +771,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     float2 sumdP = make_float2(0.f, 0.f), sumdQ = make_float2(0.f, 0.f);
     auto walk = [&](auto efc) {
         constexpr bool EF = decltype(efc)::value;
+        auto r = [](float a, float nb) -> float { return EF ? rcp1p_mul(a, nb) : rcp1p_exp2(a + nb); };
         const float2 eb = make_float2(EF ? __builtin_amdgcn_exp2f(bc.x) : bc.x, EF ? __builtin_amdgcn_exp2f(bc.y) : bc.y);
         auto fold = [&](float x, float bb) -> float { return EF ? x * bb : x + bb; };
         const int nchunks = (n + 7) >> 3;
@@ -788,28 +787,14 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             const float4 own = pq4(v);
             const float pv0 = fold(own.x, eb.x), qv0 = fold(own.z, eb.x), pv1 = fold(own.y, eb.y), qv1 = fold(own.w, eb.y);
             const float2 sv = ds2(v);
-            // sums of dm * (r - r^2) per column; 1 - tanh^2 = 4 (r - r^2).  The walk is VALU-issue bound (PMC: 93 % busy) and
-            // the quarter-rate reciprocals were half of its issue time: in exp form the two reciprocals of a column,
-            // 1 / t_P and 1 / t_Q, come from ONE v_rcp_f32 -- rc = 1 / (t_P t_Q), r_P = t_Q rc, r_Q = t_P rc (the product
-            // stays finite under EF_LIMIT_FWD) -- and everything else runs on the two columns at once (v_pk_*_f32).
-            f32x2e aP = {0.f, 0.f}, aQ = {0.f, 0.f};
-            const f32x2e pvv = {pv0, pv1}, qvv = {qv0, qv1}, one2 = {1.0f, 1.0f};
+            // sums of dm * (r - r^2) per column; 1 - tanh^2 = 4 (r - r^2)
+            float aP0 = 0.f, aQ0 = 0.f, aP1 = 0.f, aQ1 = 0.f;
             auto add = [&](const float4 &nb, float dm0, float dm1) {
-                const f32x2e dm = {dm0, dm1};
-                f32x2e rP, rQ;
-                if (EF) {
-                    const f32x2e nq = {nb.z, nb.w}, np = {nb.x, nb.y};
-                    const f32x2e tP = __builtin_elementwise_fma(pvv, nq, one2), tQ = __builtin_elementwise_fma(qvv, np, one2);
-                    const f32x2e pr = tP * tQ;
-                    const f32x2e rc = {__builtin_amdgcn_rcpf(pr.x), __builtin_amdgcn_rcpf(pr.y)};
-                    rP = tQ * rc;
-                    rQ = tP * rc;
-                } else {
-                    rP = f32x2e{rcp1p_exp2(pv0 + nb.z), rcp1p_exp2(pv1 + nb.w)};
-                    rQ = f32x2e{rcp1p_exp2(qv0 + nb.x), rcp1p_exp2(qv1 + nb.y)};
-                }
-                aP = __builtin_elementwise_fma(dm, rP * (one2 - rP), aP);
-                aQ = __builtin_elementwise_fma(dm, rQ * (one2 - rQ), aQ);
+                const float r1 = r(pv0, nb.z), r2 = r(qv0, nb.x), r3 = r(pv1, nb.w), r4 = r(qv1, nb.y);
+                aP0 = fmaf(dm0, fmaf(-r1, r1, r1), aP0);
+                aQ0 = fmaf(dm0, fmaf(-r2, r2, r2), aQ0);
+                aP1 = fmaf(dm1, fmaf(-r3, r3, r3), aP1);
+                aQ1 = fmaf(dm1, fmaf(-r4, r4, r4), aQ1);
             };
             for (; k < k1; ++k) {
                 const int u = L.nb[k];
@@ -838,7 +823,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                 }
             }
             if (valid) {
-                const float2 dP = make_float2(2.f * aP.x, 2.f * aP.y), dQ = make_float2(2.f * aQ.x, 2.f * aQ.y);     // 1/2 * 4
+                const float2 dP = make_float2(2.f * aP0, 2.f * aP1), dQ = make_float2(2.f * aQ0, 2.f * aQ1);     // 1/2 * 4
                 *reinterpret_cast<float2 *>(dPQ + ((int64_t)(2 * p) * M + o + v) * 16 + ca) = dP;
                 *reinterpret_cast<float2 *>(dPQ + ((int64_t)(2 * p + 1) * M + o + v) * 16 + ca) = dQ;
                 sumdP.x += dP.x; sumdP.y += dP.y;
