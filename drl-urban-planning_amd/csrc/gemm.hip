@@ -228,16 +228,18 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Workgroup tile (64 WM) x (64 WN), one 64 x 64 output block per wave.  128 x 128 (4 waves) is the measured optimum:
-// 256 x 128 / 128 x 256 are 3-5 % slower, 256 x 256 (16 waves on one barrier) 14 % (profiles/r02_gemm_lab.md).
-template <int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma2_kernel(const float *__restrict__ A, int64_t M, int K,
+// Workgroup tile (32 TM WM) x (32 TN WN), one (32 TM) x (32 TN) output block per wave.  128 x 128 with 64 x 64 per wave
+// (4 waves) is the measured optimum of the one-block-per-wave forms: 256 x 128 / 128 x 256 with EIGHT waves are 3-5 % slower,
+// 256 x 256 (16 waves on one barrier) 14 % (profiles/r02_gemm_lab.md).  TM / TN > 2 give a wave a bigger block instead (fewer
+// DMA and fragment-read instructions per MFMA at two waves per SIMD); PRIO raises the wave's priority over its MFMA burst.
+template <int WM, int WN, int TM = 2, int TN = 2, bool PRIO = false>
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN > 4 ? 2 : 1)) void gemm_nt_dma2_kernel(const float *__restrict__ A, int64_t M, int K,
                                                                     const float *__restrict__ W, int N, int64_t ldw,
                                                                     const float *__restrict__ bias,
                                                                     const float *__restrict__ R, float *__restrict__ C,
                                                                     int act_tanh, float alpha, int MT, int NT, int stagger_mode,
                                                                     int stagger_cycles) {
-    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
     constexpr int APANEL = BM * 16, STAGE = (BM + BN) * 16;      // floats: A panel then B panel
     constexpr int NI = (BM + BN) / 16;                           // 1 KiB LDS-DMA instructions per chunk
     constexpr int PER = NI / NW;                                 // ... per wave
@@ -255,11 +257,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma2_kernel(const float 
     const int wr = w / WN, wc = w % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -289,54 +291,57 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma2_kernel(const float 
         for (int j = 0; j < PER; ++j)
             __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kc * step[j]), (lptr_t)(smem + s * STAGE + dst[j]), 16, 0, 0);
     };
-    int aoff[2][2], boff[2][2];
+    int aoff[TM][2], boff[TN][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int g = 0; g < 2; ++g) {
+        const int sw = ((2 * g + lhi) ^ ((l31 >> 2) & 3)) * 4;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int sw = ((2 * g + lhi) ^ ((l31 >> 2) & 3)) * 4;
-            aoff[i][g] = (wr * 64 + i * 32 + l31) * 16 + sw;
-            boff[i][g] = APANEL + (wc * 64 + i * 32 + l31) * 16 + sw;
-        }
+        for (int i = 0; i < TM; ++i) aoff[i][g] = (wr * 32 * TM + i * 32 + l31) * 16 + sw;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) boff[j][g] = APANEL + (wc * 32 * TN + j * 32 + l31) * 16 + sw;
+    }
     const int KS = K >> 4;
     issue(0, 0);
     for (int ks = 0; ks < KS; ++ks) {
         wait_vmcnt<0>();                            // this wave's part of chunk ks has landed
         __builtin_amdgcn_s_barrier();               // ... and everyone's; all reads of chunk ks-1 are done
         const float *st = smem + (ks & 1) * STAGE;
-        float4 a[2][2], b[2][2];
+        float4 a[2][TM], b[2][TN];
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < 2; ++g) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[g][i] = *reinterpret_cast<const float4 *>(st + aoff[i][g]);
-                b[g][i] = *reinterpret_cast<const float4 *>(st + boff[i][g]);
-            }
+            for (int i = 0; i < TM; ++i) a[g][i] = *reinterpret_cast<const float4 *>(st + aoff[i][g]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[g][j] = *reinterpret_cast<const float4 *>(st + boff[j][g]);
+        }
         if (ks + 1 < KS) issue(ks + 1, (ks + 1) & 1);      // behind the fragment reads (hipcc drains LDS-DMA before a ds_read)
+        if (PRIO) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float av[2] = {t == 0 ? a[g][0].x : t == 1 ? a[g][0].y : t == 2 ? a[g][0].z : a[g][0].w,
-                                     t == 0 ? a[g][1].x : t == 1 ? a[g][1].y : t == 2 ? a[g][1].z : a[g][1].w};
-                const float bv[2] = {t == 0 ? b[g][0].x : t == 1 ? b[g][0].y : t == 2 ? b[g][0].z : b[g][0].w,
-                                     t == 0 ? b[g][1].x : t == 1 ? b[g][1].y : t == 2 ? b[g][1].z : b[g][1].w};
+                float av[TM], bv[TN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i) av[i] = t == 0 ? a[g][i].x : t == 1 ? a[g][i].y : t == 2 ? a[g][i].z : a[g][i].w;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j) bv[j] = t == 0 ? b[g][j].x : t == 1 ? b[g][j].y : t == 2 ? b[g][j].z : b[g][j].w;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0);
             }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int64_t gm = m0 + wr * 64 + i * 32 + l31;
+    for (int i = 0; i < TM; ++i) {
+        const int64_t gm = m0 + wr * 32 * TM + i * 32 + l31;
         if (gm >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int gn = n0 + wc * 64 + j * 32 + 8 * q + 4 * lhi;      // 4 consecutive columns gn..gn+3
+                const int gn = n0 + wc * 32 * TN + j * 32 + 8 * q + 4 * lhi;      // 4 consecutive columns gn..gn+3
                 const int64_t o = ((int64_t)(gn >> 4) * M + gm) * 16 + (gn & 15);
                 float v[4];
 #pragma unroll
@@ -370,12 +375,12 @@ void set_gemm_stagger(int mode, int cycles) {
     if (cycles >= 0) g_stagger_cycles = cycles;
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int TM = 2, int TN = 2, bool PRIO = false>
 static int launch_nt_dma2(const GemmNT &g, hipStream_t st) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const int MT = (int)((g.M + BM - 1) / BM), MT8 = (MT + 7) / 8 * 8, NT = g.N / BN;
     const size_t lds = sizeof(float) * 2 * (size_t)(BM + BN) * 16 + (size_t)g_lds_pad;
-    auto kern = gemm_nt_dma2_kernel<WM, WN>;
+    auto kern = gemm_nt_dma2_kernel<WM, WN, TM, TN, PRIO>;
     if (lds > 64 * 1024)
         UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(MT8 * NT), dim3(64 * WM * WN), lds, st, g.A, g.M, g.K, g.W, g.N, g.ldw, g.bias, g.R, g.C,
@@ -509,6 +514,12 @@ int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
             case 2: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<4, 2>(g, st); break;
             case 3: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<2, 4>(g, st); break;
             case 4: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<4, 4>(g, st); break;
+            // lab: a bigger block per wave (4 waves): 64 x 128 (workgroup 128 x 256) and 128 x 64 (256 x 128), +1 = with s_setprio
+            case 5: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<2, 2, 2, 4, false>(g, st); break;
+            case 6: if (nt_dma_ok(g) && g.N % 256 == 0) dma_rc = launch_nt_dma2<2, 2, 2, 4, true>(g, st); break;
+            case 7: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<2, 2, 4, 2, false>(g, st); break;
+            case 8: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<2, 2, 4, 2, true>(g, st); break;
+            case 9: if (nt_dma_ok(g)) dma_rc = launch_nt_dma2<2, 2, 2, 2, true>(g, st); break;
             default: break;
         }
     }

@@ -11,7 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drl_urban_planning_amd import native  # noqa: E402
 from kernel_bench import P, time_ms  # noqa: E402
 
-NAMES = {0: 'register-staged 128x128', 1: 'LDS-DMA 128x128 (default)', 2: 'LDS-DMA 256x128', 3: 'LDS-DMA 128x256', 4: 'LDS-DMA 256x256'}
+NAMES = {0: 'register-staged 128x128', 1: 'LDS-DMA 128x128 (default)', 2: 'LDS-DMA 256x128', 3: 'LDS-DMA 128x256', 4: 'LDS-DMA 256x256',
+         5: '4 waves x (64x128)', 6: '4 waves x (64x128) + setprio', 7: '4 waves x (128x64)', 8: '4 waves x (128x64) + setprio',
+         9: 'LDS-DMA 128x128 + setprio'}
+VARIANTS = tuple(int(v) for v in os.environ.get('GEMM_LAB_VARIANTS', '0,1,2,3,4').split(','))
 
 
 def main():
@@ -31,7 +34,7 @@ def main():
         for _ in range(30):
             fn()
         ref = Cc.clone()
-        for v in (0, 1, 2, 3, 4):
+        for v in VARIANTS:
             native.check(lib.upamd_tune(b'gemm_nt_dma', v))
             res = []
             for pad in (0, 12 * 1024):
@@ -46,7 +49,7 @@ def main():
         Ct0, Ct1 = torch.zeros(N // 16, Mt, 16, device=dev), torch.zeros(N // 16, Mt, 16, device=dev)
         native.check(lib.upamd_tune(b'gemm_nt_dma', 0))
         native.check(lib.upamd_gemm_nt(P(At), Mt, K, 0, 0, P(W), N, K, None, P(Rt), P(Ct0), 0, 0, 0, 1.0, st))
-        for v in (1, 2, 3, 4):
+        for v in [x for x in VARIANTS if x]:
             native.check(lib.upamd_tune(b'gemm_nt_dma', v))
             Ct1.zero_()
             native.check(lib.upamd_gemm_nt(P(At), Mt, K, 0, 0, P(W), N, K, None, P(Rt), P(Ct1), 0, 0, 0, 1.0, st))
