@@ -710,8 +710,7 @@ int64_t chain_bwd_pre_lds(const ChainDims &d) {
 template <typename A>
 static int launch_chain(void (*kern)(A), const A &a, int blocks, int64_t lds, hipStream_t st) {
     if (lds > 160 * 1024 - 512) return fail(UPAMD_E_LIMIT, "per-sample chain needs %lld bytes of LDS (model too wide)", (long long)lds);
-    if (lds > 64 * 1024)
-        UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), (size_t)lds, st, a);
     UPAMD_HIP(hipGetLastError());
     return 0;

@@ -568,9 +568,7 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     auto go = [&](bool stage, int64_t lds, int aux_cap, int fit) -> int {
 #define UPAMD_EF(L_, S_, F_)                                                                                          \
     do {                                                                                                              \
-        if (lds > 64 * 1024)                                                                                          \
-            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_>),               \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_>), lds)) return rc_;  \
         hipLaunchKernelGGL((edge_fwd_kernel<L_, S_, F_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin,    \
                            Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa);                                           \
     } while (0)
@@ -865,9 +863,7 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     auto go = [&](bool stage, int64_t lds, int aux_cap, int fit) -> int {
 #define UPAMD_EB(L_, S_, F_)                                                                                          \
     do {                                                                                                              \
-        if (lds > 64 * 1024)                                                                                          \
-            UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_, F_>),               \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_, F_>), lds)) return rc_;  \
         hipLaunchKernelGGL((edge_bwd_kernel<L_, S_, F_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G,      \
                            dhbarE, ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit, fa);                               \
     } while (0)

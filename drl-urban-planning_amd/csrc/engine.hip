@@ -107,11 +107,6 @@ ChainDims chain_dims(const upamd_model_desc &d, const Dims &x, int B) {
     return c;
 }
 
-const char *slot_name_table(int s, char *buf) {      // inverse of slot_of_name for the fixed slots (debugging)
-    (void)s; (void)buf;
-    return "";
-}
-
 // Models whose node-level weight-gradient shapes are too small for the tiled MFMA kernel (D < 32: the reference's
 // shipped D = 16) are launch-bound: their five dY^T X products per step become jobs of the one grouped launch that
 // already computes the per-sample weight gradients.

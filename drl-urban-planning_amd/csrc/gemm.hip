@@ -14,6 +14,10 @@
 //
 // Replaces the reference's nn.Linear calls on padded [B,E,2D] / [B,N,D] tensors
 // (urban_planning/models/state_encoder.py:19,59-82,110-130; policy.py:19-43) and their autograd.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "kernels.h"
 
 namespace upamd {
@@ -381,8 +385,7 @@ static int launch_nt_dma2(const GemmNT &g, hipStream_t st) {
     const int MT = (int)((g.M + BM - 1) / BM), MT8 = (MT + 7) / 8 * 8, NT = g.N / BN;
     const size_t lds = sizeof(float) * 2 * (size_t)(BM + BN) * 16 + (size_t)g_lds_pad;
     auto kern = gemm_nt_dma2_kernel<WM, WN, TM, TN, PRIO>;
-    if (lds > 64 * 1024)
-        UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int64_t)lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(MT8 * NT), dim3(64 * WM * WN), lds, st, g.A, g.M, g.K, g.W, g.N, g.ldw, g.bias, g.R, g.C,
                        g.act_tanh, g.alpha, MT, NT, g_stagger_mode, g_stagger_cycles);
     return 0;
@@ -416,6 +419,21 @@ __global__ void gemm_nt_generic_kernel(const float *__restrict__ A, int64_t M, i
     if (R) acc += R[o];
     if (act_tanh) acc = fast_tanh(acc);
     C[o] = acc * alpha;
+}
+
+int ensure_dynamic_lds(const void *kernel, int64_t lds_bytes) {
+    if (lds_bytes <= 64 * 1024) return 0;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int64_t> raised;
+    int dev = 0;
+    UPAMD_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    int64_t &have = raised[std::make_pair(dev, kernel)];
+    if (lds_bytes > have) {
+        UPAMD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        have = lds_bytes;
+    }
+    return 0;
 }
 
 int prof_begin(Profiler *prof, const char *name, hipStream_t st, double flops, double bytes) {

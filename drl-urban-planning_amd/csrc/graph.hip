@@ -407,8 +407,7 @@ int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, co
     }
     const size_t lds = sizeof(float) * (size_t)(2 * heads * D + 2 * heads * mb.max_n + 256 + 8);
     if (lds > (size_t)LDS_LIMIT) return fail(UPAMD_E_LIMIT, "attn_bwd: LDS need %zu too large", lds);
-    if (lds > 64 * 1024)
-        UPAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&attn_bwd_kernel), (int64_t)lds)) return rc;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(mb.B), dim3(256), lds, st, pk, mb, D / 16, heads, HL, r, alpha, ds, dhbarV, ld_dhbarV, GL, dr);
     UPAMD_HIP(hipGetLastError());
     return 0;

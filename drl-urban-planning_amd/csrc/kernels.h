@@ -53,6 +53,9 @@ struct Profiler {
 };
 // HIP-event bracket around one launch on `st` (no-ops unless prof->on); returns 1 if recording
 int prof_begin(Profiler *prof, const char *name, hipStream_t st, double flops, double bytes);
+// A launch that asks for more than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize raised first; the
+// largest value already set is remembered per (device, kernel), so the runtime call happens once, not per launch.
+int ensure_dynamic_lds(const void *kernel, int64_t lds_bytes);
 void prof_end(Profiler *prof, const char *name, hipStream_t st, int began);
 
 // ---- gemm.hip --------------------------------------------------------------------------
