@@ -72,6 +72,11 @@ def test_packer_hlg_shape_and_schedule():
     base = it['base']
     np.testing.assert_array_equal(flat[base:base + 3], [15, 3, 9])
     np.testing.assert_array_equal(flat[base + 3:base + 7], np.concatenate([[0], np.cumsum(pk.meta[[15, 3, 9], 0])]))
+    # incidence (edge-direction) prefix sums, read by models with num_edge_fc_layers > 1: the last of the four offset arrays
+    ninc = 2 * pk.meta[[15, 3, 9], 1]
+    assert mb.n_inc == it['n_inc'] == int(ninc.sum()) and it['max_inc'] == int(ninc.max())
+    np.testing.assert_array_equal(flat[base + 4 * 3 + 3:base + 5 * 3 + 4], np.concatenate([[0], np.cumsum(ninc)]))
+    assert mb.inc_off_dev == sched.dev.data_ptr() + 4 * (base + 4 * 3 + 3)
 
 
 def test_packer_rejects_bad_input():
