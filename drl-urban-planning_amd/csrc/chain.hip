@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256) void chain_fwd_pre_kernel(ChainFwdPre a) {
     const int nchain = (d.B + CH_R - 1) / CH_R;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nchain) {
+        if (a.part == CHAIN_LAYERS) return;
         // node features of graph b -> panel-major, K padded to 32; column 31 = 1 (a weight-gradient GEMM against Xp then
         // also yields the column sums; the forward weights of that column are zero padding)
         const int b = (int)blockIdx.x - nchain;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void chain_fwd_pre_kernel(ChainFwdPre a) {
     float *cb = rr + d.heads * d.D * R;             // [h0l][R]
     float *part = cb + d.h0l * R;                   // [CH_PART][R]
     // row descriptors (MbView::rows): meta row of the state + minibatch offsets
-    for (int i = tid; i < nr * UPAMD_META_STRIDE; i += 256) {
+    for (int i = tid; a.part != CHAIN_LAYERS && i < nr * UPAMD_META_STRIDE; i += 256) {
         const int b = b0 + i / UPAMD_META_STRIDE, c = i % UPAMD_META_STRIDE;
         int32_t v;
         if (c == 14) v = a.mb.node_off[b];
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(256) void chain_fwd_pre_kernel(ChainFwdPre a) {
         else v = a.pk.meta[(int64_t)a.mb.idx[b] * UPAMD_META_STRIDE + c];
         a.rows[(int64_t)b * UPAMD_META_STRIDE + c] = v;
     }
+    if (a.part == CHAIN_GATHER) return;
     for (int i = tid; i < d.Fn * R; i += 256) {
         const int r = i / d.Fn, k = i % d.Fn;
         const float v = r < nr ? a.pk.numerical[(int64_t)a.mb.idx[b0 + r] * d.Fn + k] : 0.f;
@@ -717,7 +719,10 @@ static int launch_chain(void (*kern)(A), const A &a, int blocks, int64_t lds, hi
 }
 
 int launch_chain_fwd_pre(const ChainFwdPre &a, hipStream_t st) {
-    return launch_chain(chain_fwd_pre_kernel, a, (a.d.B + CH_R - 1) / CH_R + a.d.B, chain_fwd_pre_lds(a.d), st);
+    const int nchain = (a.d.B + CH_R - 1) / CH_R;
+    // CHAIN_GATHER keeps the full grid (its chain workgroups write the row descriptors) but needs no LDS
+    return launch_chain(chain_fwd_pre_kernel, a, nchain + (a.part == CHAIN_LAYERS ? 0 : a.d.B),
+                        a.part == CHAIN_GATHER ? 0 : chain_fwd_pre_lds(a.d), st);
 }
 int launch_chain_fwd_post(const ChainFwdPost &a, hipStream_t st) {
     return launch_chain(chain_fwd_post_kernel, a, (a.d.B + CH_R - 1) / CH_R, chain_fwd_post_lds(a.d), st);

@@ -18,6 +18,9 @@ struct upamd_engine {
     upamd_model_desc d;
     ParamLayout P;
     Profiler prof;
+    // side stream of the forked step (see fork_side): created on first use, on the device of the caller's stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -252,6 +255,31 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
     return 0;
 }
 
+// The per-sample chain launches are latency-bound (50-65 us at any batch size, 32 workgroups at 256 rows) and most of them are
+// off the critical path: the forward's chain is needed only from the LAST GCN layer on, the backward's chain + grouped
+// per-sample weight gradients only by the final reduction.  They run on an engine-owned side stream, forked from / joined to the
+// caller's stream with events, underneath the GCN layers' GEMM / message-passing launches (tune knob "side_stream", default on).
+static int g_side_stream = 1;
+static int side_ready(upamd_engine *eng) {
+    if (eng->side) return 0;
+    UPAMD_HIP(hipStreamCreateWithFlags(&eng->side, hipStreamNonBlocking));
+    UPAMD_HIP(hipEventCreateWithFlags(&eng->ev_fork, hipEventDisableTiming));
+    UPAMD_HIP(hipEventCreateWithFlags(&eng->ev_join, hipEventDisableTiming));
+    return 0;
+}
+// side stream continues from this point of `st`
+static int fork_side(upamd_engine *eng, hipStream_t st) {
+    UPAMD_HIP(hipEventRecord(eng->ev_fork, st));
+    UPAMD_HIP(hipStreamWaitEvent(eng->side, eng->ev_fork, 0));
+    return 0;
+}
+// `st` continues after everything enqueued on the side stream so far
+static int join_side(upamd_engine *eng, hipStream_t st) {
+    UPAMD_HIP(hipEventRecord(eng->ev_join, eng->side));
+    UPAMD_HIP(hipStreamWaitEvent(st, eng->ev_join, 0));
+    return 0;
+}
+
 // UPAMD_DEBUG_SYNC=1: synchronise after every launch and name the one that faulted (debugging aid; off by default)
 static const bool g_debug_sync = getenv("UPAMD_DEBUG_SYNC") && atoi(getenv("UPAMD_DEBUG_SYNC")) != 0;
 static int debug_sync(const char *what) {
@@ -382,6 +410,7 @@ int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch
 }  // namespace
 
 void upamd::set_fold_layer1(int on) { g_fold_layer1 = on ? 1 : 0; }
+void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
 
 extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
     if (!out) return fail(UPAMD_E_INVALID, "upamd_engine_create: out is null");
@@ -409,6 +438,12 @@ extern "C" int upamd_profile_reset(upamd_engine *eng) {
 extern "C" void upamd_engine_destroy(upamd_engine *eng) {
     if (!eng) return;
     upamd_profile_reset(eng);
+    if (eng->side) {
+        (void)hipStreamSynchronize(eng->side);
+        (void)hipEventDestroy(eng->ev_fork);
+        (void)hipEventDestroy(eng->ev_join);
+        (void)hipStreamDestroy(eng->side);
+    }
     delete eng;
 }
 
@@ -583,6 +618,8 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     }
     // ---- 3. per-sample chain before the graph part (+ row descriptors, + node-feature gather)
     const ChainDims cd = chain_dims(d, x, B);
+    const bool forked = g_side_stream != 0;
+    if (forked) CK(side_ready(eng));
     {
         ChainFwdPre a;
         memset(&a, 0, sizeof(a));
@@ -594,7 +631,17 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         for (int i = 0; i <= d.n_num; ++i) a.U[i] = W(S_U + i);
         a.curg = W(S_CURG); a.C = W(S_C); a.q0 = W(S_Q0); a.q1 = W(S_Q1); a.r = W(S_R);
         a.constb = land ? W(S_CONSTB) : nullptr;
-        CK(launch_chain_fwd_pre(a, st));
+        if (forked) {
+            // row descriptors + node features first (the graph part needs them at once); the per-sample layers go to the
+            // side stream and are joined in front of the last GCN layer (the first consumer of C, then r)
+            a.part = CHAIN_GATHER;
+            CK(launch_chain_fwd_pre(a, st));
+            CK(fork_side(eng, st));
+            a.part = CHAIN_LAYERS;
+            CK(launch_chain_fwd_pre(a, eng->side));
+        } else {
+            CK(launch_chain_fwd_pre(a, st));
+        }
     }
     mb.rows = reinterpret_cast<const int32_t *>(W(S_ROWS));
     // ---- 4. node encoder on all nodes (state_encoder.py:189-190) and the GCN layers (state_encoder.py:194-197).
@@ -632,6 +679,7 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         } else {
             CK(launch_gemm_nt(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), 2 * D, nullptr, nullptr, W(S_PQ + l), 0, st, prof));
         }
+        if (forked && l == x.L) CK(join_side(eng, st));      // C (head inputs of the last layer), r, U, constb are ready
         if (x.K > 1) {
             // A_1 = tanh(P_src + Q_dst + b_0) per edge direction, A_k+1 = tanh(A_k W_k^T + b_k), then the node segment sum
             CK(launch_inc_gather_fwd(mb, D, W(S_PQ + l), PR(P.edge_b[l - 1]), gsrc, gdst, W(S_EA + LK(l, 1)), st));
@@ -881,7 +929,64 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_gemm_nt(W(S_DPRER), mb.Nrn, x.h0r, W(S_R1T), D, nullptr, nullptr, W(S_DXR), 0, st, prof));
         CK(launch_road_scatter_add(pk, mb, D, W(S_DXR), G, st));
     }
+    // ---- 3b / 7. every per-sample weight gradient dY^T X in ONE grouped MFMA launch.  Its inputs are complete once the
+    // per-sample chain below has run, so in the forked step it is launched on the side stream right behind that chain and
+    // only its slab reductions wait for the join (small models put their node-level products into the same launch: not forked)
+    struct Pending { Reducer *rd; const float *slab; int S, N, K; float *dst; int ldd, overwrite; };
+    std::vector<Pending> pending;           // the slabs are reduced after the grouped launch that fills them
+    auto grouped_launch = [&](hipStream_t gs) -> int {
+        float *slab = W(S_SLAB_SMALL);
+        int64_t used = 0;
+        // (A [B][N], X [B][K] | ones) -> dst [N][K] (ld), accumulate or overwrite; bias: X = nullptr
+        auto job = [&](Reducer &rd, const float *A, int64_t lda, int N, const float *X, int64_t ldx, int K, float *dst, int ldd,
+                       int overwrite) -> int {
+            if (tj.n >= TN_MAX_JOBS) return fail(UPAMD_E_LIMIT, "too many per-sample weight-gradient jobs");
+            const int splits = tn_job_splits(B);
+            if (used + (int64_t)splits * N * K > pl.small_slab_floats) return fail(UPAMD_E_WORKSPACE, "small-slab region exhausted");
+            int Sj = 1;
+            CK(tn_add(&tj, A, lda, N, X, ldx, K, B, slab + used, &Sj));
+            pending.push_back(Pending{&rd, slab + used, Sj, N, K, dst, ldd, overwrite});
+            used += (int64_t)Sj * N * K;
+            return 0;
+        };
+        for (int i = 0; i < d.n_value; ++i) {       // value head (value.py:15-34)
+            const int N = d.value_hidden[i];
+            const int K = i == 0 ? x.W : d.value_hidden[i - 1];
+            const float *X = i == 0 ? W(S_SV) : W(S_V + i);
+            CK(job(red1, W(S_DAV + i), N, N, X, i == 0 ? x.Wp : K, K, GR(P.value_w[i]), K, 0));
+            CK(job(red1, W(S_DAV + i), N, N, nullptr, 0, 1, GR(P.value_b[i]), 1, 0));
+        }
+        for (int i = 0; i < d.n_num; ++i) {         // numerical encoder
+            const int N = d.num_hidden[i];
+            const int K = i == 0 ? x.Fn : d.num_hidden[i - 1];
+            CK(job(red1, W(S_DAN + i), N, N, W(S_U + i), K, K, GR(P.num_w[i]), K, 0));
+            CK(job(red1, W(S_DAN + i), N, N, nullptr, 0, 1, GR(P.num_b[i]), 1, 0));
+        }
+        CK(job(red1, W(S_DATT), D, D, W(S_O), D, D, GR(P.outproj_w), D, 0));
+        CK(job(red1, W(S_DATT), D, D, nullptr, 0, 1, GR(P.outproj_b), 1, 0));
+        for (int h = 0; h < x.heads; ++h) {
+            // dWvv[h-slice,:] = do[:,h-slice]^T s[:,h,:] ;  dWkk[h-slice,:] = q1[:,h-slice]^T dr[:,h,:]
+            CK(job(red1, W(S_DO) + h * x.dh, D, x.dh, W(S_S) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWVV) + (int64_t)h * x.dh * D, D, 1));
+            CK(job(red1, W(S_Q1) + h * x.dh, D, x.dh, W(S_DR) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWKK) + (int64_t)h * x.dh * D, D, 1));
+        }
+        CK(job(red1, W(S_DO), D, D, nullptr, 0, 1, W(S_DBVV), 1, 1));
+        CK(job(red1, W(S_DQ1), D, D, W(S_Q0), D, D, gWin, D, 0));                    // in_proj, q rows
+        CK(job(red1, W(S_DQ1), D, D, nullptr, 0, 1, gbin, 1, 0));
+        CK(job(red1, W(S_DQ0), D, D, W(S_C), D, D, GR(P.q_w), D, 0));
+        CK(job(red1, W(S_DQ0), D, D, nullptr, 0, 1, GR(P.q_b), 1, 0));
+        if (land) CK(job(red1, W(S_DCONST), x.h0l, x.h0l, W(S_C), D, D, W(S_DWBD), D, 1));
+        // the current node's pass through the node encoder: after the collapsed-product gradients (same destination)
+        CK(job(red2, W(S_DC), D, D, W(S_CURG), UPAMD_NODE_PAD, x.F, GR(P.node_w), x.F, 0));
+        CK(job(red2, W(S_DC), D, D, nullptr, 0, 1, GR(P.node_b), 1, 0));
+        CK(launch_gtn(tj, gs));
+        return 0;
+    };
     // ---- 4. per-sample chain, the part before the graph: dr -> dq1 -> dq0 -> dC (+ the land-use head's two dC terms)
+    const bool forked = g_side_stream != 0 && !defer;
+    if (forked) {
+        CK(side_ready(eng));
+        CK(fork_side(eng, st));
+    }
     {
         ChainBwdPre a;
         memset(&a, 0, sizeof(a));
@@ -889,8 +994,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         a.dconst = land ? W(S_DCONST) : nullptr; a.dC_head = land ? W(S_DC_HEAD) : nullptr;
         a.WkkT = W(S_WKKT); a.Wiq = Wiq; a.Wq = PR(P.q_w); a.Wbd = W(S_WBD);
         a.dq1 = W(S_DQ1); a.dq0 = W(S_DQ0); a.dC = W(S_DC);
-        CK(launch_chain_bwd_pre(a, st));
+        CK(launch_chain_bwd_pre(a, forked ? eng->side : st));
     }
+    if (forked) CK(grouped_launch(eng->side));
     // ---- 5. GCN layers, last to first
     const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
@@ -941,57 +1047,11 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     CK(node_tn_red(G, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), [&](int Sn) {
         return red1.add(W(S_SLAB_XP2), Sn, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b));
     }));
-    // ---- 7. every per-sample weight gradient dY^T X in ONE grouped MFMA launch
-    {
-        float *slab = W(S_SLAB_SMALL);
-        int64_t used = 0;
-        struct Pending { Reducer *rd; const float *slab; int S, N, K; float *dst; int ldd, overwrite; };
-        std::vector<Pending> pending;       // the slabs are reduced after the grouped launch that fills them
-        // (A [B][N], X [B][K] | ones) -> dst [N][K] (ld), accumulate or overwrite; bias: X = nullptr
-        auto job = [&](Reducer &rd, const float *A, int64_t lda, int N, const float *X, int64_t ldx, int K, float *dst, int ldd,
-                       int overwrite) -> int {
-            if (tj.n >= TN_MAX_JOBS) return fail(UPAMD_E_LIMIT, "too many per-sample weight-gradient jobs");
-            const int splits = tn_job_splits(B);
-            if (used + (int64_t)splits * N * K > pl.small_slab_floats) return fail(UPAMD_E_WORKSPACE, "small-slab region exhausted");
-            int Sj = 1;
-            CK(tn_add(&tj, A, lda, N, X, ldx, K, B, slab + used, &Sj));
-            pending.push_back(Pending{&rd, slab + used, Sj, N, K, dst, ldd, overwrite});
-            used += (int64_t)Sj * N * K;
-            return 0;
-        };
-        for (int i = 0; i < d.n_value; ++i) {       // value head (value.py:15-34)
-            const int N = d.value_hidden[i];
-            const int K = i == 0 ? x.W : d.value_hidden[i - 1];
-            const float *X = i == 0 ? W(S_SV) : W(S_V + i);
-            CK(job(red1, W(S_DAV + i), N, N, X, i == 0 ? x.Wp : K, K, GR(P.value_w[i]), K, 0));
-            CK(job(red1, W(S_DAV + i), N, N, nullptr, 0, 1, GR(P.value_b[i]), 1, 0));
-        }
-        for (int i = 0; i < d.n_num; ++i) {         // numerical encoder
-            const int N = d.num_hidden[i];
-            const int K = i == 0 ? x.Fn : d.num_hidden[i - 1];
-            CK(job(red1, W(S_DAN + i), N, N, W(S_U + i), K, K, GR(P.num_w[i]), K, 0));
-            CK(job(red1, W(S_DAN + i), N, N, nullptr, 0, 1, GR(P.num_b[i]), 1, 0));
-        }
-        CK(job(red1, W(S_DATT), D, D, W(S_O), D, D, GR(P.outproj_w), D, 0));
-        CK(job(red1, W(S_DATT), D, D, nullptr, 0, 1, GR(P.outproj_b), 1, 0));
-        for (int h = 0; h < x.heads; ++h) {
-            // dWvv[h-slice,:] = do[:,h-slice]^T s[:,h,:] ;  dWkk[h-slice,:] = q1[:,h-slice]^T dr[:,h,:]
-            CK(job(red1, W(S_DO) + h * x.dh, D, x.dh, W(S_S) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWVV) + (int64_t)h * x.dh * D, D, 1));
-            CK(job(red1, W(S_Q1) + h * x.dh, D, x.dh, W(S_DR) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWKK) + (int64_t)h * x.dh * D, D, 1));
-        }
-        CK(job(red1, W(S_DO), D, D, nullptr, 0, 1, W(S_DBVV), 1, 1));
-        CK(job(red1, W(S_DQ1), D, D, W(S_Q0), D, D, gWin, D, 0));                    // in_proj, q rows
-        CK(job(red1, W(S_DQ1), D, D, nullptr, 0, 1, gbin, 1, 0));
-        CK(job(red1, W(S_DQ0), D, D, W(S_C), D, D, GR(P.q_w), D, 0));
-        CK(job(red1, W(S_DQ0), D, D, nullptr, 0, 1, GR(P.q_b), 1, 0));
-        if (land) CK(job(red1, W(S_DCONST), x.h0l, x.h0l, W(S_C), D, D, W(S_DWBD), D, 1));
-        // the current node's pass through the node encoder: after the collapsed-product gradients (same destination)
-        CK(job(red2, W(S_DC), D, D, W(S_CURG), UPAMD_NODE_PAD, x.F, GR(P.node_w), x.F, 0));
-        CK(job(red2, W(S_DC), D, D, nullptr, 0, 1, GR(P.node_b), 1, 0));
-        CK(launch_gtn(tj, st));
-        for (const Pending &q : pending) CK(q.rd->add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
-        for (auto &f : after_gtn) CK(f());
-    }
+    // ---- 7. (not forked: the grouped launch here) then its slab reductions, and the deferred node-level ones
+    if (forked) CK(join_side(eng, st));
+    else CK(grouped_launch(st));
+    for (const Pending &q : pending) CK(q.rd->add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
+    for (auto &f : after_gtn) CK(f());
     // ---- 8. reduction #1: every split-K slab / partial sum of the step, fixed order
     CK(red1.flush());
     // ---- 9. gradients of the prepared parameters mapped back onto the stored ones

@@ -108,6 +108,7 @@ struct FoldArgs {
     const float *Xp, *W1c, *b1c, *We, *be;
 };
 bool edge_fold_ok(const MbView &mb);
+void set_side_stream(int on);              // tune knob "side_stream" (default on): per-sample chains + grouped weight gradients on an engine-owned side stream
 void set_fold_layer1(int on);              // tune knob: compute the first GCN layer inside the message-passing kernels       // every graph of the minibatch fits the staged (LDS-resident) size classes
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
@@ -184,7 +185,11 @@ struct ChainFwdPre {
     const float *WeT, *be, *WqT, *bq, *WiqT, *biq, *Wkk, *WbdT, *b1l;
     float *U[UPAMD_MAX_MLP + 1], *curg, *C, *q0, *q1, *r, *constb;
     float *hbarE;        // mlp: We xbar_E + be  (mean over the live edges of the encoded selected endpoint)
+    // what this launch covers: CHAIN_ALL, or the two halves of a forked forward -- CHAIN_GATHER (row descriptors + node-feature
+    // gather: what the graph part needs first) and CHAIN_LAYERS (the per-sample layers, needed only from the last GCN layer on)
+    int part;
 };
+enum { CHAIN_ALL = 0, CHAIN_GATHER = 1, CHAIN_LAYERS = 2 };
 struct ChainFwdPost {
     ChainDims d; const int32_t *rows;
     const float *s, *hbarV, *hbarE, *Ulast, *WvvT, *bvv, *WoT, *bo, *WvT[UPAMD_MAX_MLP], *bv[UPAMD_MAX_MLP];

@@ -68,7 +68,7 @@ def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
 def tune():
     """set native tune knobs for one test; every knob is put back to its default afterwards"""
     from drl_urban_planning_amd import native
-    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1}
+    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1}
     touched = []
 
     def _set(name, value):
@@ -345,6 +345,32 @@ def test_wide_model_matches_oracle(D, L, heads, n_range, T):
     cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
                                    int(5.55 * n_range[1]) + 10, seed=21, road_fraction=0.3, n_range=n_range)
     _check_against_oracle(cfg, sd, replay, heads, T)
+
+
+@pytest.mark.parametrize('D,L,heads,n_range,T', [(256, 3, 1, (200, 345), 24), (64, 2, 2, (30, 60), 16)])
+def test_forked_step_is_bit_identical_to_the_single_stream_step(D, L, heads, n_range, T, tune):
+    """The per-sample chains and the grouped weight-gradient launch run on the engine's side stream underneath the GCN
+    layers (tune knob side_stream, default on).  Same kernels, same reduction orders: values and every gradient must equal
+    the single-stream step BIT FOR BIT, on every repetition (a missing fork / join dependency would show up as a mismatch)."""
+    cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
+                                   int(5.55 * n_range[1]) + 10, seed=23, road_fraction=0.3, n_range=n_range)
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, replay.states, replay.actions)
+    g = torch.Generator().manual_seed(9)
+    seeds = [torch.randn(T, generator=g).to(DEV) for _ in range(3)]
+
+    def run():
+        value, logp, ent = _forward(eng, pk, mb, flat)
+        grads = torch.zeros(eng.n_floats, device=DEV)
+        eng.backward(pk, mb, flat, seeds[0], seeds[1], seeds[2], grads)
+        torch.cuda.synchronize()
+        return [value.clone(), logp.clone(), ent.clone(), grads]
+    tune('side_stream', 0)
+    ref = run()
+    tune('side_stream', 1)
+    for rep in range(6):
+        out = run()
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b), 'repetition %d differs from the single-stream step' % rep
 
 
 def test_wide_model_with_unfused_head_backward_matches_oracle(tune):
