@@ -618,7 +618,8 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     }
     // ---- 3. per-sample chain before the graph part (+ row descriptors, + node-feature gather)
     const ChainDims cd = chain_dims(d, x, B);
-    const bool forked = g_side_stream != 0;
+    // (launch-bound small models gain nothing from the fork: its two event round trips cost more than they hide)
+    const bool forked = g_side_stream != 0 && !defer_node_tn(x.D);
     if (forked) CK(side_ready(eng));
     {
         ChainFwdPre a;
