@@ -44,10 +44,10 @@ __device__ __forceinline__ float rcp1p_exp2(float x) {      // 1 / (1 + 2^x)
 
 __host__ __device__ static inline int64_t a16(int64_t x) { return (x + 15) / 16 * 16; }
 
-__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage) {
+__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds) {
     (void)last;
     int64_t b = 0;
-    if (stage) b += (int64_t)max_n * 192;                     // P/Q interleaved (128 B/node) + H or dS (64 B/node)
+    if (stage) b += (int64_t)max_n * (hlds ? 192 : 128);      // P/Q interleaved (128 B/node) + H or dS (64 B/node)
     b = a16(b);
     b += a16(((int64_t)max_n + 1) * 4);                       // row_ptr
     b += a16((int64_t)max_inc * 2);                           // neighbour ids (u16)
@@ -79,12 +79,12 @@ struct EdgeLds {
     unsigned char *aux;   // last layer: the row's candidate-edge lists (sized by the launcher from the spare LDS)
 };
 
-__device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool stage, bool bwd) {
+__device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool stage, bool bwd, bool hlds = true) {
     EdgeLds L;
     int64_t o = 0;
     L.PQ = reinterpret_cast<float2 *>(smem);
-    L.X = reinterpret_cast<float *>(smem + (int64_t)n * 128);
-    if (stage) o = (int64_t)n * 192;
+    L.X = reinterpret_cast<float *>(smem + (int64_t)n * 128);      // (not there when !hlds: the forward then keeps H in HBM)
+    if (stage) o = (int64_t)n * (hlds ? 192 : 128);
     o = (o + 15) / 16 * 16;
     L.rp = reinterpret_cast<int *>(smem + o); o += (((int64_t)n + 1) * 4 + 15) / 16 * 16;
     L.nb = reinterpret_cast<uint16_t *>(smem + o); o += ((int64_t)e * 4 + 15) / 16 * 16;
@@ -303,7 +303,9 @@ __device__ __forceinline__ float fold_fill(const FoldArgs &fa, int64_t M, int64_
 // with W1 = [Wa|Wb|Wc|Wd] that is (Wa+Wd) m + Wc (m*c) + (Wb-Wd) c, so only FE = [m ; m*c] is materialised and
 // the c-only term becomes a per-row bias.
 // ------------------------------------------------------------------------------------------
-template <bool LAST, bool STAGE, bool FOLD>
+// HLDS = false (staged P/Q, H left in HBM): the forward needs H only for the residual add at the end of a node's walk, so a
+// graph whose slice is too big for two workgroups per CU WITH H (> ~350 nodes: the DHM-sized graphs) still fits without it.
+template <bool LAST, bool STAGE, bool FOLD, bool HLDS = true>
 __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), amdgpu_waves_per_eu(8, 8))) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
                                                                 const float *__restrict__ PQ,
                                                                 const float *__restrict__ bias,
@@ -312,20 +314,21 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                                                                 const float *__restrict__ Ccur, float *__restrict__ FE,
                                                                 int aux_cap, int fit, FoldArgs fa) {
     static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
+    static_assert(HLDS || (STAGE && !FOLD), "H stays in HBM only next to a staged (not folded) P/Q slice");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;      // one scalar load: meta row + minibatch offsets
     const int n = m[0], e = m[1];
-    // size classes (see launch_edge_fwd): fit > 0 -> only graphs whose staged slice needs <= fit bytes of LDS,
+    // size classes (see launch_edge_fwd): fit > 0 -> only graphs whose staged slice (with H) needs <= fit bytes of LDS,
     // fit < 0 -> only the larger ones
     if (fit != 0) {
-        const int64_t need = edge_lds_bytes(n, 2 * e, false, LAST, true);
+        const int64_t need = edge_lds_bytes(n, 2 * e, false, LAST, true, true);
         if (fit > 0 ? need > fit : need <= -fit) return;
     }
     const int64_t o = m[14], M = mb.M;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ca = 2 * (lane & 7), g = lane >> 3;      // this lane's two columns (ca, ca+1); node slot within the wave
-    const EdgeLds L = carve(smem, n, e, STAGE, false);
+    const EdgeLds L = carve(smem, n, e, STAGE, false, HLDS);
 
     const float *Pg = PQ + ((int64_t)(2 * p) * M + o) * 16;
     const float *Qg = PQ + ((int64_t)(2 * p + 1) * M + o) * 16;
@@ -377,18 +380,19 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         // unconditional loads from clamped (always valid) indices: no divergent control flow between the loads, so
         // they all issue back to back; out-of-range lanes simply do not commit
         const int c0 = in0 ? i0 : 0, c1 = in1 ? i1 : 0;
-        const float4 p0 = p4[c0], q0 = q4[c0], h0 = h4[c0], p1 = p4[c1], q1 = q4[c1], h1 = h4[c1];
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 p0 = p4[c0], q0 = q4[c0], h0 = HLDS ? h4[c0] : z4, p1 = p4[c1], q1 = q4[c1], h1 = HLDS ? h4[c1] : z4;
         const uint32_t nb0 = nbg[i0 < e ? i0 : 0], nb1 = nbg[i1 < e ? i1 : 0];
         const int rRp = rpg[tid <= n ? tid : 0];
         const uint32_t rOrd = og[tid < n ? tid : 0], rNm = nmg[tid < n ? tid : 0];
         float mx = 0.f;
         if (in0) {
             mx = put_pq_exp(L.PQ, i0, p0, q0);
-            reinterpret_cast<float4 *>(L.X)[i0] = h0;
+            if (HLDS) reinterpret_cast<float4 *>(L.X)[i0] = h0;
         }
         if (in1) {
             mx = fmaxf(mx, put_pq_exp(L.PQ, i1, p1, q1));
-            reinterpret_cast<float4 *>(L.X)[i1] = h1;
+            if (HLDS) reinterpret_cast<float4 *>(L.X)[i1] = h1;
         }
         if (i0 < e) reinterpret_cast<uint32_t *>(L.nb)[i0] = nb0;
         if (i1 < e) reinterpret_cast<uint32_t *>(L.nb)[i1] = nb1;
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         if (STAGE) {
             ok = stage_pq_exp(L.PQ, Pg, Qg, n, EF_LIMIT_FWD) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
             const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
-            for (int i = tid; i < n * 4; i += EDGE_THREADS) reinterpret_cast<float4 *>(L.X)[i] = h4[i];
+            for (int i = tid; HLDS && i < n * 4; i += EDGE_THREADS) reinterpret_cast<float4 *>(L.X)[i] = h4[i];
         }
         for (int i = tid; i <= n; i += EDGE_THREADS) L.rp[i] = rpg[i];
         for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
@@ -470,6 +474,9 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             int k = L.rp[v];
             const int k1 = valid ? L.rp[v + 1] : k;
             const float degf = (float)(k1 - k);
+            // H in HBM: the node's two columns are requested now and consumed after the incidence loop
+            float2 hpre = make_float2(0.f, 0.f);
+            if (STAGE && !HLDS) hpre = *reinterpret_cast<const float2 *>(Hg + v * 16 + ca);
             float acc0 = 0.f, acc1 = 0.f;          // sums over incidences of r1 + r2, per column
             for (; k < k1; ++k) {
                 const float4 nb = pq4(L.nb[k]);
@@ -480,14 +487,14 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                 const float S0 = degf - acc0, S1 = degf - acc1;     // 1/2 sum (tanh1 + tanh2) = 1/2 (2 deg - 2 acc)
                 const float inv = __builtin_amdgcn_rcpf(degf + 1e-6f);      // 1-ulp reciprocal instead of two IEEE divisions
                 float2 h;
-                if (STAGE) {
+                if (STAGE && HLDS) {
                     float2 *hx = reinterpret_cast<float2 *>(L.X + v * 16 + ca);
                     h = *hx;
                     h.x = fmaf(S0, inv, h.x);
                     h.y = fmaf(S1, inv, h.y);
                     *hx = h;
                 } else {
-                    h = *reinterpret_cast<const float2 *>(Hg + v * 16 + ca);
+                    h = STAGE ? hpre : *reinterpret_cast<const float2 *>(Hg + v * 16 + ca);
                     h.x = fmaf(S0, inv, h.x);
                     h.y = fmaf(S1, inv, h.y);
                     *reinterpret_cast<float2 *>(Ho + v * 16 + ca) = h;
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     };
     if (ef) walk(std::true_type{});
     else walk(std::false_type{});
-    if (STAGE) {
+    if (STAGE && HLDS) {
         __syncthreads();
         float4 *o4 = reinterpret_cast<float4 *>(Ho);
         for (int i = tid; i < n * 4; i += EDGE_THREADS) o4[i] = reinterpret_cast<const float4 *>(L.X)[i];
@@ -550,9 +557,12 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     }
 }
 
+static int g_fwd_h_hbm = 1;      // tune knob "fwd_h_hbm": the large size class of the forward keeps H in HBM (two workgroups per CU)
+void set_fwd_h_hbm(int on) { g_fwd_h_hbm = on ? 1 : 0; }
+
 bool edge_fold_ok(const MbView &mb) {
-    return edge_lds_bytes(mb.max_n, mb.max_inc, false, false, true) <= LDS_LIMIT &&
-           edge_lds_bytes(mb.max_n, mb.max_inc, true, false, true) <= LDS_LIMIT;
+    return edge_lds_bytes(mb.max_n, mb.max_inc, false, false, true, true) <= LDS_LIMIT &&
+           edge_lds_bytes(mb.max_n, mb.max_inc, true, false, true, true) <= LDS_LIMIT;
 }
 
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
@@ -565,18 +575,20 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     const int began = prof_begin(prof, "edge_fwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
     // one launch of a given (stage, lds, fit) configuration
-    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit) -> int {
-#define UPAMD_EF(L_, S_, F_)                                                                                          \
+    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool hlds = true) -> int {
+#define UPAMD_EF(L_, S_, F_, H_)                                                                                      \
     do {                                                                                                              \
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_>), lds)) return rc_;  \
-        hipLaunchKernelGGL((edge_fwd_kernel<L_, S_, F_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin,    \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_, H_>), lds)) return rc_;  \
+        hipLaunchKernelGGL((edge_fwd_kernel<L_, S_, F_, H_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, \
                            Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa);                                           \
     } while (0)
-        if (fold) UPAMD_EF(false, true, true);
-        else if (last && stage) UPAMD_EF(true, true, false);
-        else if (last) UPAMD_EF(true, false, false);
-        else if (stage) UPAMD_EF(false, true, false);
-        else UPAMD_EF(false, false, false);
+        if (fold) UPAMD_EF(false, true, true, true);
+        else if (last && stage && !hlds) UPAMD_EF(true, true, false, false);
+        else if (last && stage) UPAMD_EF(true, true, false, true);
+        else if (last) UPAMD_EF(true, false, false, true);
+        else if (stage && !hlds) UPAMD_EF(false, true, false, false);
+        else if (stage) UPAMD_EF(false, true, false, true);
+        else UPAMD_EF(false, false, false, true);
 #undef UPAMD_EF
         UPAMD_HIP(hipGetLastError());
         return 0;
@@ -594,11 +606,15 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
         rc = go(true, lds, aux_cap, 0);
     } else {
         // a few large graphs must not cost every workgroup its neighbour on the CU: the graphs that fit in half the
-        // LDS run in a two-per-CU launch, the rest in a second launch (staged with up to the whole LDS, or un-staged);
+        // LDS run in a two-per-CU launch, the rest in a second launch -- with H left in HBM if that keeps them at two
+        // workgroups per CU (DHM-sized graphs: ~350 .. ~530 nodes), else staged with up to the whole LDS, or un-staged;
         // a workgroup of the wrong class exits at once
         rc = go(true, LDS_HALF, 0, (int)LDS_HALF);
         if (rc == 0) {
-            if (lds_max <= LDS_LIMIT) {
+            const int64_t lds_noh = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, true, false);
+            if (!fold && g_fwd_h_hbm && lds_noh <= LDS_HALF) {
+                rc = go(true, lds_noh, 0, -(int)LDS_HALF, false);
+            } else if (lds_max <= LDS_LIMIT) {
                 rc = go(true, lds_max, 0, -(int)LDS_HALF);
             } else {
                 const int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, false);

@@ -100,7 +100,7 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
                         hipStream_t st, float *last_col_dst = nullptr);
 
 // ---- graph.hip -------------------------------------------------------------------------
-__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage);
+__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds = true);
 // First GCN layer folded into the message-passing stage-in (edge.hip: fold_fill): the workgroup computes its P/Q (and
 // H_0) slice from the raw node features.  Xp: panel-major [2][M][16]; W1c = Wcat_1 We [2D][32] (rows in P/Q panel
 // order), b1c [2D]; We (zero-padded) [D][32], be [D].
@@ -108,6 +108,7 @@ struct FoldArgs {
     const float *Xp, *W1c, *b1c, *We, *be;
 };
 bool edge_fold_ok(const MbView &mb);
+void set_fwd_h_hbm(int on);                // tune knob: large-graph size class of the forward with H left in HBM (default on)
 void set_side_stream(int on);              // tune knob "side_stream" (default on): per-sample chains + grouped weight gradients on an engine-owned side stream
 void set_fold_layer1(int on);              // tune knob: compute the first GCN layer inside the message-passing kernels       // every graph of the minibatch fits the staged (LDS-resident) size classes
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,

@@ -107,6 +107,19 @@ def test_baseline_graph_families_match_oracle_at_d256(family):
         assert n.min() < 240 and n.max() > 350
 
 
+def test_dhm_graphs_with_h_staged_in_lds_match_oracle():
+    """The large size class of the forward normally leaves H in HBM (two workgroups per CU for the > 350-node graphs);
+    tune knob fwd_h_hbm = 0 is the older path that stages H with the whole LDS (one workgroup per CU)."""
+    from drl_urban_planning_amd import native, synth
+    native.check(native.lib().upamd_tune(b'fwd_h_hbm', 0), 'upamd_tune')
+    try:
+        cfg, sd = _model()
+        pk = _full_comparison(cfg, sd, synth.make_replay(16, 'dhm', max_nodes=1000, max_edges=3000, seed=35))
+        assert pk.meta[:, 0].max() > 350
+    finally:
+        native.check(native.lib().upamd_tune(b'fwd_h_hbm', 1), 'upamd_tune')
+
+
 def test_b2048_minibatch_rows_match_oracle_on_a_subsample():
     """BASELINE cfg-2 at full size (2048 HLG-shaped graphs, D = 256, L = 3): 64 of its rows are compared with the
     oracle evaluated on those rows alone -- forward rows directly; the backward through seeds that are zero outside the
