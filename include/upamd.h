@@ -276,8 +276,15 @@ int64_t upamd_gemm_tn_scratch_floats(int32_t I, int32_t J, int64_t M);
 int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev, int32_t J, int64_t ldb, int64_t M,
                   int32_t row_major, float *scratch_dev, float *out_dev, void *stream);
 
-/* Kernel-lab knob (tools/gemm_lab.py, tests): selects a kernel configuration by name; no reference counterpart.
- *   "gemm_nt_dma": 0 = register-staged gemm_nt, k > 0 = LDS-DMA configuration k of the plain panel-major launches */
+/* Process-wide kernel-lab knobs (tools/gemm_lab.py, tests, bench.py's UPAMD_TUNE): select a kernel configuration by name; no
+ * reference counterpart.  Defaults in brackets; every setting computes the same results (the tests run both sides).
+ *   "gemm_nt_dma" [1]   0 = register-staged gemm_nt, k > 0 = LDS-DMA configuration k of the plain panel-major launches
+ *   "gemm_split"  [0]   6 | 9 = node GEMMs as fp32-equivalent split-bf16 products (see upamd_gemm_nt_split)
+ *   "fold_layer1" [1]   first GCN layer computed inside the message-passing kernels (H_0 / PQ_1 never in HBM)
+ *   "he_fused"    [1]   land-use head feature backward with its K = 32 product inside the kernel (no dFE tensor)
+ *   "side_stream" [1]   per-sample chains + grouped per-sample weight gradients on an engine-owned side stream
+ *   "fwd_h_hbm"   [1]   forward of graphs too big for two workgroups per CU keeps H in HBM instead of LDS
+ *   "gemm_lds_pad", "gemm_stagger_mode", "gemm_stagger_cycles": residency / first-round stagger of the LDS-DMA gemm_nt */
 int upamd_tune(const char *name, int32_t value);
 /* Lab hook: one wave writes `samples` pairs (shader-clock counter, 100 MHz wall-clock counter) into out_dev (int64[2 * samples]),
  * `gap_ticks` wall-clock ticks apart; launched on a side stream it measures the effective shader clock under load. */
