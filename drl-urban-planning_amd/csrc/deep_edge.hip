@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void inc_scatter_fwd_kernel(PackedView pk, MbV
                                                               const int32_t *__restrict__ cand_inc,
                                                               const float *__restrict__ Hin, float *__restrict__ Hout,
                                                               float *__restrict__ hbarV, float *__restrict__ hbarE,
-                                                              const float *__restrict__ Ccur, float *__restrict__ FE) {
+                                                              const float *__restrict__ Ccur, float *__restrict__ FE, int fe_full) {
     __shared__ float part[256];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP, t = mb.idx[b];
     const int32_t *m = META(t);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void inc_scatter_fwd_kernel(PackedView pk, MbV
             const int ci = cand_inc[q0 + q];
             const float mm = ci >= 0 ? 0.5f * (Ap[(int64_t)ci * 16] + Ap[(int64_t)grev[ci] * 16]) : 0.f;
             FE[((int64_t)p * NH + q0 + q) * 16 + c] = mm;
-            FE[((int64_t)(NP + p) * NH + q0 + q) * 16 + c] = mm * cc;
+            if (fe_full) FE[((int64_t)(NP + p) * NH + q0 + q) * 16 + c] = mm * cc;
         }
     }
 }
@@ -289,14 +289,14 @@ int launch_inc_gather_fwd(const MbView &mb, int D, const float *PQ, const float 
 
 int launch_inc_scatter_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *AK, const int32_t *grev,
                            const int32_t *cand_inc, const float *Hin, float *Hout, float *hbarV, float *hbarE,
-                           const float *Ccur, float *FE, hipStream_t st) {
+                           const float *Ccur, float *FE, hipStream_t st, int fe_full) {
     const int NP = D / 16;
     if (last)
         hipLaunchKernelGGL(inc_scatter_fwd_kernel<true>, dim3(mb.B * NP), dim3(256), 0, st, pk, mb, NP, AK, grev, cand_inc, Hin, Hout,
-                           hbarV, hbarE, Ccur, FE);
+                           hbarV, hbarE, Ccur, FE, fe_full);
     else
         hipLaunchKernelGGL(inc_scatter_fwd_kernel<false>, dim3(mb.B * NP), dim3(256), 0, st, pk, mb, NP, AK, grev, cand_inc, Hin, Hout,
-                           hbarV, hbarE, Ccur, FE);
+                           hbarV, hbarE, Ccur, FE, fe_full);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                                                                 const float *__restrict__ Hin, float *__restrict__ Hout,
                                                                 float *__restrict__ hbarV, float *__restrict__ hbarE,
                                                                 const float *__restrict__ Ccur, float *__restrict__ FE,
-                                                                int aux_cap, int fit, FoldArgs fa) {
+                                                                int aux_cap, int fit, FoldArgs fa, int fe_full) {
     static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
     static_assert(HLDS || (STAGE && !FOLD), "H stays in HBM only next to a staged (not folded) P/Q slice");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -523,7 +523,8 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                 }
                 const int64_t row = q0 + q;
                 *reinterpret_cast<float2 *>(FE + ((int64_t)p * NH + row) * 16 + ca) = mm;
-                *reinterpret_cast<float2 *>(FE + ((int64_t)(NP + p) * NH + row) * 16 + ca) = make_float2(mm.x * cc.x, mm.y * cc.y);
+                if (fe_full)       // (the m*c half is only materialised for head shapes head.hip does not cover)
+                    *reinterpret_cast<float2 *>(FE + ((int64_t)(NP + p) * NH + row) * 16 + ca) = make_float2(mm.x * cc.x, mm.y * cc.y);
             }
         }
     };
@@ -567,7 +568,7 @@ bool edge_fold_ok(const MbView &mb) {
 
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
-                    hipStream_t st, Profiler *prof, const FoldArgs *fold) {
+                    hipStream_t st, Profiler *prof, const FoldArgs *fold, int fe_full) {
     const int NP = D / 16;
     const FoldArgs fa = fold ? *fold : FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (fold && (last || !edge_fold_ok(mb)))
@@ -580,7 +581,7 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     do {                                                                                                              \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_, H_>), lds)) return rc_;  \
         hipLaunchKernelGGL((edge_fwd_kernel<L_, S_, F_, H_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, \
-                           Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa);                                           \
+                           Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa, fe_full);                                  \
     } while (0)
         if (fold) UPAMD_EF(false, true, true, true);
         else if (last && stage && !hlds) UPAMD_EF(true, true, false, false);

@@ -181,7 +181,7 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     for (int l = 2; l <= x.L; ++l) add(S_SLAB_W + l, slab_floats(2 * D, D, M));
     add(S_SLAB_XP1, slab_floats(2 * D, 32, M));
     add(S_SLAB_XP2, slab_floats(D, 32, M));
-    add(S_SLAB_FE, slab_floats(2 * D, x.h0l, NH));
+    add(S_SLAB_FE, std::max(slab_floats(2 * D, x.h0l, NH), (int64_t)head_wgrad_groups((int)B) * 2 * D * x.h0l));
     add(S_SLAB_XR, slab_floats(D, x.h0r, NR));
     // per-sample weight gradients (grouped dY^T X): <= 16 row splits of every per-sample weight (+ the collapsed ones)
     pl->small_slab_floats = 16LL * (P.n_floats + 4LL * D * D + 2LL * D * x.h0l + 4096);
@@ -528,6 +528,9 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
     const float *biq = bin, *biv = bin + 2 * D;
     const bool land = mb.Nhe > 0, road = mb.Nrn > 0;
+    // head.hip: the land-use head's first Linear works on the m half of FE alone (the m*c half is then never written)
+    const bool fe_half = head_fe_half_ok(D, x.h0l);
+    const int fe_full = fe_half ? 0 : 1;
 
     if (x.mlp) {
         // ===== rl-mlp encoder (MLPStateEncoder, state_encoder.py:217-308): node encoder only, pooled means, no attention
@@ -565,7 +568,7 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         }
         mb.rows = reinterpret_cast<const int32_t *>(W(S_ROWS));
         CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_WE_PAD), D, PR(P.node_b), nullptr, W(S_H + 0), 0, st, prof));
-        CK(launch_mlp_pool_fwd(pk, mb, D, W(S_H + 0), PR(P.node_b), W(S_C), W(S_HBARV), land ? W(S_FE) : nullptr, st));
+        CK(launch_mlp_pool_fwd(pk, mb, D, W(S_H + 0), PR(P.node_b), W(S_C), W(S_HBARV), land ? W(S_FE) : nullptr, st, fe_full));
         {
             ChainFwdPost a;
             memset(&a, 0, sizeof(a));
@@ -688,12 +691,12 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
                 CK(launch_gemm_nt(W(S_EA + LK(l, k)), mb.NI, D, PR(P.edge_wk[l - 1][k - 1]), D, PR(P.edge_bk[l - 1][k - 1]), nullptr,
                                   W(S_EA + LK(l, k + 1)), 1, st, prof));
             CK(launch_inc_scatter_fwd(pk, mb, D, l == x.L, W(S_EA + LK(l, x.K)), grev, cand_inc, W(S_H + l - 1), W(S_H + l), W(S_HBARV),
-                                      W(S_HBARE), W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st));
+                                      W(S_HBARE), W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, fe_full));
             continue;
         }
         // the last layer also writes the land-use pointer-head inputs FE (needs C, computed above)
         CK(launch_edge_fwd(pk, mb, D, l == x.L, W(S_PQ + l), PR(P.edge_b[l - 1]), W(S_H + l - 1), W(S_H + l), W(S_HBARV), W(S_HBARE),
-                           W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, prof, (l == 1 && fold) ? &fa : nullptr));
+                           W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, prof, (l == 1 && fold) ? &fa : nullptr, fe_full));
     }
     // ---- 5. attention core, then the per-sample chain after it (out-projection, state_value, value head)
     CK(launch_attn_fwd(pk, mb, D, x.heads, W(S_H + x.L), W(S_R), W(S_ALPHA), W(S_S), st));
@@ -715,8 +718,13 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     if (land) {
         // factorised first Linear: hid = tanh(FE [Wa+Wd | Wc]^T + ((Wb-Wd) c_b + b1)), the bias rows are
         // pre-written into hid and accumulated in place
-        CK(launch_he_bias_rows(pk, mb, x.h0l, W(S_CONSTB), W(S_HIDL), st));
-        CK(launch_gemm_nt(W(S_FE), mb.Nhe, 2 * D, W(S_W1F), x.h0l, nullptr, W(S_HIDL), W(S_HIDL), 1, st, prof));
+        if (fe_half) {
+            // per-graph effective weight W_b = (Wa + Wd) + Wc diag(c_b) in LDS, hid = tanh(W_b m + constb) in one kernel
+            CK(launch_head_hidden_fwd(pk, mb, D, W(S_FE), W(S_C), W(S_W1F), W(S_CONSTB), W(S_HIDL), st));
+        } else {
+            CK(launch_he_bias_rows(pk, mb, x.h0l, W(S_CONSTB), W(S_HIDL), st));
+            CK(launch_gemm_nt(W(S_FE), mb.Nhe, 2 * D, W(S_W1F), x.h0l, nullptr, W(S_HIDL), W(S_HIDL), 1, st, prof));
+        }
     }
     if (road) {
         CK(launch_road_gather(pk, mb, D, HL, W(S_XR), st));
@@ -756,6 +764,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     float *gWin = x.mlp ? grads : GR(P.inproj_w), *gbin = x.mlp ? grads : GR(P.inproj_b);
     const float *HL = W(S_H + x.L);
     const bool land = mb.Nhe > 0, road = mb.Nrn > 0;
+    const bool fe_half = head_fe_half_ok(D, x.h0l);      // the forward's decision (same process-wide knob)
     const ChainDims cd = chain_dims(d, x, B);
     Reducer red1, red2;             // reduction #1: everything independent; #2: what must follow the collapsed-product gradients
     // the step's ONE grouped dY^T X launch (per-sample weight gradients, and the node-level products of small models);
@@ -799,9 +808,15 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             // dw2 = sum_rows (sum_k dz hid), db1 = sum_rows dconst: the row sums come out of pointer_bwd2
             CK(red1.add(W(S_CSP0), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
             CK(red1.add(W(S_DCONST), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
-            CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
-                return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
-            }));
+            if (fe_half) {
+                int Sn = 1;
+                CK(launch_head_wgrad(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_SLAB_FE), &Sn, st));
+                CK(red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+            } else {
+                CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
+                    return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
+                }));
+            }
             // a candidate that is not a live edge has the bias as its embedding: its gradient is kept (-> dbe)
             if (he_feat_bwd_fused_ok(D, x.h0l)) {
                 CK(launch_he_feat_bwd_fused(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_W1FT), W(S_DMHE), W(S_DC_HEAD), st, 1));
@@ -909,9 +924,16 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(red1.add(W(S_CSP0), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
         CK(red1.add(W(S_DCONST), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
         // dW1f = dpre^T FE (mapped back onto [Wa|Wb|Wc|Wd] after the reduction, together with dWbd = dconst^T C)
-        CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
-            return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
-        }));
+        // (with FE = m only: per-graph products, the c part weighted by c_b inside the kernel -- head.hip)
+        if (fe_half) {
+            int Sn = 1;
+            CK(launch_head_wgrad(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_SLAB_FE), &Sn, st));
+            CK(red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+        } else {
+            CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
+                return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
+            }));
+        }
         // dFE = dpre W1f, then the feature backward (dMhe for the last GCN layer, dC from the m*c term); with the shipped
         // head width (h0 = 32) one kernel does both and dFE never exists in HBM
         if (he_feat_bwd_fused_ok(D, x.h0l)) {

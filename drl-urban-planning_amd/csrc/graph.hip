@@ -644,7 +644,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mlp_pool_fwd_kernel(PackedView pk, MbView mb, int NP, const float *__restrict__ H0,
                                                            const float *__restrict__ be, const float *__restrict__ C,
-                                                           float *__restrict__ hbarV, float *__restrict__ FE) {
+                                                           float *__restrict__ hbarV, float *__restrict__ FE, int fe_full) {
     __shared__ float part[256];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;
@@ -669,14 +669,14 @@ __global__ __launch_bounds__(256) void mlp_pool_fwd_kernel(PackedView pk, MbView
         for (int q = slot; q < nh; q += 16) {
             const float mm = pk.he_live[m[11] + q] ? Hg[(int64_t)pk.he_sel[m[11] + q] * 16 + c] : bias;
             FE[((int64_t)p * NH + q0 + q) * 16 + c] = mm;
-            FE[((int64_t)(NP + p) * NH + q0 + q) * 16 + c] = mm * cc;
+            if (fe_full) FE[((int64_t)(NP + p) * NH + q0 + q) * 16 + c] = mm * cc;
         }
     }
 }
 
 int launch_mlp_pool_fwd(const PackedView &pk, const MbView &mb, int D, const float *H0, const float *be, const float *C,
-                        float *hbarV, float *FE, hipStream_t st) {
-    hipLaunchKernelGGL(mlp_pool_fwd_kernel, dim3(mb.B * (D / 16)), dim3(256), 0, st, pk, mb, D / 16, H0, be, C, hbarV, FE);
+                        float *hbarV, float *FE, hipStream_t st, int fe_full) {
+    hipLaunchKernelGGL(mlp_pool_fwd_kernel, dim3(mb.B * (D / 16)), dim3(256), 0, st, pk, mb, D / 16, H0, be, C, hbarV, FE, fe_full);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }

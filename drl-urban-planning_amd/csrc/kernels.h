@@ -113,7 +113,7 @@ void set_side_stream(int on);              // tune knob "side_stream" (default o
 void set_fold_layer1(int on);              // tune knob: compute the first GCN layer inside the message-passing kernels       // every graph of the minibatch fits the staged (LDS-resident) size classes
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
-                    hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr);
+                    hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, int fe_full = 1);
 int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
                     float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr);
@@ -129,9 +129,19 @@ bool he_feat_bwd_fused_ok(int D, int h0);
 void set_he_feat_fused(int on);            // tune knob "he_fused" (default on)
 int launch_he_feat_bwd_fused(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C, const float *dprel,
                              const float *W1fT, float *dMhe, float *dC_head, hipStream_t st, int keep_dead = 0);
+// ---- head.hip: the land-use head's first Linear on the candidate messages m alone (FE keeps only its m half: the m*c half
+// is a per-graph change of the weight).  fe_half_ok: h0 == 32, D % 32 == 0, D <= 256 (tune knob "fe_half", default on)
+bool head_fe_half_ok(int D, int h0);
+void set_fe_half(int on);
+int head_wgrad_groups(int B);
+int launch_head_hidden_fwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C, const float *W1f,
+                           const float *constb, float *hid, hipStream_t st);
+// slab[G][2D][32]: per-workgroup shares of dpre^T m (rows 0 .. D-1) and of its c_b-weighted version (rows D .. 2D-1)
+int launch_head_wgrad(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C, const float *dprel,
+                      float *slab, int *S_out, hipStream_t st);
 // rl-mlp encoder (state_encoder.py:284-308): masked node mean of H^0 and the land-use head inputs gathered from H^0 rows
 int launch_mlp_pool_fwd(const PackedView &pk, const MbView &mb, int D, const float *H0, const float *be, const float *C,
-                        float *hbarV, float *FE, hipStream_t st);
+                        float *hbarV, float *FE, hipStream_t st, int fe_full = 1);
 // ... and its backward: G^0 = dhbarV / n_mask on masked nodes + the candidates' dM routed to their selected endpoint;
 // candidates that are not live edges (m == bias) contribute to dbe_extra[b][D]
 int launch_mlp_pool_bwd(const PackedView &pk, const MbView &mb, int D, const float *dhbarV, int ld, const float *dMhe, float *G0,
@@ -148,7 +158,7 @@ int launch_inc_gather_fwd(const MbView &mb, int D, const float *PQ, const float 
                           float *A1, hipStream_t st);
 int launch_inc_scatter_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *AK, const int32_t *grev,
                            const int32_t *cand_inc, const float *Hin, float *Hout, float *hbarV, float *hbarE,
-                           const float *Ccur, float *FE, hipStream_t st);
+                           const float *Ccur, float *FE, hipStream_t st, int fe_full = 1);
 int launch_inc_seed_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *AK, const float *G,
                         const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dpre, float *dbpart, hipStream_t st);
 int launch_inc_tanh_bwd(const PackedView &pk, const MbView &mb, int D, const float *A, float *dA, float *dbpart, hipStream_t st);

@@ -68,7 +68,7 @@ def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
 def tune():
     """set native tune knobs for one test; every knob is put back to its default afterwards"""
     from drl_urban_planning_amd import native
-    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1}
+    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1}
     touched = []
 
     def _set(name, value):
@@ -371,6 +371,16 @@ def test_forked_step_is_bit_identical_to_the_single_stream_step(D, L, heads, n_r
         out = run()
         for a, b in zip(ref, out):
             assert torch.equal(a, b), 'repetition %d differs from the single-stream step' % rep
+
+
+def test_wide_model_with_full_head_input_tensor_matches_oracle(tune):
+    """fe_half = 0: the land-use head's input tensor FE = [m ; m*c] is materialised in full and its first Linear / weight
+    gradient run as plain GEMMs (the path of head shapes head.hip does not cover) instead of the default m-only form with
+    per-graph effective weights."""
+    tune('fe_half', 0)
+    cfg, sd, replay = _random_case(128, 2, 4, (64, 16), (32, 1), (32, 1), (32, 32, 1), 6, 95, int(5.55 * 90) + 10, seed=21,
+                                   road_fraction=0.3, n_range=(40, 90))
+    _check_against_oracle(cfg, sd, replay, 4, 6)
 
 
 def test_wide_model_with_unfused_head_backward_matches_oracle(tune):
