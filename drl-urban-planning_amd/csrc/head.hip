@@ -39,9 +39,28 @@ __global__ __launch_bounds__(256) void head_hidden_fwd_kernel(PackedView pk, MbV
     const int nh = META(t)[2];
     if (nh == 0) return;
     const int64_t q0 = mb.he_off[b], NH = mb.Nhe;
-    for (int i = threadIdx.x; i < 32 * D; i += 256) {
-        const int k = i / D, d = i % D;
-        wb[k * LDW + d] = fmaf(W1f[(int64_t)k * 2 * D + D + d], C[(int64_t)b * D + d], W1f[(int64_t)k * 2 * D + d]);
+    // W_b: 32 D elements over 256 threads, eight elements' loads in flight per thread (one at a time made this prologue the
+    // longest part of the kernel: ~30 dependent L2 round trips per workgroup)
+    constexpr int PER = 32 * D / 256;
+#pragma unroll
+    for (int i0 = 0; i0 < PER; i0 += 8) {
+        float wa[8], wc[8], cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < PER) {
+                const int i = (i0 + u) * 256 + threadIdx.x, k = i / D, d = i % D;
+                wa[u] = W1f[(int64_t)k * 2 * D + d];
+                wc[u] = W1f[(int64_t)k * 2 * D + D + d];
+                cv[u] = C[(int64_t)b * D + d];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < PER) {
+                const int i = (i0 + u) * 256 + threadIdx.x, k = i / D, d = i % D;
+                wb[k * LDW + d] = fmaf(wc[u], cv[u], wa[u]);
+            }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
@@ -67,6 +86,9 @@ __global__ __launch_bounds__(256) void head_hidden_fwd_kernel(PackedView pk, MbV
                     x[p][1] = src[1];
                 }
             }
+            // keep the eight loads together: left alone, the scheduler sinks each one next to its four MFMAs (shorter live
+            // ranges next to the 128 hoisted weight registers) and a tile becomes 32 serial memory round trips
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 if (pc + p < NP) {
@@ -97,7 +119,7 @@ __global__ __launch_bounds__(256) void head_hidden_fwd_kernel(PackedView pk, MbV
 // share of  sum_rows dpre[row][k] m[row][d]  and of its per-graph c_b[d]-weighted version.  Workgroup wg takes the graphs
 // wg, wg + G, ... in that order (fixed assignment: bit-reproducible); wave w owns the 32-column tiles w and w + 4 of d.
 // MFMA over the graph's candidates (two per step): A = dpre^T (register dimension = hidden unit k), B = m (lane dimension = the
-// tile's column), both read as 4-byte elements of 64-byte row segments, sixteen steps of loads in flight.
+// tile's column), both read as 4-byte elements of 64-byte row segments, eight steps (16 candidates) of loads in flight.
 template <int TPW>      // column tiles per wave: D / 32 / 4 rounded up (1 or 2)
 __global__ __launch_bounds__(256) void head_wgrad_kernel(PackedView pk, MbView mb, int NP, int G, const float *__restrict__ FE,
                                                          const float *__restrict__ C, const float *__restrict__ dprel,
@@ -121,10 +143,11 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(PackedView pk, MbView m
         for (int j = 0; j < TPW; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) tg[j][i] = 0.f;
-        for (int s0 = 0; s0 < nh; s0 += 16) {                   // 8 MFMA steps = 16 candidates per trip
-            float av[8], bv[TPW][8];
+        constexpr int ST = 8;                                   // MFMA steps (= 2 ST candidates) per trip: all its loads in flight at once (16: no faster, one wave per SIMD less)
+        for (int s0 = 0; s0 < nh; s0 += 2 * ST) {
+            float av[ST], bv[TPW][ST];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < ST; ++u) {
                 const int cand = s0 + 2 * u + kh;
                 const int64_t row = q0 + min(cand, nh - 1);     // clamped: loads stay unconditional, masked below
                 av[u] = dprel[aoff + row * 16];
@@ -135,8 +158,9 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(PackedView pk, MbView m
                 }
                 if (cand >= nh) av[u] = 0.f;
             }
+            __builtin_amdgcn_sched_barrier(0);      // every load of the trip in flight before its first MFMA (see head_hidden_fwd_kernel)
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < ST; ++u)
 #pragma unroll
                 for (int j = 0; j < TPW; ++j) tg[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[j][u], tg[j], 0, 0, 0);
         }
@@ -171,7 +195,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(PackedView pk, MbView m
 static int g_fe_half = 1;
 void set_fe_half(int on) { g_fe_half = on ? 1 : 0; }
 bool head_fe_half_ok(int D, int h0) { return g_fe_half && h0 == 32 && D % 32 == 0 && D <= 256; }
-int head_wgrad_groups(int B) { return B < 512 ? B : 512; }
+int head_wgrad_groups(int B) { return B < 768 ? B : 768; }      // three resident workgroups per CU
 
 int launch_head_hidden_fwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C, const float *W1f,
                            const float *constb, float *hid, hipStream_t st) {
