@@ -284,6 +284,7 @@ int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev
  *   "he_fused"    [1]   land-use head feature backward with its K = 32 product inside the kernel (no dFE tensor)
  *   "side_stream" [1]   per-sample chains + grouped per-sample weight gradients on an engine-owned side stream
  *   "fwd_h_hbm"   [1]   forward of graphs too big for two workgroups per CU keeps H in HBM instead of LDS
+ *   "fe_half"     [1]   land-use head's first Linear on the candidate messages m alone (no m*c tensor; hidden = 32, D % 32 == 0, D <= 256)
  *   "gemm_lds_pad", "gemm_stagger_mode", "gemm_stagger_cycles": residency / first-round stagger of the LDS-DMA gemm_nt */
 int upamd_tune(const char *name, int32_t value);
 /* Lab hook: one wave writes `samples` pairs (shader-clock counter, 100 MHz wall-clock counter) into out_dev (int64[2 * samples]),
