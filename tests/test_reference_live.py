@@ -56,23 +56,28 @@ def test_oracle_update_matches_the_live_reference_on_a_fresh_replay():
 
 
 def test_oracle_step_time_is_the_reference_step_time():
-    """min-of-3 wall time of a whole update_params (6 optimizer steps of 32 padded rows + the two no-grad sweeps),
-    interleaved reference / oracle so that machine noise hits both alike."""
+    """min-of-N wall time of a whole update_params (6 optimizer steps of 32 padded rows + the two no-grad sweeps),
+    interleaved reference / oracle so that machine noise hits both alike.  A shared build box is noisy (other jobs, the
+    thread pool right after a compile): the pair is re-measured, with more rounds, before a ratio outside 10 % counts."""
     torch.set_num_threads(min(4, torch.get_num_threads()))
     replay = _replay()
     t_ref, t_orc = [], []
-    for rep in range(4):
-        ag, ou = _pair()
-        np.random.seed(5)
-        t0 = time.perf_counter()
-        ag.update_params(replay, 0)
-        t1 = time.perf_counter()
-        np.random.seed(5)
-        ou.update_params(replay)
-        t2 = time.perf_counter()
-        if rep:                               # the first round warms allocators / thread pools
-            t_ref.append(t1 - t0)
-            t_orc.append(t2 - t1)
-    ratio = min(t_orc) / min(t_ref)
+    ratio = None
+    for attempt in range(3):
+        for rep in range(4 + 2 * attempt):
+            ag, ou = _pair()
+            np.random.seed(5)
+            t0 = time.perf_counter()
+            ag.update_params(replay, 0)
+            t1 = time.perf_counter()
+            np.random.seed(5)
+            ou.update_params(replay)
+            t2 = time.perf_counter()
+            if rep or attempt:                    # the very first round warms allocators / thread pools
+                t_ref.append(t1 - t0)
+                t_orc.append(t2 - t1)
+        ratio = min(t_orc) / min(t_ref)           # minima over everything measured so far
+        if 0.90 <= ratio <= 1.10:
+            break
     assert 0.90 <= ratio <= 1.10, 'oracle %.3f s vs reference %.3f s per update_params (ratio %.3f)' % (
         min(t_orc), min(t_ref), ratio)
