@@ -143,26 +143,39 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(PackedView pk, MbView m
         for (int j = 0; j < TPW; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) tg[j][i] = 0.f;
-        constexpr int ST = 8;                                   // MFMA steps (= 2 ST candidates) per trip: all its loads in flight at once (16: no faster, one wave per SIMD less)
-        for (int s0 = 0; s0 < nh; s0 += 2 * ST) {
-            float av[ST], bv[TPW][ST];
+        constexpr int ST = 8;                                   // MFMA steps (= 2 ST candidates) per trip
+        // operands of one trip, requested a whole trip ahead and unconditionally (clamped rows; the last trip re-fetches
+        // itself): with a branch around the prefetch the compiler waits for every outstanding load at the join
+        auto fetch = [&](int s0, float (&av)[ST], float (&bv)[TPW][ST]) {
 #pragma unroll
             for (int u = 0; u < ST; ++u) {
-                const int cand = s0 + 2 * u + kh;
-                const int64_t row = q0 + min(cand, nh - 1);     // clamped: loads stay unconditional, masked below
+                const int64_t row = q0 + min(s0 + 2 * u + kh, nh - 1);
                 av[u] = dprel[aoff + row * 16];
 #pragma unroll
                 for (int j = 0; j < TPW; ++j) {
-                    const int tile = w + 4 * j;
-                    bv[j][u] = tile < tiles ? FE[((int64_t)(2 * tile + (r >> 4)) * NH + row) * 16 + (r & 15)] : 0.f;
+                    const int tile = min(w + 4 * j, tiles - 1);      // (a wave without a j-th tile redoes its last one; never written out)
+                    bv[j][u] = FE[((int64_t)(2 * tile + (r >> 4)) * NH + row) * 16 + (r & 15)];
                 }
-                if (cand >= nh) av[u] = 0.f;
             }
-            __builtin_amdgcn_sched_barrier(0);      // every load of the trip in flight before its first MFMA (see head_hidden_fwd_kernel)
+        };
+        float av[ST], bv[TPW][ST];
+        fetch(0, av, bv);
+        for (int s0 = 0; s0 < nh; s0 += 2 * ST) {
+            float an[ST], bn[TPW][ST];
+            fetch(s0 + 2 * ST < nh ? s0 + 2 * ST : s0, an, bn);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < ST; ++u)
+            for (int u = 0; u < ST; ++u) {
+                const float a = (s0 + 2 * u + kh < nh) ? av[u] : 0.f;      // candidates past the end contribute nothing
 #pragma unroll
-                for (int j = 0; j < TPW; ++j) tg[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[j][u], tg[j], 0, 0, 0);
+                for (int j = 0; j < TPW; ++j) tg[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j][u], tg[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < ST; ++u) {
+                av[u] = an[u];
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) bv[j][u] = bn[j][u];
+            }
         }
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
