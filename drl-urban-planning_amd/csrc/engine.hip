@@ -280,6 +280,16 @@ static int join_side(upamd_engine *eng, hipStream_t st) {
     return 0;
 }
 
+// An error return between fork and join must not leave side-stream work running on a workspace the caller may free next:
+// the guard drains the side stream unless the join was reached
+struct SideGuard {
+    upamd_engine *eng;
+    bool armed = false;
+    ~SideGuard() {
+        if (armed && eng->side) (void)hipStreamSynchronize(eng->side);
+    }
+};
+
 // UPAMD_DEBUG_SYNC=1: synchronise after every launch and name the one that faulted (debugging aid; off by default)
 static const bool g_debug_sync = getenv("UPAMD_DEBUG_SYNC") && atoi(getenv("UPAMD_DEBUG_SYNC")) != 0;
 static int debug_sync(const char *what) {
@@ -623,6 +633,7 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     const ChainDims cd = chain_dims(d, x, B);
     // (launch-bound small models gain nothing from the fork: its two event round trips cost more than they hide)
     const bool forked = g_side_stream != 0 && !defer_node_tn(x.D);
+    SideGuard side_guard{eng};
     if (forked) CK(side_ready(eng));
     {
         ChainFwdPre a;
@@ -641,6 +652,7 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
             a.part = CHAIN_GATHER;
             CK(launch_chain_fwd_pre(a, st));
             CK(fork_side(eng, st));
+            side_guard.armed = true;
             a.part = CHAIN_LAYERS;
             CK(launch_chain_fwd_pre(a, eng->side));
         } else {
@@ -683,7 +695,10 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         } else {
             CK(launch_gemm_nt(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), 2 * D, nullptr, nullptr, W(S_PQ + l), 0, st, prof));
         }
-        if (forked && l == x.L) CK(join_side(eng, st));      // C (head inputs of the last layer), r, U, constb are ready
+        if (forked && l == x.L) {                            // C (head inputs of the last layer), r, U, constb are ready
+            CK(join_side(eng, st));
+            side_guard.armed = false;
+        }
         if (x.K > 1) {
             // A_1 = tanh(P_src + Q_dst + b_0) per edge direction, A_k+1 = tanh(A_k W_k^T + b_k), then the node segment sum
             CK(launch_inc_gather_fwd(mb, D, W(S_PQ + l), PR(P.edge_b[l - 1]), gsrc, gdst, W(S_EA + LK(l, 1)), st));
@@ -1006,9 +1021,11 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     };
     // ---- 4. per-sample chain, the part before the graph: dr -> dq1 -> dq0 -> dC (+ the land-use head's two dC terms)
     const bool forked = g_side_stream != 0 && !defer;
+    SideGuard side_guard{eng};
     if (forked) {
         CK(side_ready(eng));
         CK(fork_side(eng, st));
+        side_guard.armed = true;
     }
     {
         ChainBwdPre a;
@@ -1071,8 +1088,12 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         return red1.add(W(S_SLAB_XP2), Sn, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b));
     }));
     // ---- 7. (not forked: the grouped launch here) then its slab reductions, and the deferred node-level ones
-    if (forked) CK(join_side(eng, st));
-    else CK(grouped_launch(st));
+    if (forked) {
+        CK(join_side(eng, st));
+        side_guard.armed = false;
+    } else {
+        CK(grouped_launch(st));
+    }
     for (const Pending &q : pending) CK(q.rd->add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
     for (auto &f : after_gtn) CK(f());
     // ---- 8. reduction #1: every split-K slab / partial sum of the step, fixed order
