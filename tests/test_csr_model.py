@@ -32,3 +32,27 @@ def test_csr_forward_backward_vs_oracle(name):
     for k, g in G.items():
         ref_key = 'grad/actor_net.' + k if not k.startswith('value_head.') else 'grad/value_net.' + k
         np.testing.assert_allclose(g, z[ref_key], rtol=2e-4, atol=2e-6 * max(scale, 1.0), err_msg=k)
+
+
+def test_land_use_head_first_linear_on_the_messages_alone():
+    """csrc/head.hip: with c a per-GRAPH vector the m*c half of the head input [m ; m*c] is a per-graph change of the weight,
+    W_b = Wa' + Wc diag(c_b); the weight gradient splits into sum dpre^T m and its per-graph c_b-weighted version.  Both
+    identities against the explicit [m ; m*c] form (float64)."""
+    rng = np.random.default_rng(0)
+    D, h0 = 12, 5
+    sizes = [7, 0, 4, 9]                                 # candidates per graph (one graph without any)
+    W = rng.standard_normal((h0, 2 * D))                # [Wa' | Wc]
+    C = rng.standard_normal((len(sizes), D))
+    const = rng.standard_normal((len(sizes), h0))
+    m = [rng.standard_normal((k, D)) for k in sizes]
+    dpre = [rng.standard_normal((k, h0)) for k in sizes]
+    hid_ref = [np.tanh(np.concatenate([mb, mb * C[b]], 1) @ W.T + const[b]) for b, mb in enumerate(m)]
+    dW_ref = sum(dp.T @ np.concatenate([mb, mb * C[b]], 1) for b, (mb, dp) in enumerate(zip(m, dpre)))
+    dWa, dWc = np.zeros((h0, D)), np.zeros((h0, D))
+    for b, (mb, dp) in enumerate(zip(m, dpre)):
+        Wb = W[:, :D] + W[:, D:] * C[b]                 # head_hidden_fwd: built once per graph
+        np.testing.assert_allclose(np.tanh(mb @ Wb.T + const[b]), hid_ref[b], rtol=1e-12, atol=1e-12)
+        T = dp.T @ mb                                   # head_wgrad: per-graph product, accumulated plain and c-weighted
+        dWa += T
+        dWc += T * C[b]
+    np.testing.assert_allclose(np.concatenate([dWa, dWc], 1), dW_ref, rtol=1e-12, atol=1e-12)
