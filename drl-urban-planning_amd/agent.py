@@ -24,11 +24,14 @@ Data parallelism (the reference has none): see ``dist.py``
 the reference's meaning in ``dp_mode='global'`` -- the GLOBAL minibatch, of which every rank processes
 ``mini_batch_size / world`` rows -- and is the per-rank minibatch in ``dp_mode='local'``.
 
-``zero_grad`` semantics: the goldens (and this implementation) follow torch >= 2.0, where ``zero_grad()`` sets the
-gradients of a head that saw no row to ``None`` and Adam skips that head.  The reference pins torch <= 1.13, whose
-``zero_grad()`` zero-fills: there, a head without rows still takes an Adam step with g = 0 once it has had a
-gradient (step count + moment decay + a momentum move).  ``legacy_zero_grad=True`` reproduces that.
+``zero_grad`` semantics: under torch >= 2.0 ``zero_grad()`` sets the gradients of a head that saw no row to ``None``
+and Adam skips that head.  The reference pins torch <= 1.13 (requirements.txt:3), whose ``zero_grad()`` zero-fills:
+there, a head without rows still takes an Adam step with g = 0 once it has had a gradient (step count + moment
+decay + a momentum move).  ``legacy_zero_grad=True`` reproduces the pinned behaviour, ``False`` the newer one, and the
+default ``None`` follows the torch that is INSTALLED -- i.e. what the reference's own ``self.optimizer.zero_grad()``
+would do in this process (both are pinned by goldens generated with the real reference: tests/golden/case_s.npz).
 """
+import inspect
 import math
 import os
 import time
@@ -37,8 +40,17 @@ import numpy as np
 import torch
 
 from . import packer
-from .dist import DistContext, batch_fingerprint, global_counts, order_fingerprint, split_minibatch
+from .dist import DistContext, batch_fingerprint, global_counts, order_fingerprint, split_minibatch, states_fingerprint
 from .models import backend_of
+
+
+def torch_zero_grad_zero_fills():
+    """True when the installed torch's ``Optimizer.zero_grad()`` zero-fills gradients (torch < 2.0) instead of setting
+    them to None."""
+    try:
+        return inspect.signature(torch.optim.Optimizer.zero_grad).parameters['set_to_none'].default is False
+    except (KeyError, ValueError, TypeError):
+        return False
 
 
 class IterationState:
@@ -65,7 +77,7 @@ class PPOUpdater:
     def __init__(self, policy_net, value_net, lr=4e-4, eps=1e-5, weight_decay=0.0, betas=(0.9, 0.999), gamma=1.0,
                  tau=0.0, clip_epsilon=0.2, value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4,
                  mini_batch_size=256, batch_stage=False, max_grad_norm=1.0, dist_ctx=None, pack_threads=0,
-                 sub_batches=1, dp_mode='auto', dp_balance='edges', legacy_zero_grad=False):
+                 sub_batches=1, dp_mode='auto', dp_balance='edges', legacy_zero_grad=None):
         self.policy_net, self.value_net = policy_net, value_net
         self.backend = backend_of(policy_net)
         self.lr, self.eps, self.weight_decay, self.betas = lr, eps, weight_decay, betas
@@ -80,7 +92,7 @@ class PPOUpdater:
             raise ValueError("dp_mode must be 'auto', 'global' or 'local'")
         self.dp_mode, self.dp_balance = dp_mode, dp_balance
         self._mode = 'single'                 # resolved per update_params: 'single' | 'global' | 'local'
-        self.legacy_zero_grad = bool(legacy_zero_grad)
+        self.legacy_zero_grad = torch_zero_grad_zero_fills() if legacy_zero_grad is None else bool(legacy_zero_grad)
         self._group_seen = [False, False, False]
         self.pack_threads = pack_threads
         # sub_batches = 2: the two halves of every minibatch run on two HIP streams so the MFMA-bound GEMMs of
@@ -131,7 +143,7 @@ class PPOUpdater:
             self._rowbuf_B = rows
 
     # ------------------------------------------------------------------ data-parallel mode
-    def _resolve_mode(self, batch):
+    def _resolve_mode(self, batch, packed):
         """'single' (no collectives) | 'global' (same batch everywhere, slices of one global permutation) |
         'local' (own shard per rank).  'auto' picks 'global' exactly when every rank was handed the same batch."""
         d = self.dist
@@ -139,7 +151,7 @@ class PPOUpdater:
             return 'single'
         if d.world == 1 or self.dp_mode == 'local':
             return 'local'
-        same = d.same_everywhere(batch_fingerprint(batch), self.engine.device)
+        same = d.same_everywhere(batch_fingerprint(batch) + (states_fingerprint(packed),), self.engine.device)
         if self.dp_mode == 'global' and not same:
             raise RuntimeError("dp_mode='global' needs the same replay batch on every rank (sample once and "
                                "dist.broadcast_batch it, or use dp_mode='local' for per-rank shards)")
@@ -198,17 +210,18 @@ class PPOUpdater:
         """Pack + upload the replay, value / old-log-prob pre-pass (:256-264, :283-292), GAE (:267)."""
         engine, dev = self.engine, self.engine.device
         agent = self.policy_net.agent
-        self._mode = self._resolve_mode(batch)
-        R = self.local_rows()
-        if self.sub_batches > 1 and R % self.sub_batches:
-            raise ValueError('sub_batches must divide the %d rows a rank processes per step' % R)
-        self._ensure_rowbufs(R)
         T = len(batch.states)
         if not hasattr(self, '_pack_cache'):
             self._pack_cache = {}
         packed = packer.pack_replay(batch.states, np.asarray(batch.actions), agent.node_dim,
                                     agent.numerical_feature_size, n_threads=self.pack_threads,
-                                    reuse=self._pack_cache).to(dev)
+                                    reuse=self._pack_cache)
+        self._mode = self._resolve_mode(batch, packed)       # (the fingerprint reads the packed host buffer)
+        packed.to(dev)
+        R = self.local_rows()
+        if self.sub_batches > 1 and R % self.sub_batches:
+            raise ValueError('sub_batches must divide the %d rows a rank processes per step' % R)
+        self._ensure_rowbufs(R)
         torch.cuda.current_stream(dev).synchronize()      # the pinned staging buffer may be refilled next iteration
         rewards = self._to_f32(batch.rewards, dev)
         masks = self._to_f32(batch.masks, dev)
@@ -228,7 +241,8 @@ class PPOUpdater:
                 continue
             mb, _ = sched.minibatch(k)
             lo, hi = int(rows[0]), int(rows[-1]) + 1
-            engine.forward(packed, mb, self.flat, values[lo:hi], logp[lo:hi], ent[lo:hi], keep=False)
+            # no backward is pending on slot 0 here: the pre-pass shares the training arena (no second multi-GB slot)
+            engine.forward(packed, mb, self.flat, values[lo:hi], logp[lo:hi], ent[lo:hi], keep=False, slot=0)
         if shared:
             self.dist.all_reduce_sum(values)
             self.dist.all_reduce_sum(logp)
@@ -246,7 +260,12 @@ class PPOUpdater:
         meta = it.packed.meta
         stage_np = meta[:, packer.M_STAGE]
         if self.batch_stage:
+            # get_perm_batch_stage (:273-279): land-use rows first, then road rows, both in the shuffled order; the
+            # reference indexes a two-entry list with stage.argmax(), so a row of any other stage is an IndexError
             st = stage_np[it.order]
+            if ((st != 0) & (st != 1)).any():
+                raise IndexError('batch_stage: row %d is neither a land-use nor a road row (list index out of range in '
+                                 'the reference\'s get_perm_batch_stage)' % int(it.order[np.flatnonzero((st != 0) & (st != 1))[0]]))
             it.order = np.concatenate([it.order[st == 0], it.order[st == 1]])
         count = lambda rows: [len(rows), int((it.exps_np[rows] != 0).sum()), int((stage_np[rows] == 0).sum()),
                               int((stage_np[rows] == 1).sum())]
@@ -416,10 +435,21 @@ class HipUpdateMixin:
                             entropy_coef=self.entropy_coef, num_optim_epoch=self.opt_num_epochs,
                             mini_batch_size=self.mini_batch_size, batch_stage=bool(specs.get('batch_stage', False)),
                             dist_ctx=ctx, dp_mode=os.environ.get('UPAMD_DP_MODE', 'auto'),
-                            legacy_zero_grad=os.environ.get('UPAMD_LEGACY_ZERO_GRAD', '0') == '1')
+                            legacy_zero_grad=self._legacy_zero_grad())
             up.loss_iter = self.loss_iter
             self._upamd_updater = up
         return up
+
+    def _legacy_zero_grad(self):
+        """What ``self.optimizer.zero_grad()`` (urban_planning_agent.py:334) does in THIS process: zero-fill (the
+        reference's pinned torch <= 1.13) or set to None (torch >= 2.0).  UPAMD_LEGACY_ZERO_GRAD = 0 | 1 overrides."""
+        env = os.environ.get('UPAMD_LEGACY_ZERO_GRAD')
+        if env in ('0', '1'):
+            return env == '1'
+        try:
+            return inspect.signature(self.optimizer.zero_grad).parameters['set_to_none'].default is False
+        except (AttributeError, KeyError, ValueError, TypeError):
+            return torch_zero_grad_zero_fills()
 
     def update_params(self, batch, iteration):
         up = self._hip_updater()
@@ -433,5 +463,6 @@ def install(agent):
     """Patch an existing reference agent INSTANCE (its networks must come from our create_sgnn_model)."""
     import types
     agent._hip_updater = types.MethodType(HipUpdateMixin._hip_updater, agent)
+    agent._legacy_zero_grad = types.MethodType(HipUpdateMixin._legacy_zero_grad, agent)
     agent.update_params = types.MethodType(HipUpdateMixin.update_params, agent)
     return agent

@@ -8,19 +8,27 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.h"
 
 using namespace upamd;
 
+// side stream of the forked step (see fork_side) + its fork / join events
+struct SideCtx {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
 struct upamd_engine {
     upamd_model_desc d;
     ParamLayout P;
     Profiler prof;
-    // side stream of the forked step (see fork_side): created on first use, on the device of the caller's stream
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // one side context per CALLER stream (created on first use, on the device of that stream): two callers that drive
+    // the engine on two streams (PPOUpdater(sub_batches=2), an action server next to the learner) do not queue their
+    // side chains behind each other.  The engine's entry points are not re-entrant: the host wrapper serialises them.
+    std::unordered_map<hipStream_t, SideCtx> sides;
 };
 
 namespace {
@@ -260,33 +268,36 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
 // per-sample weight gradients only by the final reduction.  They run on an engine-owned side stream, forked from / joined to the
 // caller's stream with events, underneath the GCN layers' GEMM / message-passing launches (tune knob "side_stream", default on).
 static int g_side_stream = 1;
-static int side_ready(upamd_engine *eng) {
-    if (eng->side) return 0;
-    UPAMD_HIP(hipStreamCreateWithFlags(&eng->side, hipStreamNonBlocking));
-    UPAMD_HIP(hipEventCreateWithFlags(&eng->ev_fork, hipEventDisableTiming));
-    UPAMD_HIP(hipEventCreateWithFlags(&eng->ev_join, hipEventDisableTiming));
+static int side_ready(upamd_engine *eng, hipStream_t st, SideCtx **out) {
+    SideCtx &c = eng->sides[st];
+    if (!c.side) {
+        UPAMD_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        UPAMD_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+        UPAMD_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+    }
+    *out = &c;
     return 0;
 }
 // side stream continues from this point of `st`
-static int fork_side(upamd_engine *eng, hipStream_t st) {
-    UPAMD_HIP(hipEventRecord(eng->ev_fork, st));
-    UPAMD_HIP(hipStreamWaitEvent(eng->side, eng->ev_fork, 0));
+static int fork_side(SideCtx *c, hipStream_t st) {
+    UPAMD_HIP(hipEventRecord(c->ev_fork, st));
+    UPAMD_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     return 0;
 }
 // `st` continues after everything enqueued on the side stream so far
-static int join_side(upamd_engine *eng, hipStream_t st) {
-    UPAMD_HIP(hipEventRecord(eng->ev_join, eng->side));
-    UPAMD_HIP(hipStreamWaitEvent(st, eng->ev_join, 0));
+static int join_side(SideCtx *c, hipStream_t st) {
+    UPAMD_HIP(hipEventRecord(c->ev_join, c->side));
+    UPAMD_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
     return 0;
 }
 
 // An error return between fork and join must not leave side-stream work running on a workspace the caller may free next:
 // the guard drains the side stream unless the join was reached
 struct SideGuard {
-    upamd_engine *eng;
+    SideCtx *c = nullptr;
     bool armed = false;
     ~SideGuard() {
-        if (armed && eng->side) (void)hipStreamSynchronize(eng->side);
+        if (armed && c && c->side) (void)hipStreamSynchronize(c->side);
     }
 };
 
@@ -448,11 +459,13 @@ extern "C" int upamd_profile_reset(upamd_engine *eng) {
 extern "C" void upamd_engine_destroy(upamd_engine *eng) {
     if (!eng) return;
     upamd_profile_reset(eng);
-    if (eng->side) {
-        (void)hipStreamSynchronize(eng->side);
-        (void)hipEventDestroy(eng->ev_fork);
-        (void)hipEventDestroy(eng->ev_join);
-        (void)hipStreamDestroy(eng->side);
+    for (auto &kv : eng->sides) {
+        SideCtx &c = kv.second;
+        if (!c.side) continue;
+        (void)hipStreamSynchronize(c.side);
+        (void)hipEventDestroy(c.ev_fork);
+        (void)hipEventDestroy(c.ev_join);
+        (void)hipStreamDestroy(c.side);
     }
     delete eng;
 }
@@ -633,8 +646,12 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     const ChainDims cd = chain_dims(d, x, B);
     // (launch-bound small models gain nothing from the fork: its two event round trips cost more than they hide)
     const bool forked = g_side_stream != 0 && !defer_node_tn(x.D);
-    SideGuard side_guard{eng};
-    if (forked) CK(side_ready(eng));
+    SideGuard side_guard;
+    SideCtx *sc = nullptr;
+    if (forked) {
+        CK(side_ready(eng, st, &sc));
+        side_guard.c = sc;
+    }
     {
         ChainFwdPre a;
         memset(&a, 0, sizeof(a));
@@ -651,10 +668,10 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
             // side stream and are joined in front of the last GCN layer (the first consumer of C, then r)
             a.part = CHAIN_GATHER;
             CK(launch_chain_fwd_pre(a, st));
-            CK(fork_side(eng, st));
+            CK(fork_side(sc, st));
             side_guard.armed = true;
             a.part = CHAIN_LAYERS;
-            CK(launch_chain_fwd_pre(a, eng->side));
+            CK(launch_chain_fwd_pre(a, sc->side));
         } else {
             CK(launch_chain_fwd_pre(a, st));
         }
@@ -696,7 +713,7 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
             CK(launch_gemm_nt(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), 2 * D, nullptr, nullptr, W(S_PQ + l), 0, st, prof));
         }
         if (forked && l == x.L) {                            // C (head inputs of the last layer), r, U, constb are ready
-            CK(join_side(eng, st));
+            CK(join_side(sc, st));
             side_guard.armed = false;
         }
         if (x.K > 1) {
@@ -1021,10 +1038,12 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     };
     // ---- 4. per-sample chain, the part before the graph: dr -> dq1 -> dq0 -> dC (+ the land-use head's two dC terms)
     const bool forked = g_side_stream != 0 && !defer;
-    SideGuard side_guard{eng};
+    SideGuard side_guard;
+    SideCtx *sc = nullptr;
     if (forked) {
-        CK(side_ready(eng));
-        CK(fork_side(eng, st));
+        CK(side_ready(eng, st, &sc));
+        side_guard.c = sc;
+        CK(fork_side(sc, st));
         side_guard.armed = true;
     }
     {
@@ -1034,9 +1053,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         a.dconst = land ? W(S_DCONST) : nullptr; a.dC_head = land ? W(S_DC_HEAD) : nullptr;
         a.WkkT = W(S_WKKT); a.Wiq = Wiq; a.Wq = PR(P.q_w); a.Wbd = W(S_WBD);
         a.dq1 = W(S_DQ1); a.dq0 = W(S_DQ0); a.dC = W(S_DC);
-        CK(launch_chain_bwd_pre(a, forked ? eng->side : st));
+        CK(launch_chain_bwd_pre(a, forked ? sc->side : st));
     }
-    if (forked) CK(grouped_launch(eng->side));
+    if (forked) CK(grouped_launch(sc->side));
     // ---- 5. GCN layers, last to first
     const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
@@ -1089,7 +1108,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     }));
     // ---- 7. (not forked: the grouped launch here) then its slab reductions, and the deferred node-level ones
     if (forked) {
-        CK(join_side(eng, st));
+        CK(join_side(sc, st));
         side_guard.armed = false;
     } else {
         CK(grouped_launch(st));

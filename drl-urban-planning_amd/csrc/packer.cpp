@@ -16,7 +16,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -52,9 +54,24 @@ inline int argmax3(const float *s) {
     return best;
 }
 
+// Default packer thread count: this process's share of the host -- the CPUs it may run on (affinity mask), divided by
+// the ranks torchrun started on this node (LOCAL_WORLD_SIZE, else WORLD_SIZE), capped at 64 (the fill is memory-bound:
+// more threads than that only contend).  Eight ranks on a 256-CPU host get 32 threads each instead of 8 x 256.
+int default_pack_threads() {
+    int cpus = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) cpus = std::min(cpus, (int)CPU_COUNT(&set));
+    int ranks = 1;
+    const char *lw = getenv("LOCAL_WORLD_SIZE");
+    if (!lw || !*lw) lw = getenv("WORLD_SIZE");
+    if (lw && atoi(lw) > 1) ranks = atoi(lw);
+    return std::max(1, std::min(64, cpus / ranks));
+}
+
 template <typename F>
 int parallel_for(int64_t T, int n_threads, F &&fn) {
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = default_pack_threads();
     n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, T / 64));
     std::atomic<int> status{0};
     if (n_threads <= 1) {

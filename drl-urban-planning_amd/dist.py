@@ -181,6 +181,19 @@ def batch_fingerprint(batch):
     return len(batch.states), crc
 
 
+def states_fingerprint(packed):
+    """crc32 of what the packer extracted from the STATES of a replay: per-state live node / edge / candidate counts,
+    stage, action slot and node-mask count (meta columns 0-6; the pad sizes are left out because a compact record and
+    the padded tuple it was made from differ there) and every state's numerical feature row.  Two replays with the
+    same per-row scalars but different graphs (synthetic replays, equal action seeds) differ here, so 'auto' cannot
+    mistake rank-local shards for one shared batch."""
+    meta = np.ascontiguousarray(packed.meta[:, :7])
+    crc = zlib.crc32(meta.tobytes())
+    L = packed.layout
+    num = packed.host_buf.numpy()[L.off_numerical:L.off_numerical + 4 * int(L.T) * int(L.numerical_dim)]
+    return zlib.crc32(num.tobytes(), crc)
+
+
 def global_counts(ctx, lists, device):
     """Element-wise sum over ranks of several equal-length integer lists (per-minibatch row counts);
     one tiny all-reduce per epoch, not per step."""

@@ -3,6 +3,7 @@ and the scratch workspace (torch tensors = device memory plumbing) and forwards 
 the C ABI with raw pointers.  No math happens here.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -34,6 +35,10 @@ class NativeEngine:
         self.table, self.n_floats, self.groups = native.param_table(desc)
         self.index = {name: (off, rows, cols, grp) for name, off, rows, cols, grp in self.table}
         self.ws_slots = {}        # scratch workspaces; slot > 0 = concurrent sub-batches on side streams
+        # The native entry points are not re-entrant (per-stream side contexts, profiler tables, the slot workspaces):
+        # host threads that share one engine -- a rollout.ActionServer thread next to the learner -- are serialised
+        # here.  Only the ENQUEUE is under the lock; the kernels of two callers still overlap on their streams.
+        self.lock = threading.RLock()
 
     def _st(self):
         return _stream(self.device)
@@ -108,23 +113,30 @@ class NativeEngine:
         return C.c_void_p(aligned), C.c_int64(ws.numel() - (aligned - base)), aligned - base
 
     # ---- forward / backward
-    def forward(self, packed, mb, flat_params, value, logp, ent, keep=True, slot=0, ws=None):
-        """keep=False: a no-grad forward; it runs in the scratch slot 'nograd' unless a workspace is named, so it never
-        overwrites activations that a backward on slot 0 (or on a private workspace) still needs."""
-        if ws is None:
-            if not keep and slot == 0:
-                slot = 'nograd'
-            self.ensure_workspace(mb, slot)
-        wsp, wsb, _ = self._ws_args(slot, ws)
-        with self._on_device():
-            native.check(self.lib.upamd_forward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
-                                                _ptr(flat_params), wsp, wsb, _ptr(value), _ptr(logp), _ptr(ent),
-                                                1 if keep else 0, self._st()), 'upamd_forward')
-        self.last_forward_slot = slot if ws is None else None
+    def forward(self, packed, mb, flat_params, value, logp, ent, keep=True, slot=None, ws=None):
+        """slot=None: slot 0 for a forward whose activations are kept, the scratch slot 'nograd' for a no-grad one, so
+        that a stray no-grad forward never overwrites activations a backward on slot 0 still needs.  A caller that
+        knows no backward is pending (the PPO pre-pass) names slot 0 itself and spares the second arena."""
+        with self.lock:
+            if ws is None:
+                if slot is None:
+                    slot = 0 if keep else 'nograd'
+                self.ensure_workspace(mb, slot)
+            wsp, wsb, _ = self._ws_args(slot, ws)
+            with self._on_device():
+                native.check(self.lib.upamd_forward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
+                                                    _ptr(flat_params), wsp, wsb, _ptr(value), _ptr(logp), _ptr(ent),
+                                                    1 if keep else 0, self._st()), 'upamd_forward')
+            self.last_forward_slot = slot if ws is None else None
+
+    def release_slot(self, slot):
+        """Give a slot's workspace back to the caching allocator (stream-ordered)."""
+        with self.lock:
+            self.ws_slots.pop(slot, None)
 
     def backward(self, packed, mb, flat_params, dvalue, dlogp, dent, grads, slot=0, ws=None):
         wsp, wsb, _ = self._ws_args(slot, ws)
-        with self._on_device():
+        with self.lock, self._on_device():
             native.check(self.lib.upamd_backward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
                                                  _ptr(flat_params), wsp, wsb, _ptr(dvalue), _ptr(dlogp), _ptr(dent),
                                                  _ptr(grads), self._st()), 'upamd_backward')

@@ -186,11 +186,14 @@ class _Runner:
     (``value_net(x1)``, then ``get_log_prob_entropy(x2, a)``, then ``loss.backward()`` -- or a no-grad
     ``select_action`` between a forward and its backward).  No-grad runners use the engine's scratch slot."""
 
-    def __init__(self, engine, packed, sched, need_grad):
+    def __init__(self, engine, packed, sched, need_grad, private_ws=False):
         self.engine, self.packed, self.sched = engine, packed, sched
         self.mb, self.item = sched.minibatch(0)
         self.need_grad = need_grad
-        self.ws = engine.alloc_workspace(self.mb) if need_grad else None
+        # private_ws: a no-grad forward whose intermediates are READ BACK afterwards (the action heads' logits) also
+        # owns its workspace -- the shared scratch slot could be overwritten by another thread's no-grad forward (the
+        # action server next to the learner's pre-pass) between the forward and the read
+        self.ws = engine.alloc_workspace(self.mb) if (need_grad or private_ws) else None
         self.slot = 0 if need_grad else 'nograd'
         self.backward_done = False
 
@@ -271,7 +274,7 @@ class _HipBackend:
             pieces.append(torch.zeros(engine.n_floats - cursor, device=engine.device))
         return torch.cat(pieces)
 
-    def run(self, x, action):
+    def run(self, x, action, private_ws=False):
         """x: list[B] of list[9] tensors on any device.  Returns (value, logp, ent) f32[B] on the GPU."""
         device = next(self.shared_net.parameters()).device
         engine = self.engine(device)
@@ -286,7 +289,7 @@ class _HipBackend:
                                 self.shared_net.agent.numerical_feature_size).to(device)
         sched = packer.Schedule(pk, [np.arange(B)], device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.named_params().values())
-        runner = _Runner(engine, pk, sched, need_grad)
+        runner = _Runner(engine, pk, sched, need_grad, private_ws)
         flat = self.flat_params_autograd(engine)
         value, logp, ent = _HipNetwork.apply(flat, runner)
         return value, logp, ent, runner
@@ -298,7 +301,7 @@ class _HipBackend:
         stage f32[B, 3]) on the networks' device."""
         device = next(self.shared_net.parameters()).device
         with torch.no_grad():
-            _, _, _, runner = self.run(x, None)
+            _, _, _, runner = self.run(x, None, private_ws=True)
             pk, mb, meta = runner.packed, runner.mb, runner.packed.meta
             B = mb.B
             stage_id = meta[:B, packer.M_STAGE]

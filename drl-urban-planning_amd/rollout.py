@@ -51,8 +51,9 @@ class ActionClient:
 
     MAX_ROWS = 64
 
-    def __init__(self, shm_name, index, slot_bytes, conn):
+    def __init__(self, shm_name, index, slot_bytes, conn, timeout_s=120.0):
         self._shm_name, self.index, self.slot_bytes, self.conn = shm_name, index, slot_bytes, conn
+        self.timeout_s = timeout_s            # a dead server must not hang the sampling phase for ever
         self._shm = None
         self.type = 'discrete'
 
@@ -76,6 +77,8 @@ class ActionClient:
             sizes.append(int(rec.size))
             cursor = _align(cursor + rec.size)
         self.conn.send((sizes, bool(mean_action)))
+        if not self.conn.poll(self.timeout_s):
+            raise TimeoutError('action server did not answer within %.0f s (is its serving thread alive?)' % self.timeout_s)
         status = self.conn.recv()
         if status != 'ok':
             raise RuntimeError('action server: %s' % status)
@@ -100,6 +103,7 @@ class ActionServer:
         self._server_ends = [p[0] for p in self.pipes]
         self._index_of = {id(c): i for i, c in enumerate(self._server_ends)}
         self.stats = dict(batches=0, requests=0, rows=0, max_rows=0, busy_s=0.0)
+        self.last_error = None
         self._thread = None
         self._stop = threading.Event()
 
@@ -173,6 +177,20 @@ class ActionServer:
         return action.cpu().numpy()
 
     # ---- background service in the learner process
+    def launch(self, worker_fn, worker_args, mp_context=None):
+        """Fork the env workers FIRST, then start the serving thread: `fork()` while another thread of this process is
+        inside the HIP runtime / the allocator can leave the child with a lock that nobody will release.  (The HIP
+        runtime itself may be initialised before the fork, as in the reference, as long as the children never touch
+        it.)  `worker_fn(client, *args)` runs in each child; returns the started processes."""
+        if self._thread is not None:
+            raise RuntimeError('launch() must fork the workers before the serving thread exists; call stop() first')
+        ctx = mp_context or multiprocessing.get_context('fork')
+        procs = [ctx.Process(target=worker_fn, args=(self.client(i),) + tuple(a)) for i, a in enumerate(worker_args)]
+        for p in procs:
+            p.start()
+        self.start()
+        return procs
+
     def start(self):
         if self._thread is None:
             self._stop.clear()
@@ -182,7 +200,18 @@ class ActionServer:
 
     def _loop(self):
         while not self._stop.is_set():
-            self.serve_once(timeout=0.02)
+            try:
+                self.serve_once(timeout=0.02)
+            except Exception as exc:                # a broken pipe, an OSError from wait(): tell whoever is waiting, keep serving
+                self.stats['errors'] = self.stats.get('errors', 0) + 1
+                self.last_error = '%s: %s' % (type(exc).__name__, exc)
+                for conn in self._server_ends:
+                    try:
+                        if not conn.closed and conn.poll(0):
+                            conn.recv()
+                            conn.send(self.last_error)
+                    except (EOFError, OSError):
+                        conn.close()
 
     def stop(self):
         if self._thread is not None:

@@ -80,12 +80,14 @@ class ScalarLog:
 
 def make_reference_agent(ref, cfg, policy_net, value_net, lr=4e-4, eps=1e-5, weight_decay=0.0, gamma=1.0,
                          tau=0.0, clip_epsilon=0.2, value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4,
-                         mini_batch_size=256):
+                         mini_batch_size=256, batch_stage=False, legacy_zero_grad=False):
     """UrbanPlanningAgent without env/logger setup (object.__new__ + the fields __init__ would set,
     urban_planning_agent.py:28-47, 145-151)."""
     import torch
     ag = object.__new__(ref.UrbanPlanningAgent)
     cfg.mini_batch_size = mini_batch_size
+    if batch_stage:
+        cfg.agent_specs = dict(cfg.agent_specs, batch_stage=True)      # urban_planning_agent.py:314
     ag.cfg = cfg
     ag.training = True
     ag.device = torch.device('cpu')
@@ -103,4 +105,9 @@ def make_reference_agent(ref, cfg, policy_net, value_net, lr=4e-4, eps=1e-5, wei
     ag.opt_num_epochs = num_optim_epoch
     ag.mini_batch_size = mini_batch_size
     ag.policy_grad_clip = [(policy_net.parameters(), 1), (value_net.parameters(), 1)]
+    if legacy_zero_grad:
+        # the reference pins torch <= 1.13 (requirements.txt:3), whose Optimizer.zero_grad() zero-fills the gradients;
+        # the installed torch sets them to None.  Re-create the pinned behaviour on the reference's own optimizer
+        import functools
+        ag.optimizer.zero_grad = functools.partial(ag.optimizer.zero_grad, set_to_none=False)
     return ag

@@ -325,8 +325,15 @@ class OracleUpdater:
     """
 
     def __init__(self, P, lr=4e-4, eps=1e-5, weight_decay=0.0, gamma=1.0, tau=0.0, clip_epsilon=0.2,
-                 value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4, mini_batch_size=256, num_heads=1):
+                 value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4, mini_batch_size=256, num_heads=1,
+                 batch_stage=False, legacy_zero_grad=False):
         self.P = P
+        # cfg.agent_specs['batch_stage'] (urban_planning_agent.py:314-319)
+        self.batch_stage = batch_stage
+        # the reference pins torch <= 1.13 (requirements.txt:3) whose Optimizer.zero_grad() zero-fills; torch >= 2.0
+        # sets the gradients to None.  They differ for a head that gets no row in a minibatch (Adam skips a None
+        # gradient but steps on a zero one).  False = the installed torch's semantics (what the goldens' `upd/*` hold)
+        self.legacy_zero_grad = legacy_zero_grad
         self.names = list(P.keys())
         self.optimizer = torch.optim.Adam([P[k] for k in self.names], lr=lr, eps=eps, weight_decay=weight_decay)
         self.gamma, self.tau = gamma, tau
@@ -348,7 +355,7 @@ class OracleUpdater:
         loss, vl, sl, el = ppo_losses(self.P, tensorfy(states_b), actions_b, advantages_b, returns_b,
                                       fixed_log_probs_b, exps_b, self.clip_epsilon, self.value_pred_coef,
                                       self.entropy_coef, self.num_heads)
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=not self.legacy_zero_grad)
         loss.backward()
         self.clip_policy_grad()
         self.optimizer.step()
@@ -382,6 +389,18 @@ class OracleUpdater:
             actions, returns, advantages, fixed_log_probs, exps = \
                 actions[perm].clone(), returns[perm].clone(), advantages[perm].clone(), \
                 fixed_log_probs[perm].clone(), exps[perm].clone()
+            if self.batch_stage:
+                # get_perm_batch_stage (urban_planning_agent.py:273-279): land-use rows first, then road rows, each in
+                # the shuffled order; a row of any other stage raises IndexError there, and here
+                inds = [[], []]
+                for i, x in enumerate(states):
+                    inds[int(np.argmax(np.asarray(x[-1])))].append(i)
+                ps_np = np.array(inds[0] + inds[1])
+                ps = torch.from_numpy(ps_np).long()
+                states = [states[i] for i in ps_np]
+                actions, returns, advantages, fixed_log_probs, exps = \
+                    actions[ps].clone(), returns[ps].clone(), advantages[ps].clone(), \
+                    fixed_log_probs[ps].clone(), exps[ps].clone()
             for i in range(int(math.floor(num_state / self.mini_batch_size))):
                 ind = slice(i * self.mini_batch_size, min((i + 1) * self.mini_batch_size, num_state))
                 self.step(states[ind], actions[ind], advantages[ind], returns[ind], fixed_log_probs[ind], exps[ind])

@@ -17,6 +17,7 @@ for p in (os.path.dirname(HERE), HERE):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import dp_cases  # noqa: E402
 import helpers  # noqa: E402
 from duck_agent import make_duck_agent  # noqa: E402
 from test_oracle_golden import CASE_B, CASE_EPOCHS, CASE_HYPER, CASE_SEED  # noqa: E402
@@ -31,14 +32,19 @@ def main():
     dev_index = rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    z, sd, states = helpers.load_case(name)
-    cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
+    if name == 'big_mixed':             # BASELINE model size, mixed HLG + DHM graphs (tests/dp_cases.py)
+        cfg, sd, replay = dp_cases.big_mixed()
+        hyper, epochs, B_glob, seed0 = dp_cases.BIG['hyper'], dp_cases.BIG['epochs'], dp_cases.BIG['B'], dp_cases.BIG['seed']
+    else:
+        z, sd, states = helpers.load_case(name)
+        cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
+        replay = synth.Replay(states, z['actions'], z['masks'], z['rewards'], z['exps'])
+        hyper, epochs, B_glob, seed0 = CASE_HYPER[name], CASE_EPOCHS[name], CASE_B[name], CASE_SEED[name]
     policy_net, value_net, ac = helpers.build_product(cfg)
     ac.load_state_dict(sd)
     ac.to(dev)
-    B = CASE_B[name] if mode != 'local' else CASE_B[name] // world
-    agent = make_duck_agent(cfg, policy_net, value_net, ac, CASE_HYPER[name], CASE_EPOCHS[name], B)
-    replay = synth.Replay(states, z['actions'], z['masks'], z['rewards'], z['exps'])
+    B = B_glob if mode != 'local' else B_glob // world
+    agent = make_duck_agent(cfg, policy_net, value_net, ac, hyper, epochs, B)
     if mode == 'bcast':
         ctx = DistContext.from_env(device=dev)
         agent.dist_ctx = ctx
@@ -46,12 +52,10 @@ def main():
             replay = None
         replay = broadcast_batch(ctx, replay, src=0, device=dev)
     elif mode == 'local':
-        T = len(states) // world
-        sl = slice(rank * T, (rank + 1) * T)
-        replay = synth.Replay(states[sl], z['actions'][sl], z['masks'][sl], z['rewards'][sl], z['exps'][sl])
+        replay = dp_cases.shard(replay, rank, world)
     logs = []
     for it in range(2):
-        np.random.seed(CASE_SEED[name] + 11 + it)
+        np.random.seed(seed0 + 11 + it)
         agent.update_params(replay, it)
         up = agent._hip_updater()
         logs.append(up.last_losses.copy())

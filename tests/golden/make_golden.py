@@ -60,6 +60,15 @@ CASES = {
                    max_nodes=40, max_edges=96, T=24, B=8, epochs=2, seed=17, road_fraction=0.3,
                    hyper=dict(lr=4e-4, eps=1e-5, weight_decay=1e-4, gamma=0.99, tau=0.95, clip_epsilon=0.2,
                               value_pred_coef=0.5, entropy_coef=0.01)),
+    # cfg.agent_specs['batch_stage'] = True (urban_planning_agent.py:273-279, 314-319): minibatches regrouped by stage, so
+    # most of them hold one stage only and the other pointer head gets no gradient -- the case where torch <= 1.13
+    # (zero_grad zero-fills: the idle head still takes Adam steps) and torch >= 2.0 (grad None: Adam skips it) differ.
+    # `upd*` = the installed torch's semantics, `updz*` = the reference's pinned ones
+    'case_s': dict(model=dict(D=16, L=2, S=(64, 16), heads=1, land_head=(32, 1), road_head=(32, 1),
+                              value_head=(32, 32, 1)), batch_stage=True,
+                   max_nodes=40, max_edges=96, T=28, B=6, epochs=2, seed=23, road_fraction=0.5,
+                   hyper=dict(lr=1e-3, eps=1e-5, weight_decay=1e-4, gamma=0.99, tau=0.95, clip_epsilon=0.2,
+                              value_pred_coef=0.5, entropy_coef=0.01)),
 }
 
 
@@ -162,6 +171,22 @@ def main():
             out['upd2_sd/' + k] = v.detach().numpy().copy()
         out['upd2/scalars'] = np.array([v for (t, v, s) in ag2.tb_logger.scalars if t in (
             'loss/loss', 'loss/value_loss', 'loss/surr_loss', 'loss/entropy_loss')]).reshape(-1, 4)
+
+        if spec.get('batch_stage'):
+            # the same two calls with the stage regrouping on, under both zero_grad semantics
+            for tag, legacy in (('upds', False), ('updz', True)):
+                cfg3, policy3, value3 = build(ref, spec)
+                ag3 = ref_import.make_reference_agent(ref, cfg3, policy3, value3, num_optim_epoch=spec['epochs'],
+                                                      mini_batch_size=B, batch_stage=True, legacy_zero_grad=legacy, **hy)
+                for call in (0, 1):
+                    np.random.seed(spec['seed'] + 11 + call)
+                    ag3.update_params(replay, call)
+                    for k, v in ref.ActorCritic(policy3, value3).state_dict().items():
+                        out['%s%s_sd/%s' % (tag, '' if call == 0 else '2', k)] = v.detach().numpy().copy()
+                out[tag + '/scalars'] = np.array([v for (t, v, s) in ag3.tb_logger.scalars if t in (
+                    'loss/loss', 'loss/value_loss', 'loss/surr_loss', 'loss/entropy_loss')]).reshape(-1, 4)
+            st = np.array([int(np.argmax(s[8])) for s in replay.states])
+            out['upds/stage_of_row'] = st
 
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **out)

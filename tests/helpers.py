@@ -22,6 +22,9 @@ CASE_MODEL = {
     # num_edge_fc_layers = 2: the edge MLP has a second Linear behind the factorisable one (state_encoder.py:59-82)
     'case_k': dict(D=32, L=2, K=2, S=(64, 16), heads=2, land_head=(32, 1), road_head=(16, 1), value_head=(32, 32, 1),
                    max_nodes=40, max_edges=96),
+    # batch_stage = True (urban_planning_agent.py:314-319); same dims as case_a
+    'case_s': dict(D=16, L=2, S=(64, 16), heads=1, land_head=(32, 1), road_head=(32, 1), value_head=(32, 32, 1),
+                   max_nodes=40, max_edges=96),
 }
 MLP_CASES = ('case_m',)       # built with create_mlp_model (the rl-mlp encoder)
 
