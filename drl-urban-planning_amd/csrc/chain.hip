@@ -58,11 +58,11 @@ __global__ __launch_bounds__(256) void permute_kernel(PermJobs P) {
             if (J.dst2) J.dst2[g] = v;
             break;
         }
-        case PERM_WCAT: {                       // W [D][2D] = [Wa | Wb] -> Wcat [2D][D] (P/Q panel row order) + transpose
+        case PERM_WCAT: {                       // W [D][2D] = [Wa | Wb] -> Wcat [2D][D] (rows in P/Q pair order, kernels.h) + transpose
             const int D = J.rows;
             if (g >= 2 * D * D) return;
             const int jp = g / D, kk = g % D;
-            const int row = (jp >> 5) * 16 + (jp & 15), half = (jp >> 4) & 1;
+            const int row = pq_col(jp), half = pq_side(jp);
             const float v = J.src[(int64_t)row * 2 * D + half * D + kk];
             J.dst[g] = v;
             if (J.dst2) J.dst2[(int64_t)kk * 2 * D + jp] = v;
@@ -817,8 +817,8 @@ int launch_gtn(const TnJobs &P, hipStream_t st) {
 // ------------------------------------------------------------------------------------------ grouped slab reduction
 // dst (+)= sum_s slab[s][i][j] in a FIXED order (16 slab groups summed by 16 threads per element, then combined 0..15).
 // modes: 0 dst[i*ldd + j] for j < jkeep (+ dst2[i] += the j == J-1 column);  1 dst[j*ldd + i];
-//        2 GCN un-permute: slab row i = P/Q column j' -> dst[((i>>5)*16 + (i&15))*ldd + ((i>>4)&1)*J + j];
-//        3 I == 1, J == 2D in P/Q panel order: dst[p*16+c] += the P half, dst2[j] = the whole vector (may be null)
+//        2 GCN un-permute: slab row i = P/Q position (pair order) -> dst[pq_col(i)*ldd + pq_side(i)*J + j];
+//        3 I == 1, J == 2D in P/Q pair order: dst[column] += the P entries, dst2[j] = the whole vector (may be null)
 __global__ __launch_bounds__(1024) void greduce_kernel(RedJobs P) {
     __shared__ float part[16][65];
     const int k = find_job(P.j, P.n, (int)blockIdx.x, &RedJob::blk_begin);
@@ -855,10 +855,10 @@ __global__ __launch_bounds__(1024) void greduce_kernel(RedJobs P) {
         float *p = J.dst + (int64_t)j * J.ldd + i;
         *p = J.overwrite ? acc : *p + acc;
     } else if (J.mode == 2) {
-        const int row = (i >> 5) * 16 + (i & 15), half = (i >> 4) & 1;
+        const int row = pq_col(i), half = pq_side(i);
         J.dst[(int64_t)row * J.ldd + half * J.J + j] += acc;
     } else {
-        if (((j >> 4) & 1) == 0) J.dst[(j >> 5) * 16 + (j & 15)] += acc;
+        if (pq_side(j) == 0) J.dst[pq_col(j)] += acc;
         if (J.dst2) J.dst2[j] = acc;
     }
 }

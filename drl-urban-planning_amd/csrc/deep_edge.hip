@@ -93,8 +93,15 @@ __global__ __launch_bounds__(256) void inc_gather_fwd_kernel(const float *__rest
     const int cq = (int)(g & 3);
     const int64_t k = (g >> 2) % NI;
     const int p = (int)((g >> 2) / NI);
-    const float4 pp = *reinterpret_cast<const float4 *>(PQ + ((int64_t)(2 * p) * M + gsrc[k]) * 16 + 4 * cq);
-    const float4 qq = *reinterpret_cast<const float4 *>(PQ + ((int64_t)(2 * p + 1) * M + gdst[k]) * 16 + 4 * cq);
+    // P/Q pair order (kernels.h): columns 4 cq .. 4 cq + 3 = the pairs 2 cq, 2 cq + 1 = chunks (2 cq) & 3, + 1 of the node's
+    // row in panel 2 p + (cq >> 1); a chunk is (P_c, P_c+1, Q_c, Q_c+1)
+    const int64_t pan = (int64_t)(2 * p + (cq >> 1)) * M;
+    const int ch = 8 * (cq & 1);
+    const float4 s0 = *reinterpret_cast<const float4 *>(PQ + (pan + gsrc[k]) * 16 + ch);
+    const float4 s1 = *reinterpret_cast<const float4 *>(PQ + (pan + gsrc[k]) * 16 + ch + 4);
+    const float4 d0 = *reinterpret_cast<const float4 *>(PQ + (pan + gdst[k]) * 16 + ch);
+    const float4 d1 = *reinterpret_cast<const float4 *>(PQ + (pan + gdst[k]) * 16 + ch + 4);
+    const float4 pp = make_float4(s0.x, s0.y, s1.x, s1.y), qq = make_float4(d0.z, d0.w, d1.z, d1.w);
     const float4 bb = *reinterpret_cast<const float4 *>(bias + p * 16 + 4 * cq);
     *reinterpret_cast<float4 *>(A1 + ((int64_t)p * NI + k) * 16 + 4 * cq) =
         make_float4(tanh_fast(pp.x + qq.x + bb.x), tanh_fast(pp.y + qq.y + bb.y), tanh_fast(pp.z + qq.z + bb.z),
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256) void inc_tanh_bwd_kernel(PackedView pk, MbView
 }
 
 // dP_v = sum_{k in inc(v)} dpre_1[k],  dQ_v = sum_{k in inc(v)} dpre_1[rev k]  (dpre_1[k = v -> u] feeds P_v and Q_u),
-// written in the P/Q panel order of the node GEMM's output, + the per-graph column sums of dP | dQ (edge.hip's format)
+// written in the P/Q pair order of the node GEMM's output, + the per-graph column sums of dP | dQ (edge.hip's format)
 __global__ __launch_bounds__(256) void inc_scatter_bwd_kernel(PackedView pk, MbView mb, int NP, const float *__restrict__ dpre1,
                                                               const int32_t *__restrict__ grev, float *__restrict__ dPQ,
                                                               float *__restrict__ dbias_part) {
@@ -253,16 +260,18 @@ __global__ __launch_bounds__(256) void inc_scatter_bwd_kernel(PackedView pk, MbV
             dP += Dp[(io + k) * 16];
             dQ += Dp[(int64_t)grev[io + k] * 16];
         }
-        dPQ[((int64_t)(2 * p) * M + o + v) * 16 + c] = dP;
-        dPQ[((int64_t)(2 * p + 1) * M + o + v) * 16 + c] = dQ;
+        const int pos = pq_pos(0, c);           // position of P column c inside the pair's 32 floats; its Q is 2 further
+        float *row = dPQ + ((int64_t)(2 * p + (pos >> 4)) * M + o + v) * 16 + (pos & 15);
+        row[0] = dP;
+        row[2] = dQ;
         sP += dP;
         sQ += dQ;
     }
     const float tP = colgroup_sum(sP, part);
     const float tQ = colgroup_sum(sQ, part);
     if (threadIdx.x < 16) {
-        dbias_part[(int64_t)b * (NP * 32) + (2 * p) * 16 + c] = tP;
-        dbias_part[(int64_t)b * (NP * 32) + (2 * p + 1) * 16 + c] = tQ;
+        dbias_part[(int64_t)b * (NP * 32) + p * 32 + pq_pos(0, c)] = tP;
+        dbias_part[(int64_t)b * (NP * 32) + p * 32 + pq_pos(1, c)] = tQ;
     }
 }
 

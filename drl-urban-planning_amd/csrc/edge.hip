@@ -96,16 +96,23 @@ __device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool
     return L;
 }
 
-// interleave a graph's P and Q panel slices into LDS, pre-scaled, by column PAIRS: the 16 bytes of node v and columns
-// (c, c+1), c even, are C2 * (P_c, P_c+1, Q_c, Q_c+1) -- the order the packed two-column math of the walks consumes
+// The P/Q tensor is in pair order (kernels.h): the 16 floats of node v in panel 2p are the column pairs 0..3 of the
+// slice -- chunk j = (P_2j, P_2j+1, Q_2j, Q_2j+1), the order the packed two-column math of the walks consumes -- and
+// panel 2p + 1 holds pairs 4..7.  The LDS row of a node (32 floats) is [panel 2p's 16 | panel 2p + 1's 16]: staging is a
+// 16-byte-chunk copy.  Pg / Qg below are those two panel slices ("A" / "B" halves of the rows), not P and Q.
+// float4 index i of a half (node i >> 2, chunk i & 3) -> its float offset in the LDS slice
+__device__ __forceinline__ int pq_slot(int i) { return (i >> 2) * 32 + (i & 3) * 4; }
+
+// linear form, pre-scaled by C2
 __device__ __forceinline__ void stage_pq(float2 *PQl, const float *Pg, const float *Qg, int n) {
     const float4 *p4 = reinterpret_cast<const float4 *>(Pg);
     const float4 *q4 = reinterpret_cast<const float4 *>(Qg);
+    float *dl = reinterpret_cast<float *>(PQl);
     for (int i = threadIdx.x; i < n * 4; i += EDGE_THREADS) {
         const float4 pp = p4[i], qq = q4[i];
-        float4 *d = reinterpret_cast<float4 *>(PQl + i * 4);       // 4 consecutive (P,Q) pairs = 32 B
-        d[0] = make_float4(C2 * pp.x, C2 * pp.y, C2 * qq.x, C2 * qq.y);
-        d[1] = make_float4(C2 * pp.z, C2 * pp.w, C2 * qq.z, C2 * qq.w);
+        float *d = dl + pq_slot(i);
+        *reinterpret_cast<float4 *>(d) = make_float4(C2 * pp.x, C2 * pp.y, C2 * pp.z, C2 * pp.w);
+        *reinterpret_cast<float4 *>(d + 16) = make_float4(C2 * qq.x, C2 * qq.y, C2 * qq.z, C2 * qq.w);
     }
 }
 
@@ -121,15 +128,15 @@ constexpr float EF_LIMIT = 56.f, EF_BIAS_LIMIT = 6.f;
 // finite: 2 (2 EF_LIMIT_FWD + EF_BIAS_LIMIT) < 127.
 constexpr float EF_LIMIT_FWD = 28.f;
 
-// writes the exp form of P/Q floats [4i, 4i+4) of the slice; returns the largest |C2 P|, |C2 Q| seen
+// writes the exp form of float4 i of both row halves of the slice; returns the largest |C2 x| seen
 __device__ __forceinline__ float put_pq_exp(float2 *PQl, int i, const float4 &pp, const float4 &qq) {
     const float ax = C2 * pp.x, ay = C2 * pp.y, az = C2 * pp.z, aw = C2 * pp.w;
     const float bx = C2 * qq.x, by = C2 * qq.y, bz = C2 * qq.z, bw = C2 * qq.w;
-    float4 *d = reinterpret_cast<float4 *>(PQl + i * 4);
-    d[0] = make_float4(__builtin_amdgcn_exp2f(ax), __builtin_amdgcn_exp2f(ay), __builtin_amdgcn_exp2f(bx),
-                       __builtin_amdgcn_exp2f(by));
-    d[1] = make_float4(__builtin_amdgcn_exp2f(az), __builtin_amdgcn_exp2f(aw), __builtin_amdgcn_exp2f(bz),
-                       __builtin_amdgcn_exp2f(bw));
+    float *d = reinterpret_cast<float *>(PQl) + pq_slot(i);
+    *reinterpret_cast<float4 *>(d) = make_float4(__builtin_amdgcn_exp2f(ax), __builtin_amdgcn_exp2f(ay), __builtin_amdgcn_exp2f(az),
+                                                 __builtin_amdgcn_exp2f(aw));
+    *reinterpret_cast<float4 *>(d + 16) = make_float4(__builtin_amdgcn_exp2f(bx), __builtin_amdgcn_exp2f(by), __builtin_amdgcn_exp2f(bz),
+                                                      __builtin_amdgcn_exp2f(bw));
     return fmaxf(fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fmaxf(fabsf(az), fabsf(aw))),
                  fmaxf(fmaxf(fabsf(bx), fabsf(by)), fmaxf(fabsf(bz), fabsf(bw))));
 }
@@ -186,9 +193,9 @@ __device__ __forceinline__ void fold_load_x(const FoldArgs &fa, int64_t M, int64
 
 __device__ __forceinline__ void fold_load_w(const FoldArgs &fa, int p, bool h, FoldOps &ops) {
     const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
-    // weight row behind LDS float r of a node.  P/Q tile: pair q = r / 4 holds [P_2q, P_2q+1, Q_2q, Q_2q+1] (Wcat rows
-    // in P/Q panel order: 32 p + 16 side + column); H tile: column r (< 16; the upper half of the tile is discarded)
-    const int wrow = h ? 16 * p + (r & 15) : 32 * p + 16 * ((r >> 1) & 1) + 2 * (r >> 2) + (r & 1);
+    // weight row behind LDS float r of a node.  P/Q tile: pair q = r / 4 holds [P_2q, P_2q+1, Q_2q, Q_2q+1] and the rows of
+    // W1c are in the same pair order (kernels.h): row 32 p + r; H tile: column r (< 16; the upper half of the tile is discarded)
+    const int wrow = h ? 16 * p + (r & 15) : 32 * p + r;
     const float4 *w4 = reinterpret_cast<const float4 *>((h ? fa.We : fa.W1c) + (int64_t)wrow * 32 + 12 * kh);
 #pragma unroll
     for (int q = 0; q < 3; ++q) ops.wa[q] = w4[q];
@@ -443,9 +450,8 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     // (P_ca, P_ca+1, Q_ca, Q_ca+1) of node u: exp form or scaled linear form
     auto pq4 = [&](int u) -> float4 {
         if (STAGE) return *reinterpret_cast<const float4 *>(L.PQ + u * 16 + ca);
-        const float2 pp = *reinterpret_cast<const float2 *>(Pg + u * 16 + ca);
-        const float2 qq = *reinterpret_cast<const float2 *>(Qg + u * 16 + ca);
-        return make_float4(C2 * pp.x, C2 * pp.y, C2 * qq.x, C2 * qq.y);
+        const float4 x = *reinterpret_cast<const float4 *>(((lane & 4) ? Qg : Pg) + u * 16 + 4 * (lane & 3));      // pair order
+        return make_float4(C2 * x.x, C2 * x.y, C2 * x.z, C2 * x.w);
     };
     float2 sumS = make_float2(0.f, 0.f), sumH = make_float2(0.f, 0.f);
     auto walk = [&](auto efc) {
@@ -772,9 +778,8 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     }
     auto pq4 = [&](int u) -> float4 {
         if (STAGE) return *reinterpret_cast<const float4 *>(L.PQ + u * 16 + ca);
-        const float2 pp = *reinterpret_cast<const float2 *>(Pg + u * 16 + ca);
-        const float2 qq = *reinterpret_cast<const float2 *>(Qg + u * 16 + ca);
-        return make_float4(C2 * pp.x, C2 * pp.y, C2 * qq.x, C2 * qq.y);
+        const float4 x = *reinterpret_cast<const float4 *>(((lane & 4) ? Qg : Pg) + u * 16 + 4 * (lane & 3));      // pair order
+        return make_float4(C2 * x.x, C2 * x.y, C2 * x.z, C2 * x.w);
     };
     auto ds2 = [&](int u) -> float2 {
         if (STAGE) return *reinterpret_cast<const float2 *>(L.X + u * 16 + ca);
@@ -839,8 +844,9 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             }
             if (valid) {
                 const float2 dP = make_float2(2.f * aP0, 2.f * aP1), dQ = make_float2(2.f * aQ0, 2.f * aQ1);     // 1/2 * 4
-                *reinterpret_cast<float2 *>(dPQ + ((int64_t)(2 * p) * M + o + v) * 16 + ca) = dP;
-                *reinterpret_cast<float2 *>(dPQ + ((int64_t)(2 * p + 1) * M + o + v) * 16 + ca) = dQ;
+                // pair order: (dP_ca, dP_ca+1, dQ_ca, dQ_ca+1) is chunk (lane & 3) of the node's row in panel 2p + ((lane >> 2) & 1)
+                *reinterpret_cast<float4 *>(dPQ + ((int64_t)(2 * p + ((lane >> 2) & 1)) * M + o + v) * 16 + 4 * (lane & 3)) =
+                    make_float4(dP.x, dP.y, dQ.x, dQ.y);
                 sumdP.x += dP.x; sumdP.y += dP.y;
                 sumdQ.x += dQ.x; sumdQ.y += dQ.y;
             }
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     };
     if (ef) walk(std::true_type{});
     else walk(std::false_type{});
-    // per-graph column sums of dP and dQ (bias gradient = sum dP; layer 1 also needs sum dQ), P/Q panel order
+    // per-graph column sums of dP and dQ (bias gradient = sum dP; layer 1 also needs sum dQ), P/Q pair order
 #pragma unroll
     for (int sft = 8; sft <= 32; sft <<= 1) {
         sumdP.x += __shfl_xor(sumdP.x, sft); sumdP.y += __shfl_xor(sumdP.y, sft);
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         float tot = 0.f;
 #pragma unroll
         for (int q = 0; q < EDGE_WAVES; ++q) tot += L.red[(q * 2 + which) * 16 + cc];
-        dbias_part[(int64_t)b * (NP * 32) + (2 * p + which) * 16 + cc] = tot;
+        dbias_part[(int64_t)b * (NP * 32) + p * 32 + pq_pos(which, cc)] = tot;
     }
 }
 

@@ -814,9 +814,9 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restr
     } else if (mode == 1) {
         dst[(int64_t)j * ldd + i] += acc;
     } else {
-        // slab row i = permuted P/Q column j' of the layer; slab col j = input feature k
-        const int row = (i >> 5) * 16 + (i & 15);
-        const int half = (i >> 4) & 1;
+        // slab row i = P/Q position (pair order, kernels.h) of the layer; slab col j = input feature k
+        const int row = pq_col(i);
+        const int half = pq_side(i);
         dst[(int64_t)row * ldd + half * J + j] += acc;
     }
 }

@@ -17,6 +17,16 @@
 
 namespace upamd {
 
+// "Pair order" of the 2D P | Q columns of a GCN layer (rows of Wcat, columns of PQ / dPQ, entries of the bias partial sums):
+// position c' = 32 p + 4 j + t holds   P column 16 p + 2 j + t (t = 0, 1)   or   Q column 16 p + 2 j + (t - 2) (t = 2, 3).
+// In the panel-major PQ tensor the 16 floats of a node in panel 2p (2p + 1) are then exactly the LDS image the
+// message-passing walk wants for column pairs 0..3 (4..7): [P_2j, P_2j+1, Q_2j, Q_2j+1] per 16-byte chunk, so the edge
+// kernels stage a slice with plain 16-byte copies (LDS-DMA) and write dP | dQ of two columns with one 16-byte store.
+__host__ __device__ inline int pq_col(int cp) { return (cp >> 5) * 16 + ((cp >> 2) & 7) * 2 + (cp & 1); }
+__host__ __device__ inline int pq_side(int cp) { return (cp >> 1) & 1; }      // 0 = P (Wa), 1 = Q (Wb)
+// position of (side, column)
+__host__ __device__ inline int pq_pos(int side, int col) { return (col >> 4) * 32 + ((col >> 1) & 7) * 4 + side * 2 + (col & 1); }
+
 struct PackedView {   // device pointers into the packed replay (upamd_pack_layout)
     const int32_t *meta;
     const float *X;
@@ -95,14 +105,14 @@ bool tn_shape_mfma_ok(int I, int J);       // the tiled split-K kernel handles I
 int launch_gemm_tn(const float *A, int I, const float *Bm, int J, int64_t M, float *slabs, int *S_out,
                    hipStream_t st, Profiler *prof);
 // dst (+)= sum_s slabs[s]:  mode 0: dst[i*ldd + j], j < jkeep;  mode 1: dst[j*ldd + i];
-// mode 2: GCN un-permute, slab row j' -> dst[((j'/32)*16 + j'%16)*ldd + ((j'/16)&1)*J + k]
+// mode 2: GCN un-permute, slab row j' (P/Q pair order) -> dst[pq_col(j')*ldd + pq_side(j')*J + k]
 int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int jkeep, float *dst, int ldd,
                         hipStream_t st, float *last_col_dst = nullptr);
 
 // ---- graph.hip -------------------------------------------------------------------------
 __host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds = true);
 // First GCN layer folded into the message-passing stage-in (edge.hip: fold_fill): the workgroup computes its P/Q (and
-// H_0) slice from the raw node features.  Xp: panel-major [2][M][16]; W1c = Wcat_1 We [2D][32] (rows in P/Q panel
+// H_0) slice from the raw node features.  Xp: panel-major [2][M][16]; W1c = Wcat_1 We [2D][32] (rows in P/Q pair
 // order), b1c [2D]; We (zero-padded) [D][32], be [D].
 struct FoldArgs {
     const float *Xp, *W1c, *b1c, *We, *be;
