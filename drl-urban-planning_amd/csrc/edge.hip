@@ -36,7 +36,8 @@ constexpr int EDGE_THREADS = 1024;
 constexpr int EDGE_WAVES = EDGE_THREADS / 64;
 constexpr int64_t LDS_LIMIT = 160 * 1024 - 1024;      // dynamic LDS a launch may ask for (the kernels also own 256 static bytes)
 constexpr int64_t LDS_HALF = 80 * 1024 - 2048;       // two workgroups per CU (with slack for the allocation granularity)
-constexpr float C2 = 2.8853900817779268f;      // 2 * log2(e)
+constexpr int64_t LDS_HALF_HARD = 80 * 1024 - 512;   // ... with next to no slack (256 static bytes + rounding): the DHM size class
+constexpr float C2 = PQ_C2;                    // 2 * log2(e)
 
 __device__ __forceinline__ float rcp1p_exp2(float x) {      // 1 / (1 + 2^x)
     return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x) + 1.0f);
@@ -44,13 +45,13 @@ __device__ __forceinline__ float rcp1p_exp2(float x) {      // 1 / (1 + 2^x)
 
 __host__ __device__ static inline int64_t a16(int64_t x) { return (x + 15) / 16 * 16; }
 
-__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds) {
+__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds, bool nblds) {
     (void)last;
     int64_t b = 0;
     if (stage) b += (int64_t)max_n * (hlds ? 192 : 128);      // P/Q interleaved (128 B/node) + H or dS (64 B/node)
     b = a16(b);
     b += a16(((int64_t)max_n + 1) * 4);                       // row_ptr
-    b += a16((int64_t)max_inc * 2);                           // neighbour ids (u16)
+    if (nblds) b += a16((int64_t)max_inc * 2);                // neighbour ids (u16)
     b += a16((int64_t)max_n * 2);                             // processing order (u16)
     if (!bwd) b += a16(max_n);                                // node_mask bytes
     b += EDGE_WAVES * 2 * 16 * 4;                             // cross-wave reduction scratch
@@ -79,7 +80,7 @@ struct EdgeLds {
     unsigned char *aux;   // last layer: the row's candidate-edge lists (sized by the launcher from the spare LDS)
 };
 
-__device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool stage, bool bwd, bool hlds = true) {
+__device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool stage, bool bwd, bool hlds = true, bool nblds = true) {
     EdgeLds L;
     int64_t o = 0;
     L.PQ = reinterpret_cast<float2 *>(smem);
@@ -87,7 +88,7 @@ __device__ __forceinline__ EdgeLds carve(unsigned char *smem, int n, int e, bool
     if (stage) o = (int64_t)n * (hlds ? 192 : 128);
     o = (o + 15) / 16 * 16;
     L.rp = reinterpret_cast<int *>(smem + o); o += (((int64_t)n + 1) * 4 + 15) / 16 * 16;
-    L.nb = reinterpret_cast<uint16_t *>(smem + o); o += ((int64_t)e * 4 + 15) / 16 * 16;
+    L.nb = reinterpret_cast<uint16_t *>(smem + o); if (nblds) o += ((int64_t)e * 4 + 15) / 16 * 16;
     L.ord = reinterpret_cast<uint16_t *>(smem + o); o += ((int64_t)n * 2 + 15) / 16 * 16;
     L.nm = reinterpret_cast<uint8_t *>(smem + o);
     if (!bwd) o += ((int64_t)n + 15) / 16 * 16;
@@ -154,6 +155,103 @@ __device__ __forceinline__ bool stage_pq_exp(float2 *PQl, const float *Pg, const
 // trips (P/Q twice, H twice, row pointers, neighbour ids, order/mask).  When the slice fits two trips per thread
 // (n <= 512 nodes, e <= 2048 edges) every load is issued into registers first and only then committed to LDS.
 __device__ __forceinline__ bool fits_batched(int n, int e) { return n * 4 <= 2 * EDGE_THREADS && e <= 2 * EDGE_THREADS; }
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA stage-in (round 3).  With the P/Q tensor in pair order and already in exp form (the node GEMM's epilogue writes
+// 2^(C2 x) block by block, kernels.h: PQ_EXP_LIMIT) the slice a workgroup needs is a pure 16-byte-chunk copy: it goes
+// HBM -> LDS by global_load_lds_dwordx4 without touching a VGPR, the exponentials and the ds_write pass of the register
+// path are gone, and so is the 64-VGPR squeeze around them.  `pqflag` (one byte per 64 x 64 block of the GEMM output,
+// 1 = that block is in linear form) is read alongside; a workgroup that meets a linear block -- or a bias outside the
+// exp-form range -- converts its slice IN PLACE afterwards (dma_fixup: rare, slow, exact to ~3e-7).
+// ------------------------------------------------------------------------------------------
+// P/Q slice: wave-instruction t fills LDS bytes [1024 t, 1024 t + 1024) = nodes 8t .. 8t+7 (lane: node 8t + lane/8, chunk lane%8);
+// chunks 0..3 come from panel 2p (A), 4..7 from panel 2p + 1 (B).  Lanes of nodes >= n are masked off.
+__device__ __forceinline__ void dma_pq_slice(float2 *PQl, const float *Ag, const float *Bg, int n) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned char *l = reinterpret_cast<unsigned char *>(PQl);
+    for (int t = w; t < ((n + 7) >> 3); t += EDGE_WAVES) {
+        const int node = 8 * t + (lane >> 3);
+        if (node < n)
+            __builtin_amdgcn_global_load_lds((gptr_t)(((lane & 4) ? Bg : Ag) + node * 16 + 4 * (lane & 3)), (lptr_t)(l + t * 1024), 16, 0, 0);
+    }
+}
+// a 16-column slice (H or G: 64 B per node): wave-instruction t = nodes 16t .. 16t+15, lane: node 16t + lane/4, chunk lane%4
+__device__ __forceinline__ void dma_x_slice(float *Xl, const float *Xg, int n) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned char *l = reinterpret_cast<unsigned char *>(Xl);
+    for (int t = w; t < ((n + 15) >> 4); t += EDGE_WAVES) {
+        const int node = 16 * t + (lane >> 2);
+        if (node < n) __builtin_amdgcn_global_load_lds((gptr_t)(Xg + node * 16 + 4 * (lane & 3)), (lptr_t)(l + t * 1024), 16, 0, 0);
+    }
+}
+// 1 if any 64-row block of the GEMM output that this graph's rows [o, o + n) touch (column block of panel pair p) is linear
+__device__ __forceinline__ int dma_flags_bad(const uint8_t *pqflag, int nfb, int64_t o, int n, int p) {
+    const int64_t r0 = o >> 6;
+    const int nr = (int)(((o + n - 1) >> 6) - r0) + 1;
+    int bad = 0;
+    for (int i = threadIdx.x; i < nr; i += EDGE_THREADS) bad |= pqflag[(r0 + i) * nfb + (p >> 1)];
+    return bad;
+}
+// The slice in LDS is a raw copy with at least one linear block in it (or the bias is out of range): bring every float to
+// the linear form C2 x (exp-form blocks through log2), then back to exp form if the workgroup's own slice allows it.
+// Returns true when LDS holds the exp form.  Contains barriers: call from uniform control flow.
+__device__ __forceinline__ bool dma_fixup(float2 *PQl, const uint8_t *pqflag, int nfb, int64_t o, int n, int p, float limit, bool bias_ok) {
+    float4 *l4 = reinterpret_cast<float4 *>(PQl);
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < n * 8; i += EDGE_THREADS) {            // 16-byte chunk i: node i / 8
+        float4 v = l4[i];
+        if (pqflag[((o + (i >> 3)) >> 6) * nfb + (p >> 1)])
+            v = make_float4(C2 * v.x, C2 * v.y, C2 * v.z, C2 * v.w);
+        else
+            v = make_float4(__builtin_amdgcn_logf(v.x), __builtin_amdgcn_logf(v.y), __builtin_amdgcn_logf(v.z), __builtin_amdgcn_logf(v.w));
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        l4[i] = v;
+    }
+    const bool ef = !__syncthreads_or((mx <= limit && bias_ok) ? 0 : 1);
+    if (ef) {
+        for (int i = threadIdx.x; i < n * 8; i += EDGE_THREADS) {
+            const float4 v = l4[i];
+            l4[i] = make_float4(__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y), __builtin_amdgcn_exp2f(v.z), __builtin_amdgcn_exp2f(v.w));
+        }
+        __syncthreads();
+    }
+    return ef;
+}
+// the graph's lists (row pointers, neighbour ids, processing order, node-mask bytes) through registers: up to three neighbour
+// words, one entry of the others per thread, all requested before anything is committed (one round trip)
+struct ListRegs {
+    uint32_t nb0, nb1, nb2, ord, nm;
+    int rp;
+};
+__device__ __forceinline__ void lists_load(ListRegs &r, const int32_t *rpg, const uint32_t *nbg, const uint16_t *og, const uint8_t *nmg,
+                                           int n, int e) {
+    const int tid = threadIdx.x;
+    r.nb0 = nbg[tid < e ? tid : 0];
+    r.nb1 = nbg[tid + EDGE_THREADS < e ? tid + EDGE_THREADS : 0];
+    r.nb2 = nbg[tid + 2 * EDGE_THREADS < e ? tid + 2 * EDGE_THREADS : 0];
+    r.rp = rpg[tid <= n ? tid : 0];
+    r.ord = og[tid < n ? tid : 0];
+    r.nm = nmg ? nmg[tid < n ? tid : 0] : 0;
+}
+__device__ __forceinline__ void lists_commit(const ListRegs &r, const EdgeLds &L, const int32_t *rpg, const uint32_t *nbg, const uint16_t *og,
+                                             const uint8_t *nmg, int n, int e) {
+    const int tid = threadIdx.x;
+    uint32_t *nb32 = reinterpret_cast<uint32_t *>(L.nb);
+    if (tid < e) nb32[tid] = r.nb0;
+    if (tid + EDGE_THREADS < e) nb32[tid + EDGE_THREADS] = r.nb1;
+    if (tid + 2 * EDGE_THREADS < e) nb32[tid + 2 * EDGE_THREADS] = r.nb2;
+    for (int i = tid + 3 * EDGE_THREADS; i < e; i += EDGE_THREADS) nb32[i] = nbg[i];
+    if (tid <= n) L.rp[tid] = r.rp;
+    if (tid < n) {
+        L.ord[tid] = (uint16_t)r.ord;
+        if (nmg) L.nm[tid] = (uint8_t)r.nm;
+    }
+    for (int i = tid + EDGE_THREADS; i <= n; i += EDGE_THREADS) L.rp[i] = rpg[i];
+    for (int i = tid + EDGE_THREADS; i < n; i += EDGE_THREADS) {
+        L.ord[i] = og[i];
+        if (nmg) L.nm[i] = nmg[i];
+    }
+}
 
 __device__ __forceinline__ float rcp1p_mul(float a, float b) {      // 1 / (1 + a*b)
     return __builtin_amdgcn_rcpf(fmaf(a, b, 1.0f));
@@ -312,16 +410,20 @@ __device__ __forceinline__ float fold_fill(const FoldArgs &fa, int64_t M, int64_
 // ------------------------------------------------------------------------------------------
 // HLDS = false (staged P/Q, H left in HBM): the forward needs H only for the residual add at the end of a node's walk, so a
 // graph whose slice is too big for two workgroups per CU WITH H (> ~350 nodes: the DHM-sized graphs) still fits without it.
-template <bool LAST, bool STAGE, bool FOLD, bool HLDS = true>
+// DMA = the LDS-DMA stage-in (the P/Q tensor carries exp-form flags); a template parameter so that the register-staged
+// path and its 24 staging VGPRs do not exist in those instantiations.
+template <bool LAST, bool STAGE, bool FOLD, bool HLDS = true, bool DMA = false>
 __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), amdgpu_waves_per_eu(8, 8))) void edge_fwd_kernel(PackedView pk, MbView mb, int NP,
                                                                 const float *__restrict__ PQ,
                                                                 const float *__restrict__ bias,
                                                                 const float *__restrict__ Hin, float *__restrict__ Hout,
                                                                 float *__restrict__ hbarV, float *__restrict__ hbarE,
                                                                 const float *__restrict__ Ccur, float *__restrict__ FE,
-                                                                int aux_cap, int fit, FoldArgs fa, int fe_full) {
+                                                                int aux_cap, int fit, FoldArgs fa, int fe_full,
+                                                                const uint8_t *__restrict__ pqflag, int nfb) {
     static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
     static_assert(HLDS || (STAGE && !FOLD), "H stays in HBM only next to a staged (not folded) P/Q slice");
+    static_assert(!DMA || (STAGE && !FOLD), "the LDS-DMA stage-in belongs to the staged, not folded kernels");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
     const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;      // one scalar load: meta row + minibatch offsets
@@ -378,6 +480,16 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         }
         const float mx = fold_end<true>(fa, M, o, n, p, role, ops, L.PQ, L.X, true);
         ok = mx <= EF_LIMIT_FWD && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+    } else if (DMA) {
+        // LDS-DMA stage-in: the slices as raw 16-byte chunks, the lists through registers, one round trip for everything
+        dma_pq_slice(L.PQ, Pg, Qg, n);
+        if (HLDS) dma_x_slice(L.X, Hg, n);
+        ListRegs lr;
+        lists_load(lr, rpg, nbg, og, nmg, n, e);
+        const int bad = dma_flags_bad(pqflag, nfb, o, n, p);
+        lists_commit(lr, L, rpg, nbg, og, nmg, n, e);
+        wait_vmcnt<0>();                                   // this wave's DMA has landed (the barrier below covers the others')
+        ok = !bad && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
     } else if (STAGE && fits_batched(n, e)) {
         const float4 *p4 = reinterpret_cast<const float4 *>(Pg), *q4 = reinterpret_cast<const float4 *>(Qg);
         const float4 *h4 = reinterpret_cast<const float4 *>(Hg);
@@ -439,9 +551,13 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     if (STAGE) {
         ef = !__syncthreads_or(ok ? 0 : 1);
         if (!ef) {                         // magnitudes outside the exp-form range: linear form, exponentials in the loop
-            if (FOLD) fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, false);
-            else stage_pq(L.PQ, Pg, Qg, n);
-            __syncthreads();
+            if (DMA) {
+                ef = dma_fixup(L.PQ, pqflag, nfb, o, n, p, EF_LIMIT_FWD, fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT);
+            } else {
+                if (FOLD) fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, false);
+                else stage_pq(L.PQ, Pg, Qg, n);
+                __syncthreads();
+            }
         }
     } else {
         __syncthreads();
@@ -451,6 +567,8 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     auto pq4 = [&](int u) -> float4 {
         if (STAGE) return *reinterpret_cast<const float4 *>(L.PQ + u * 16 + ca);
         const float4 x = *reinterpret_cast<const float4 *>(((lane & 4) ? Qg : Pg) + u * 16 + 4 * (lane & 3));      // pair order
+        if (pqflag && !pqflag[((o + u) >> 6) * nfb + (p >> 1)])     // the GEMM stored this block in exp form
+            return make_float4(__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y), __builtin_amdgcn_logf(x.z), __builtin_amdgcn_logf(x.w));
         return make_float4(C2 * x.x, C2 * x.y, C2 * x.z, C2 * x.w);
     };
     float2 sumS = make_float2(0.f, 0.f), sumH = make_float2(0.f, 0.f);
@@ -564,6 +682,8 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     }
 }
 
+static int g_bwd_nb_global = 1;  // tune knob "bwd_nb_global", see edge_bwd_kernel (NBG)
+void set_bwd_nb_global(int on) { g_bwd_nb_global = on ? 1 : 0; }
 static int g_fwd_h_hbm = 1;      // tune knob "fwd_h_hbm": the large size class of the forward keeps H in HBM (two workgroups per CU)
 void set_fwd_h_hbm(int on) { g_fwd_h_hbm = on ? 1 : 0; }
 
@@ -574,8 +694,10 @@ bool edge_fold_ok(const MbView &mb) {
 
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
-                    hipStream_t st, Profiler *prof, const FoldArgs *fold, int fe_full) {
+                    hipStream_t st, Profiler *prof, const FoldArgs *fold, int fe_full, const uint8_t *pqflag) {
     const int NP = D / 16;
+    const int nfb = 2 * D / 64;                // 64-column blocks of the P/Q GEMM's output
+    if (fold) pqflag = nullptr;                // (a folded layer's P/Q never comes from the GEMM)
     const FoldArgs fa = fold ? *fold : FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (fold && (last || !edge_fold_ok(mb)))
         return fail(UPAMD_E_LIMIT, "edge_fwd: the folded first layer needs the staged size class and a later layer behind it");
@@ -583,19 +705,20 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
     // one launch of a given (stage, lds, fit) configuration
     auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool hlds = true) -> int {
-#define UPAMD_EF(L_, S_, F_, H_)                                                                                      \
+#define UPAMD_EF(L_, S_, F_, H_, D_)                                                                                  \
     do {                                                                                                              \
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_, H_>), lds)) return rc_;  \
-        hipLaunchKernelGGL((edge_fwd_kernel<L_, S_, F_, H_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, \
-                           Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa, fe_full);                                  \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_, H_, D_>), lds)) return rc_;  \
+        hipLaunchKernelGGL((edge_fwd_kernel<L_, S_, F_, H_, D_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, \
+                           Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa, fe_full, pqflag, nfb);                     \
     } while (0)
-        if (fold) UPAMD_EF(false, true, true, true);
-        else if (last && stage && !hlds) UPAMD_EF(true, true, false, false);
-        else if (last && stage) UPAMD_EF(true, true, false, true);
-        else if (last) UPAMD_EF(true, false, false, true);
-        else if (stage && !hlds) UPAMD_EF(false, true, false, false);
-        else if (stage) UPAMD_EF(false, true, false, true);
-        else UPAMD_EF(false, false, false, true);
+        const bool dma = pqflag != nullptr;
+        if (fold) UPAMD_EF(false, true, true, true, false);
+        else if (last && stage && !hlds) { if (dma) UPAMD_EF(true, true, false, false, true); else UPAMD_EF(true, true, false, false, false); }
+        else if (last && stage) { if (dma) UPAMD_EF(true, true, false, true, true); else UPAMD_EF(true, true, false, true, false); }
+        else if (last) UPAMD_EF(true, false, false, true, false);
+        else if (stage && !hlds) { if (dma) UPAMD_EF(false, true, false, false, true); else UPAMD_EF(false, true, false, false, false); }
+        else if (stage) { if (dma) UPAMD_EF(false, true, false, true, true); else UPAMD_EF(false, true, false, true, false); }
+        else UPAMD_EF(false, false, false, true, false);
 #undef UPAMD_EF
         UPAMD_HIP(hipGetLastError());
         return 0;
@@ -642,7 +765,10 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
 // The pointer-head term touches only the row's candidate edges: it is added from the packer's per-node
 // candidate-incidence lists after the main walk, so the main loop stays branch-free.
 // ------------------------------------------------------------------------------------------
-template <bool LAST, bool STAGE, bool FOLD>
+// NBG: the neighbour ids are walked from global memory (L1 / L2 hits: every panel's workgroup of the graph reads the same
+// list, a node's ids are consecutive) instead of LDS.  Without the 4 e bytes of the list a DHM-sized graph (up to ~400 nodes)
+// fits HALF the LDS with P/Q and dS staged: two workgroups per CU instead of one for the backward's large size class.
+template <bool LAST, bool STAGE, bool FOLD, bool DMA = false, bool NBG = false>
 __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), amdgpu_waves_per_eu(8, 8))) void edge_bwd_kernel(PackedView pk, MbView mb, int NP,
                                                                 const float *__restrict__ PQ,
                                                                 const float *__restrict__ bias,
@@ -650,7 +776,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                                                                 const float *__restrict__ dhbarE, int ld_dhbarE,
                                                                 const float *__restrict__ dMhe, float *__restrict__ dPQ,
                                                                 float *__restrict__ dbias_part, int aux_cap, int fit,
-                                                                FoldArgs fa) {
+                                                                FoldArgs fa, const uint8_t *__restrict__ pqflag, int nfb) {
     static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
@@ -663,7 +789,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     const int64_t o = m[14], M = mb.M;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ca = 2 * (lane & 7), g = lane >> 3;      // this lane's two columns (ca, ca+1); node slot within the wave
-    const EdgeLds L = carve(smem, n, e, STAGE, true);
+    const EdgeLds L = carve(smem, n, e, STAGE, true, true, !NBG);
 
     const float *Pg = PQ + ((int64_t)(2 * p) * M + o) * 16;
     const float *Qg = PQ + ((int64_t)(2 * p + 1) * M + o) * 16;
@@ -672,9 +798,46 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     const uint32_t *nbg = reinterpret_cast<const uint32_t *>(pk.inc_nbr + 2 * (int64_t)m[10]);
     const uint16_t *og = pk.order + m[9];
     const float2 bc = make_float2(C2 * bias[p * 16 + ca], C2 * bias[p * 16 + ca + 1]);
-    const bool batched = STAGE && fits_batched(n, e);
+    static_assert(!DMA || (STAGE && !FOLD), "the LDS-DMA stage-in belongs to the staged, not folded kernels");
+    static_assert(!NBG || DMA, "the list-in-global walk is built on the LDS-DMA stage-in");
+    constexpr bool dma = DMA;                                  // LDS-DMA stage-in (see dma_pq_slice)
+    const bool batched = STAGE && !dma && fits_batched(n, e);
     bool ok = false;
-    if (batched) {
+    if (dma) {
+        dma_pq_slice(L.PQ, Pg, Qg, n);
+        dma_x_slice(L.X, Gg, n);                               // raw G; turned into dS in place below
+        ListRegs lr;
+        lists_load(lr, rpg, nbg, og, nullptr, n, NBG ? 0 : e);
+        // degrees of the G rows whose chunks THIS lane has requested (wave-instruction t = w, w + 16: node 16 t + lane / 4)
+        const int v0 = 16 * w + (lane >> 2), v1 = v0 + 16 * EDGE_WAVES;
+        const int d00 = rpg[v0 < n ? v0 : 0], d01 = rpg[v0 < n ? v0 + 1 : 0];
+        const int d10 = rpg[v1 < n ? v1 : 0], d11 = rpg[v1 < n ? v1 + 1 : 0];
+        float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);          // the lane's four columns are the same on every trip
+        if (LAST) {
+            const float4 dh = *reinterpret_cast<const float4 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + (tid & 3) * 4);
+            ex4 = make_float4(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e, 0.5f * dh.z / (float)e, 0.5f * dh.w / (float)e);
+        }
+        const int bad = dma_flags_bad(pqflag, nfb, o, n, p);
+        lists_commit(lr, L, rpg, nbg, og, nullptr, n, NBG ? 0 : e);
+        wait_vmcnt<0>();                                       // this wave's DMA has landed: its own chunks may be rewritten
+        float4 *x4 = reinterpret_cast<float4 *>(L.X);
+        if (v0 < n) {
+            const float inv = __builtin_amdgcn_rcpf((float)(d01 - d00) + 1e-6f);
+            const float4 g0 = x4[4 * v0 + (lane & 3)];
+            x4[4 * v0 + (lane & 3)] = make_float4(fmaf(g0.x, inv, ex4.x), fmaf(g0.y, inv, ex4.y), fmaf(g0.z, inv, ex4.z), fmaf(g0.w, inv, ex4.w));
+        }
+        if (v1 < n) {
+            const float inv = __builtin_amdgcn_rcpf((float)(d11 - d10) + 1e-6f);
+            const float4 g1 = x4[4 * v1 + (lane & 3)];
+            x4[4 * v1 + (lane & 3)] = make_float4(fmaf(g1.x, inv, ex4.x), fmaf(g1.y, inv, ex4.y), fmaf(g1.z, inv, ex4.z), fmaf(g1.w, inv, ex4.w));
+        }
+        for (int v = v1 + 16 * EDGE_WAVES; v < n; v += 16 * EDGE_WAVES) {      // graphs above 512 nodes
+            const float inv = __builtin_amdgcn_rcpf((float)(rpg[v + 1] - rpg[v]) + 1e-6f);
+            const float4 gg = x4[4 * v + (lane & 3)];
+            x4[4 * v + (lane & 3)] = make_float4(fmaf(gg.x, inv, ex4.x), fmaf(gg.y, inv, ex4.y), fmaf(gg.z, inv, ex4.z), fmaf(gg.w, inv, ex4.w));
+        }
+        ok = !bad && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
+    } else if (batched) {
         // one memory round trip (see fits_batched): P/Q, G, the degrees of the G rows, the lists -- then commit
         const float4 *p4 = reinterpret_cast<const float4 *>(Pg), *q4 = reinterpret_cast<const float4 *>(Qg);
         const float4 *g4 = reinterpret_cast<const float4 *>(Gg);
@@ -742,15 +905,19 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     }
     bool ef = false;                       // LDS holds the exp form (workgroup-uniform), see stage_pq_exp
     if (STAGE) {
-        if (!batched) {
+        if (!batched && !dma) {
             if (FOLD) ok = fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, true) <= EF_LIMIT && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
             else ok = stage_pq_exp(L.PQ, Pg, Qg, n) && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
         }
         ef = !__syncthreads_or(ok ? 0 : 1);
         if (!ef) {
-            if (FOLD) fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, false);
-            else stage_pq(L.PQ, Pg, Qg, n);
-            __syncthreads();
+            if (dma) {
+                ef = dma_fixup(L.PQ, pqflag, nfb, o, n, p, EF_LIMIT, fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT);
+            } else {
+                if (FOLD) fold_fill<false>(fa, M, o, n, p, L.PQ, L.X, false);
+                else stage_pq(L.PQ, Pg, Qg, n);
+                __syncthreads();
+            }
         }
     } else {
         __syncthreads();
@@ -760,7 +927,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         const float2 dh = *reinterpret_cast<const float2 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + ca);
         extra = make_float2(0.5f * dh.x / (float)e, 0.5f * dh.y / (float)e);
     }
-    if (STAGE && !batched) {
+    if (STAGE && !batched && !dma) {
         float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);       // the thread's four columns are the same on every trip
         if (LAST) {
             const float4 dh = *reinterpret_cast<const float4 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + (tid & 3) * 4);
@@ -779,6 +946,8 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     auto pq4 = [&](int u) -> float4 {
         if (STAGE) return *reinterpret_cast<const float4 *>(L.PQ + u * 16 + ca);
         const float4 x = *reinterpret_cast<const float4 *>(((lane & 4) ? Qg : Pg) + u * 16 + 4 * (lane & 3));      // pair order
+        if (pqflag && !pqflag[((o + u) >> 6) * nfb + (p >> 1)])     // the GEMM stored this block in exp form
+            return make_float4(__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y), __builtin_amdgcn_logf(x.z), __builtin_amdgcn_logf(x.w));
         return make_float4(C2 * x.x, C2 * x.y, C2 * x.z, C2 * x.w);
     };
     auto ds2 = [&](int u) -> float2 {
@@ -816,8 +985,16 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                 aP1 = fmaf(dm1, fmaf(-r3, r3, r3), aP1);
                 aQ1 = fmaf(dm1, fmaf(-r4, r4, r4), aQ1);
             };
+            const uint16_t *nb16 = reinterpret_cast<const uint16_t *>(nbg);
+            int un = NBG ? nb16[k < k1 ? k : 0] : 0;           // (NBG: the next id is requested one trip ahead)
             for (; k < k1; ++k) {
-                const int u = L.nb[k];
+                int u;
+                if (NBG) {
+                    u = un;
+                    un = nb16[k + 1 < k1 ? k + 1 : k];
+                } else {
+                    u = L.nb[k];
+                }
                 const float2 su = ds2(u);
                 add(pq4(u), sv.x + su.x, sv.y + su.y);
             }
@@ -876,25 +1053,32 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
 
 int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
-                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold) {
+                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold, const uint8_t *pqflag) {
     const int NP = D / 16;
+    const int nfb = 2 * D / 64;
+    if (fold) pqflag = nullptr;
     const FoldArgs fa = fold ? *fold : FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (fold && (last || !edge_fold_ok(mb)))
         return fail(UPAMD_E_LIMIT, "edge_bwd: the folded first layer needs the staged size class and a later layer behind it");
     const int began = prof_begin(prof, "edge_bwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
-    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit) -> int {
-#define UPAMD_EB(L_, S_, F_)                                                                                          \
+    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool nbg = false) -> int {
+#define UPAMD_EB(L_, S_, F_, D_, N_)                                                                                  \
     do {                                                                                                              \
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_, F_>), lds)) return rc_;  \
-        hipLaunchKernelGGL((edge_bwd_kernel<L_, S_, F_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G,      \
-                           dhbarE, ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit, fa);                               \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_, F_, D_, N_>), lds)) return rc_;  \
+        hipLaunchKernelGGL((edge_bwd_kernel<L_, S_, F_, D_, N_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G,  \
+                           dhbarE, ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit, fa, pqflag, nfb);                  \
     } while (0)
-        if (fold) UPAMD_EB(false, true, true);
-        else if (last && stage) UPAMD_EB(true, true, false);
-        else if (last) UPAMD_EB(true, false, false);
-        else if (stage) UPAMD_EB(false, true, false);
-        else UPAMD_EB(false, false, false);
+        const bool dma = pqflag != nullptr;
+        if (nbg) {
+            if (last) UPAMD_EB(true, true, false, true, true);
+            else UPAMD_EB(false, true, false, true, true);
+        } else
+        if (fold) UPAMD_EB(false, true, true, false, false);
+        else if (last && stage) { if (dma) UPAMD_EB(true, true, false, true, false); else UPAMD_EB(true, true, false, false, false); }
+        else if (last) UPAMD_EB(true, false, false, false, false);
+        else if (stage) { if (dma) UPAMD_EB(false, true, false, true, false); else UPAMD_EB(false, true, false, false, false); }
+        else UPAMD_EB(false, false, false, false, false);
 #undef UPAMD_EB
         UPAMD_HIP(hipGetLastError());
         return 0;
@@ -913,7 +1097,10 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     } else {                                                      // size classes, see launch_edge_fwd
         rc = go(true, LDS_HALF, -1, (int)LDS_HALF);
         if (rc == 0) {
-            if (lds_max <= LDS_LIMIT) {
+            const int64_t lds_nonb = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, true, true, false);
+            if (pqflag && g_bwd_nb_global && lds_nonb <= LDS_HALF_HARD) {
+                rc = go(true, lds_nonb, -1, -(int)LDS_HALF, true);      // neighbour ids from global memory: still two per CU
+            } else if (lds_max <= LDS_LIMIT) {
                 rc = go(true, lds_max, -1, -(int)LDS_HALF);
             } else {
                 const int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, false);

@@ -67,7 +67,8 @@ enum Slot : int {
     S_EWT = S_EA + MAXL * (MAXK + 1),     // + lk, k = 1 .. K-1: W_k^T
     S_EBP = S_EWT + MAXL * (MAXK + 1),    // + lk, k = 1 .. K-1: per-graph column sums of dpre_k+1 [B, D] (bias gradient of linear_k)
     S_ESLAB = S_EBP + MAXL * (MAXK + 1),  // + lk, k = 1 .. K-1: split-K slabs of dW_k
-    S_COUNT = S_ESLAB + MAXL * (MAXK + 1)
+    S_PQF = S_ESLAB + MAXL * (MAXK + 1),  // + l (1 .. L): bytes, exp-form flags of the layer's P/Q GEMM output (kernels.h: PQ_EXP_LIMIT)
+    S_COUNT = S_PQF + MAXL + 1
 };
 
 struct Plan {
@@ -158,6 +159,7 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     add(S_C, B * D);
     for (int l = 0; l <= x.L; ++l) add(S_H + l, M * D);
     for (int l = 1; l <= x.L; ++l) add(S_PQ + l, M * 2 * D);
+    for (int l = 1; l <= x.L; ++l) add(S_PQF + l, (gemm_exp_flag_bytes(M, 2 * D) + 3) / 4);
     add(S_HBARV, B * D); add(S_HBARE, B * D);
     add(S_Q0, B * D); add(S_Q1, B * D); add(S_R, B * x.heads * D); add(S_ALPHA, (int64_t)x.heads * M);
     add(S_S, B * x.heads * D); add(S_O, B * D); add(S_ATT, B * D);
@@ -321,6 +323,18 @@ static int debug_sync(const char *what) {
         }                                          \
     } while (0)
 
+// tune knob "pq_exp" (default on): the P/Q GEMMs of layers 2 .. L store their output in exp form (flagged block by block)
+// and the message-passing kernels stage it by LDS-DMA (edge.hip: dma_pq_slice)
+static int g_pq_exp = 1;
+// the P/Q product of layer l as launched by the forward; the backward re-derives the same decision from it
+static GemmNT pq_gemm(const float *H, int64_t M, int D, const float *Wcat, float *PQ) {
+    GemmNT g;
+    g.A = H; g.M = M; g.K = D; g.lda = 0; g.a_rm = false; g.W = Wcat; g.N = 2 * D; g.ldw = D; g.bias = nullptr; g.R = nullptr;
+    g.C = PQ; g.ldc = 0; g.c_rm = false; g.act_tanh = 0; g.alpha = 1.f;
+    return g;
+}
+static bool pq_exp_layer(const GemmNT &g, int l, int K) { return g_pq_exp && K == 1 && l >= 2 && gemm_nt_exp_store_ok(g); }
+
 // slabs[s][I][J] = partial sums of A[rows, I](pm)^T * Bm[rows, J](pm): the tiled split-K MFMA kernel where the shape allows
 // (I % 128 == 0), otherwise one grouped-kernel launch with panel-major operands (narrow models: D = 16 ... 64)
 // tune knob "fold_layer1" (default on): first GCN layer computed inside the message-passing kernels
@@ -431,6 +445,7 @@ int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch
 }  // namespace
 
 void upamd::set_fold_layer1(int on) { g_fold_layer1 = on ? 1 : 0; }
+void upamd::set_pq_exp(int on) { g_pq_exp = on ? 1 : 0; }
 void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
 
 extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
@@ -707,10 +722,19 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         CK(launch_permute(pj, blocks, st));
     }
     for (int l = 1; l <= x.L; ++l) {
+        const uint8_t *pqflag = nullptr;        // != nullptr: this layer's P/Q is in exp form, block by block
         if (l == 1) {
             if (!fold) CK(launch_gemm_nt(W(S_XP), mb.M, 32, W(S_W1C), 2 * D, W(S_B1C), nullptr, W(S_PQ + 1), 0, st, prof));
         } else {
-            CK(launch_gemm_nt(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), 2 * D, nullptr, nullptr, W(S_PQ + l), 0, st, prof));
+            GemmNT g = pq_gemm(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), W(S_PQ + l));
+            bool used = false;
+            if (pq_exp_layer(g, l, x.K)) {
+                g.exp_flags = reinterpret_cast<uint8_t *>(W(S_PQF + l));
+                g.exp_used = &used;
+            }
+            CK(launch_gemm_nt_ex(g, st, prof));
+            if (g.exp_flags && !used) return fail(UPAMD_E_INVALID, "P/Q GEMM of layer %d did not take the exp-form store it was planned with", l);
+            if (used) pqflag = g.exp_flags;
         }
         if (forked && l == x.L) {                            // C (head inputs of the last layer), r, U, constb are ready
             CK(join_side(sc, st));
@@ -728,7 +752,7 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         }
         // the last layer also writes the land-use pointer-head inputs FE (needs C, computed above)
         CK(launch_edge_fwd(pk, mb, D, l == x.L, W(S_PQ + l), PR(P.edge_b[l - 1]), W(S_H + l - 1), W(S_H + l), W(S_HBARV), W(S_HBARE),
-                           W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, prof, (l == 1 && fold) ? &fa : nullptr, fe_full));
+                           W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, prof, (l == 1 && fold) ? &fa : nullptr, fe_full, pqflag));
     }
     // ---- 5. attention core, then the per-sample chain after it (out-projection, state_value, value head)
     CK(launch_attn_fwd(pk, mb, D, x.heads, W(S_H + x.L), W(S_R), W(S_ALPHA), W(S_S), st));
@@ -1081,9 +1105,13 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                 std::swap(cur, other);
             }
             CK(launch_inc_scatter_bwd(pk, mb, D, cur, grev, dPQ, W(S_DBIAS + l), st));
-        } else
-        CK(launch_edge_bwd(pk, mb, D, last, W(S_PQ + l), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp, (last && land) ? W(S_DMHE) : nullptr,
-                           dPQ, W(S_DBIAS + l), st, prof, (l == 1 && fold) ? &fa : nullptr));
+        } else {
+            // the forward's decision for this layer (same minibatch, same knobs): P/Q in exp form with block flags
+            const bool expf = l >= 2 && pq_exp_layer(pq_gemm(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), W(S_PQ + l)), l, x.K);
+            CK(launch_edge_bwd(pk, mb, D, last, W(S_PQ + l), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp, (last && land) ? W(S_DMHE) : nullptr,
+                               dPQ, W(S_DBIAS + l), st, prof, (l == 1 && fold) ? &fa : nullptr,
+                               expf ? reinterpret_cast<const uint8_t *>(W(S_PQF + l)) : nullptr));
+        }
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
         CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
         if (l > 1) {

@@ -201,8 +201,6 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_mfma_kernel(const float *__res
 //     halves, inline-asm reads with counted lgkmcnt, s_setprio, 32- and 64-wide chunks) measured no better and were removed.
 // Only the panel-major A / C, row-major [N][K] weight form (the dominant launches); everything else keeps the
 // register-staged kernel above.
-typedef __attribute__((address_space(1))) const void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
 
 // Every workgroup of a launch starts at the same instant and the tiles cost the same, so without help the co-resident
 // workgroups of a CU (and of the whole chip) run in lockstep: all of them stream their prologue, then all compute, then
@@ -227,11 +225,6 @@ __device__ __forceinline__ void first_wave_stagger(int mode, int cycles) {
     while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 // Workgroup tile (32 TM WM) x (32 TN WN), one (32 TM) x (32 TN) output block per wave.  128 x 128 with 64 x 64 per wave
 // (4 waves) is the measured optimum of the one-block-per-wave forms: 256 x 128 / 128 x 256 with EIGHT waves are 3-5 % slower,
 // 256 x 256 (16 waves on one barrier) 14 % (profiles/r02_gemm_lab.md).  TM / TN > 2 give a wave a bigger block instead (fewer
@@ -242,7 +235,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 4 ? 2 : 1)) void gemm_nt_d
                                                                     const float *__restrict__ bias,
                                                                     const float *__restrict__ R, float *__restrict__ C,
                                                                     int act_tanh, float alpha, int MT, int NT, int stagger_mode,
-                                                                    int stagger_cycles) {
+                                                                    int stagger_cycles, uint8_t *__restrict__ exp_flags) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
     constexpr int APANEL = BM * 16, STAGE = (BM + BN) * 16;      // floats: A panel then B panel
     constexpr int NI = (BM + BN) / 16;                           // 1 KiB LDS-DMA instructions per chunk
@@ -337,6 +330,30 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 4 ? 2 : 1)) void gemm_nt_d
             }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
+    if (TM == 2 && TN == 2 && exp_flags) {
+        // exp-form store (kernels.h: PQ_EXP_LIMIT): the wave's 64 x 64 block goes out as 2^(PQ_C2 x) when every |PQ_C2 x| of
+        // the block is within the limit, else unchanged with its flag raised.  Wave-local decision: no barrier; the VALU
+        // is ~13 % busy in this kernel, the 64 v_exp_f32 per lane are free.
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[i][j][r]));
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
+        const bool lin = !(mx * PQ_C2 <= PQ_EXP_LIMIT);       // (a NaN anywhere keeps the block linear)
+        if (lane == 0) exp_flags[(int64_t)(mt * (BM / 64) + wr) * (N >> 6) + (n0 >> 6) + wc] = lin ? 1 : 0;
+        if (!lin) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_amdgcn_exp2f(PQ_C2 * acc[i][j][r]);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int64_t gm = m0 + wr * 32 * TM + i * 32 + l31;
@@ -386,10 +403,31 @@ static int launch_nt_dma2(const GemmNT &g, hipStream_t st) {
     const size_t lds = sizeof(float) * 2 * (size_t)(BM + BN) * 16 + (size_t)g_lds_pad;
     auto kern = gemm_nt_dma2_kernel<WM, WN, TM, TN, PRIO>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int64_t)lds)) return rc;
+    // exp-form store: only the 64 x 64-per-wave forms, and only for a bare product
+    uint8_t *flags = (TM == 2 && TN == 2 && !g.bias && !g.R && !g.act_tanh && g.alpha == 1.f) ? g.exp_flags : nullptr;
     hipLaunchKernelGGL(kern, dim3(MT8 * NT), dim3(64 * WM * WN), lds, st, g.A, g.M, g.K, g.W, g.N, g.ldw, g.bias, g.R, g.C,
-                       g.act_tanh, g.alpha, MT, NT, g_stagger_mode, g_stagger_cycles);
+                       g.act_tanh, g.alpha, MT, NT, g_stagger_mode, g_stagger_cycles, flags);
+    if (g.exp_used) *g.exp_used = flags != nullptr;
     return 0;
 }
+
+// mirrors launch_gemm_nt_ex's choice of kernel: true iff a launch of g with exp_flags set will write them
+static bool nt_dma_ok(const GemmNT &g);
+static int nt_tile(const GemmNT &g);
+bool gemm_nt_exp_store_ok(const GemmNT &g) {
+    if (g.M <= 0 || g.bias || g.R || g.act_tanh || g.alpha != 1.f || g.a_rm || g.c_rm) return false;
+    if (!gemm_nt_mfma_ok(g) || g.K % 16 != 0 || g.N % 16 != 0) return false;
+    const int bn = nt_tile(g);
+    if (g.K == 32 || bn != 128) return false;
+    if (g_nt_split && g_nt_dma_variant != 0 && gemm_nt_split_ok(g)) return false;
+    switch (g_nt_dma_variant) {
+        case 1: case 2: case 9: return nt_dma_ok(g);
+        case 3: case 4: return nt_dma_ok(g) && g.N % 256 == 0;
+        default: return false;
+    }
+}
+
+int64_t gemm_exp_flag_bytes(int64_t M, int N) { return 2 * ((M + 127) / 128) * (int64_t)(N / 64 > 0 ? N / 64 : 1); }
 
 static bool nt_dma_ok(const GemmNT &g) {
     return !g.a_rm && !g.c_rm && !g.w_kn && g.N % 128 == 0 && g.K % 16 == 0 && g.K >= 64 && g.ldw % 4 == 0 &&
@@ -462,8 +500,10 @@ bool gemm_nt_mfma_ok(const GemmNT &g) {
 
 // N-tile width of a launch.  Small-M problems (the per-sample [B, D] layers: 16 M-tiles) take a narrower tile so that
 // at least ~half the CUs get a workgroup.
+static int64_t g_nt_min_wgs = 128;              // tune knob "nt_min_wgs" (tests force the 128-wide tile on small problems with 1)
+void set_gemm_nt_min_wgs(int v) { g_nt_min_wgs = v > 0 ? v : 128; }
 static int nt_tile(const GemmNT &g) {
-    constexpr int64_t MIN_WGS = 128;
+    const int64_t MIN_WGS = g_nt_min_wgs;
     const int64_t MT = (g.M + 127) / 128;
     if (g.N % 128 == 0 && MT * (g.N / 128) >= MIN_WGS) return 128;
     if (g.N % 64 == 0 && (g.N % 128 != 0 || MT * (g.N / 64) >= MIN_WGS)) return 64;
@@ -495,6 +535,7 @@ static void launch_nt_layout(const GemmNT &g, hipStream_t st, bool k32 = false) 
 }
 
 int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof) {
+    if (g.exp_used) *g.exp_used = false;
     if (g.M <= 0) return 0;
     const bool mfma = gemm_nt_mfma_ok(g);
     if (!mfma && (g.a_rm || g.c_rm)) return fail(UPAMD_E_INVALID, "gemm_nt: row-major operands need the MFMA path (K=%d N=%d)", g.K, g.N);

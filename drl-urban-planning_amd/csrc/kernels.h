@@ -27,6 +27,20 @@ __host__ __device__ inline int pq_side(int cp) { return (cp >> 1) & 1; }      //
 // position of (side, column)
 __host__ __device__ inline int pq_pos(int side, int col) { return (col >> 4) * 32 + ((col >> 1) & 7) * 4 + side * 2 + (col & 1); }
 
+// LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, lane i's 16 bytes land at the wave-uniform LDS base + 16 i;
+// no staging VGPRs, no ds_write pass).  Completion is tracked by vmcnt only.
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+constexpr float PQ_C2 = 2.8853900817779268f;      // 2 * log2(e): tanh(x) = 1 - 2 / (1 + 2^(PQ_C2 x))
+// The P/Q GEMM of a GCN layer may store its output in EXP FORM, 2^(PQ_C2 x), which is what the message-passing kernels
+// stage into LDS anyway (edge.hip): a 64-row x 64-column output block whose largest |PQ_C2 x| is <= PQ_EXP_LIMIT is
+// written as 2^(PQ_C2 x) with flag 0, any other block as plain x with flag 1.  flags: [2 * ceil(M / 128)][N / 64] bytes.
+constexpr float PQ_EXP_LIMIT = 28.f;              // = edge.hip's EF_LIMIT_FWD: products of two factors and the bias stay finite
+
 struct PackedView {   // device pointers into the packed replay (upamd_pack_layout)
     const int32_t *meta;
     const float *X;
@@ -80,9 +94,16 @@ struct GemmNT {
     float *C; int64_t ldc; bool c_rm;
     int act_tanh; float alpha;
     bool w_kn = false;          // W is given as [K][N] (row stride ldw) instead of [N][K]: C = A W, no transpose needed
+    // exp-form store (see PQ_EXP_LIMIT): honoured only by the LDS-DMA kernel with 64 x 64 wave blocks and only without
+    // bias / residual / activation; launch_gemm_nt_ex reports through *exp_used whether the flags were written
+    uint8_t *exp_flags = nullptr;
+    bool *exp_used = nullptr;
 };
+int64_t gemm_exp_flag_bytes(int64_t M, int N);
+bool gemm_nt_exp_store_ok(const GemmNT &g);      // a launch of g with exp_flags set WILL write them (same choice as the launcher)
 bool gemm_nt_mfma_ok(const GemmNT &g);
 void set_gemm_nt_dma_variant(int v);
+void set_gemm_nt_min_wgs(int v);            // tune knob "nt_min_wgs": workgroups a launch must have before the 128-wide N tile is used
 void set_gemm_stagger(int mode, int cycles);
 void set_gemm_lds_pad(int bytes);   // first-residency-round stagger of the GEMM workgroups (-1 = keep)       // kernel-lab knob: LDS-DMA configuration of the plain panel-major launches
 int launch_gemm_nt_ex(const GemmNT &g, hipStream_t st, Profiler *prof);
@@ -110,7 +131,8 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
                         hipStream_t st, float *last_col_dst = nullptr);
 
 // ---- graph.hip -------------------------------------------------------------------------
-__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds = true);
+__host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds = true, bool nblds = true);
+void set_bwd_nb_global(int on);            // tune knob "bwd_nb_global" (default on): large size class of the backward walks the neighbour ids from global memory
 // First GCN layer folded into the message-passing stage-in (edge.hip: fold_fill): the workgroup computes its P/Q (and
 // H_0) slice from the raw node features.  Xp: panel-major [2][M][16]; W1c = Wcat_1 We [2D][32] (rows in P/Q pair
 // order), b1c [2D]; We (zero-padded) [D][32], be [D].
@@ -120,13 +142,14 @@ struct FoldArgs {
 bool edge_fold_ok(const MbView &mb);
 void set_fwd_h_hbm(int on);                // tune knob: large-graph size class of the forward with H left in HBM (default on)
 void set_side_stream(int on);              // tune knob "side_stream" (default on): per-sample chains + grouped weight gradients on an engine-owned side stream
+void set_pq_exp(int on);                   // tune knob "pq_exp" (default on): exp-form P/Q from the GEMM epilogue + LDS-DMA stage-in
 void set_fold_layer1(int on);              // tune knob: compute the first GCN layer inside the message-passing kernels       // every graph of the minibatch fits the staged (LDS-resident) size classes
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
-                    hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, int fe_full = 1);
+                    hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, int fe_full = 1, const uint8_t *pqflag = nullptr);
 int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
-                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr);
+                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, const uint8_t *pqflag = nullptr);
 int launch_attn_fwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     float *alpha, float *s, hipStream_t st);
 int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,

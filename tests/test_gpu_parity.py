@@ -68,7 +68,7 @@ def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
 def tune():
     """set native tune knobs for one test; every knob is put back to its default afterwards"""
     from drl_urban_planning_amd import native
-    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1}
+    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1, 'pq_exp': 1, 'nt_min_wgs': 128, 'bwd_nb_global': 1}
     touched = []
 
     def _set(name, value):
@@ -371,6 +371,58 @@ def test_forked_step_is_bit_identical_to_the_single_stream_step(D, L, heads, n_r
         out = run()
         for a, b in zip(ref, out):
             assert torch.equal(a, b), 'repetition %d differs from the single-stream step' % rep
+
+
+@pytest.mark.parametrize('D,L,heads,n_range,T,fold', [(256, 3, 1, (200, 345), 24, 1), (64, 3, 2, (30, 60), 16, 1),
+                                                         (64, 2, 2, (30, 60), 16, 0), (128, 3, 4, (380, 520), 6, 1), (128, 3, 4, (360, 400), 8, 1),
+                                                         (64, 3, 2, (520, 700), 3, 1)])
+def test_dma_stage_in_is_bit_identical_to_the_register_stage_in(D, L, heads, n_range, T, fold, tune):
+    """Round 3: the P/Q GEMM of layers 2..L stores 2^(C2 x) block by block (tune knob pq_exp, default on) and the
+    message-passing kernels copy their slices HBM -> LDS by LDS-DMA instead of loading, exponentiating and ds_writing
+    them.  Same arithmetic (the exponential moved into the GEMM epilogue, everything else untouched): values and every
+    gradient must equal the register-staged path BIT FOR BIT.  nt_min_wgs = 1 makes the small cases take the 128-wide
+    LDS-DMA GEMM tile that carries the exp-form store; fold = 0 also runs layer 1 through the plain kernels; the
+    380..520- and 520..700-node cases are the large size classes (H in HBM / one workgroup per CU, looped DMA), 360..400
+    the DHM size class whose backward walks the neighbour ids from global memory (two workgroups per CU)."""
+    tune('nt_min_wgs', 1)
+    tune('fold_layer1', fold)
+    cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
+                                   int(5.55 * n_range[1]) + 10, seed=29, road_fraction=0.3, n_range=n_range)
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, replay.states, replay.actions)
+    g = torch.Generator().manual_seed(9)
+    seeds = [torch.randn(T, generator=g).to(DEV) for _ in range(3)]
+
+    def run():
+        value, logp, ent = _forward(eng, pk, mb, flat)
+        grads = torch.zeros(eng.n_floats, device=DEV)
+        eng.backward(pk, mb, flat, seeds[0], seeds[1], seeds[2], grads)
+        torch.cuda.synchronize()
+        return [value.clone(), logp.clone(), ent.clone(), grads]
+    tune('pq_exp', 0)
+    ref = run()
+    tune('pq_exp', 1)
+    for rep in range(3):
+        out = run()
+        for name, a, b in zip(('value', 'logp', 'entropy', 'grads'), ref, out):
+            assert torch.equal(a, b), '%s differs from the register-staged path (repetition %d, max |diff| %.3e)' % (
+                name, rep, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize('gain,bias', [(40.0, 0.0), (1.0, 3.0), (400.0, 0.5), (12.0, 0.0)])
+def test_saturating_edge_mlp_on_the_dma_path_matches_oracle(gain, bias, tune):
+    """The saturation cases with the exp-form store in play (3 layers, nt_min_wgs = 1): GEMM output blocks beyond the
+    exp-form limit stay linear and raise their flag, the workgroups that meet one convert their slice in LDS (log2 of the
+    exp-form blocks; back to exp form when their own slice allows it, else the linear walk) -- gain 12 leaves a mix of
+    flagged and unflagged blocks."""
+    tune('nt_min_wgs', 1)
+    D, L, heads, T, n_range = 64, 3, 2, 6, (30, 60)
+    cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
+                                   int(5.55 * n_range[1]) + 10, seed=33, road_fraction=0.3, n_range=n_range)
+    sd = dict(sd)
+    for k in list(sd):
+        if 'edge_fc_layers' in k:
+            sd[k] = sd[k] * gain if k.endswith('weight') else sd[k] + bias
+    _check_against_oracle(cfg, sd, replay, heads, T, tol=3e-4 if gain > 1 else 1e-4)
 
 
 def test_wide_model_with_full_head_input_tensor_matches_oracle(tune):
