@@ -100,6 +100,18 @@ def _record_sections(h):
     return out, off
 
 
+def _write_record(h, arrays):
+    """header + the nine (already trimmed) arrays -> one contiguous uint8 record"""
+    sections, total = _record_sections(h)
+    rec = np.zeros(total, dtype=np.uint8)
+    rec[:_REC_HEADER.itemsize] = np.frombuffer(h.tobytes(), dtype=np.uint8)
+    for f, dt, shape, off in sections:
+        n = int(np.prod(shape))
+        if n:
+            rec[off:off + n * np.dtype(dt).itemsize] = arrays[f].reshape(-1)[:n].view(np.uint8)
+    return rec
+
+
 def compact_state(state):
     """9-field padded state (observation_extractor.py:207-228) -> compact uint8 record (see above)."""
     if len(state) != 9:
@@ -121,14 +133,75 @@ def compact_state(state):
     h['pad_n'], h['pad_e'], h['edge_fill'] = nf.shape[0], ei.shape[0], fill
     h['n_rows'] = int(used_n[-1]) + 1 if used_n.size else 0
     h['e_rows'] = int(used_e[-1]) + 1 if used_e.size else 0
-    sections, total = _record_sections(h)
-    rec = np.zeros(total, dtype=np.uint8)
-    rec[:_REC_HEADER.itemsize] = np.frombuffer(h.tobytes(), dtype=np.uint8)
-    for f, dt, shape, off in sections:
-        n = int(np.prod(shape))
-        src = a[f].reshape(-1) if f in (0, 3, 8) else a[f][:shape[0]].reshape(-1)
-        rec[off:off + n * np.dtype(dt).itemsize] = src[:n].view(np.uint8) if n else src[:0].view(np.uint8)
-    return rec
+    nr, er = int(h['n_rows']), int(h['e_rows'])
+    return _write_record(h, [a[0], a[1][:nr], a[2][:er], a[3], a[4][:nr], a[5][:er], a[6][:er], a[7][:nr], a[8]])
+
+
+def compact_from_arrays(numerical, node_features, edge_index, current_node, land_use_mask, road_mask, stage, pad_n, pad_e,
+                        node_mask=None, edge_mask=None):
+    """The compact record of an observation straight from the UNPADDED arrays the extractor holds before it pads them
+    (observation_extractor.py:99-132: ``obs_nodes [n, F]``, ``edges [e, 2]``; :207-228: the masks handed to ``get_obs``)
+    -- byte for byte the record ``compact_state`` makes of the padded 9-field tuple, without ever building the ~148 KB
+    padded arrays.  ``pad_n`` / ``pad_e`` = the extractor's ``max_num_nodes`` / ``max_num_edges``; the node / edge masks
+    default to all-True over the live rows (what ``_get_obs_graph`` emits).  Raises the extractor's own ``ValueError``
+    when a limit is exceeded (:80-81, :94-95)."""
+    nf = _as_array(node_features, np.float32)
+    ei = _as_array(edge_index, np.int64)
+    if nf.ndim != 2 or (ei.size and (ei.ndim != 2 or ei.shape[1] != 2)):
+        raise ValueError('node features must be [n, F] and edge index [e, 2]')
+    ei = ei.reshape(-1, 2)
+    n, e = nf.shape[0], ei.shape[0]
+    pad_n, pad_e = int(pad_n), int(pad_e)
+    if n > pad_n:
+        raise ValueError('The number of nodes exceeds the maximum limit.')
+    if e > pad_e:
+        raise ValueError('The number of edges exceeds the maximum limit.')
+
+    def mask(m, rows, limit, what):
+        m = np.ones(rows, dtype=np.bool_) if m is None else _as_array(m, np.bool_).reshape(-1)
+        if m.size > limit:
+            raise ValueError('The number of %s exceeds the maximum limit.' % what)
+        return m
+    nm, rm = mask(node_mask, n, pad_n, 'nodes'), mask(road_mask, n, pad_n, 'nodes')
+    em, lm = mask(edge_mask, e, pad_e, 'edges'), mask(land_use_mask, e, pad_e, 'edges')
+    # what compact_state would find in the padded tuple: the pad rows repeat (pad_n - 1, pad_n - 1) and all-zero features
+    if e < pad_e:
+        fill = pad_n - 1
+    else:
+        fill = int(ei[-1, 0]) if e and ei[-1, 0] == ei[-1, 1] and abs(int(ei[-1, 0])) < 2 ** 31 else 0
+
+    def last_used(flags):
+        idx = np.flatnonzero(flags)
+        return int(idx[-1]) + 1 if idx.size else 0
+
+    def grow(m, rows):                      # a mask shorter / longer than the live rows: pad with False like _pad_mask
+        out = np.zeros(rows, dtype=np.bool_)
+        out[:min(rows, m.size)] = m[:rows]
+        return out
+    rows_n = max(n, nm.size, rm.size)
+    used_n = grow(nm, rows_n) | grow(rm, rows_n)
+    used_n[:n] |= (nf != 0).any(axis=1)
+    rows_e = max(e, em.size, lm.size)
+    used_e = grow(em, rows_e) | grow(lm, rows_e)
+    used_e[:e] |= (ei != fill).any(axis=1)
+    nr, er = last_used(used_n), last_used(used_e)
+    h = np.zeros((), dtype=_REC_HEADER)
+    num = _as_array(numerical, np.float32).reshape(-1)
+    cur = _as_array(current_node, np.float32).reshape(-1)
+    st = _as_array(stage, np.float32).reshape(-1)
+    h['magic'], h['node_dim'], h['numerical_len'] = _REC_MAGIC, nf.shape[1], num.size
+    h['cur_len'], h['stage_len'] = cur.size, st.size
+    h['pad_n'], h['pad_e'], h['edge_fill'] = pad_n, pad_e, fill
+    h['n_rows'], h['e_rows'] = nr, er
+
+    def rows(a, k, fill_value=0):           # the first k rows of an array with >= 0 live rows (zero / fill beyond them)
+        if a.shape[0] >= k:
+            return a[:k]
+        out = np.full((k,) + a.shape[1:], fill_value, dtype=a.dtype)
+        out[:a.shape[0]] = a
+        return out
+    return _write_record(h, [num, rows(nf, nr), rows(ei, er, fill), cur, grow(nm, nr), grow(em, er), grow(lm, er),
+                             grow(rm, nr), st])
 
 
 def is_record(obj):

@@ -252,6 +252,7 @@ class SharedArena:
         else:
             self.shm = shared_memory.SharedMemory(name=name)
             self.owner = False
+        self._pinned = False
 
     @property
     def name(self):
@@ -271,6 +272,25 @@ class SharedArena:
 
     def reset(self):
         self.header[:] = 0
+
+    def pin(self):
+        """Page-lock the arena in the LEARNER process (hipHostRegister): the pages the packer threads read once per iteration
+        can no longer be swapped or migrated, and a device-side consumer may DMA from them directly.  Needs a GPU runtime;
+        returns whether the arena is now registered.  Workers attached to the same shared memory are unaffected."""
+        if self._pinned:
+            return True
+        if not torch.cuda.is_available():
+            return False
+        addr = np.frombuffer(self.shm.buf, dtype=np.uint8).ctypes.data
+        rc = torch.cuda.cudart().cudaHostRegister(addr, self.shm.size, 0)
+        self._pinned = int(rc) == 0
+        return self._pinned
+
+    def _unpin(self):
+        if self._pinned:
+            addr = np.frombuffer(self.shm.buf, dtype=np.uint8).ctypes.data
+            torch.cuda.cudart().cudaHostUnregister(addr)
+            self._pinned = False
 
     def append(self, state, action, mask, reward, exp):
         rec = _to_record(state)
@@ -295,6 +315,7 @@ class SharedArena:
         return states, t[:, 2:4].astype(np.float32), t[:, 4].copy(), t[:, 5].copy(), t[:, 6].copy()
 
     def close(self, unlink=None):
+        self._unpin()
         self.shm.close()
         if self.owner if unlink is None else unlink:
             try:

@@ -79,6 +79,9 @@ def test_gpu_action_server_with_sampling_and_eval_clients():
             if mean:
                 assert np.array_equal(a, want[t].numpy()), (pid, t, a, want[t])
     # the arenas go straight into the update (records are consumed in place)
+    for a in arenas[:n_workers]:                # page-locked in the learner (hipHostRegister): the packer reads pinned memory
+        assert a.pin()
+        assert torch.frombuffer(a.shm.buf, dtype=torch.uint8).is_pinned()
     batch = rollout.RecordBatch([rollout.ArenaMemory(a) for a in arenas[:n_workers]])
     assert len(batch) == n_workers * n_steps
     before = {k: v.detach().clone() for k, v in ac.state_dict().items()}

@@ -204,3 +204,26 @@ def test_mlp_encoder_inputs_selected_endpoint_and_mean_features():
                 if emask[k]:
                     assert he_sel[o + q] == sel[k]
     assert saw_second
+
+
+def test_compact_record_straight_from_the_unpadded_arrays():
+    """`compact_from_arrays` (what a patched ObservationExtractor.get_obs calls, observation_extractor.py:207-228) builds the
+    record from the UNPADDED node / edge arrays and masks; it must equal `compact_state(padded tuple)` byte for byte --
+    incl. a graph with a self-loop and duplicate edges, isolated nodes, the unpadded row (n == N, e == E) and land-use
+    candidates on slots beyond the live edges -- and raise the extractor's errors when a limit is exceeded."""
+    import cases
+    N, E = 40, 96
+    rep = cases.quirky_replay(24, N, E, seed=3, road_fraction=0.35, dead_candidate=True)
+    for t, s in enumerate(rep.states):
+        n, e = int(s[4].sum()), int(s[5].sum())
+        lm_rows = max(e, int(np.flatnonzero(s[6])[-1]) + 1 if s[6].any() else 0)      # a candidate may sit behind the live edges
+        rec = packer.compact_from_arrays(s[0], s[1][:n], s[2][:e], s[3], s[6][:lm_rows], s[7][:n], s[8], N, E)
+        assert np.array_equal(rec, packer.compact_state(s)), t
+        back = packer.expand_state(rec, padded=True)
+        for f in range(9):
+            assert np.array_equal(back[f], s[f]), (t, f)
+    s = rep.states[0]
+    with pytest.raises(ValueError, match='number of nodes exceeds'):
+        packer.compact_from_arrays(s[0], s[1], s[2][:5], s[3], s[6][:5], s[7], s[8], N - 1, E)
+    with pytest.raises(ValueError, match='number of edges exceeds'):
+        packer.compact_from_arrays(s[0], s[1][:10], s[2], s[3], s[6], s[7][:10], s[8], N, E - 1)
