@@ -41,6 +41,9 @@ WORKLOADS = {
     'hlg_d256': dict(community='hlg', D=256, L=3, B=2048, T=16384, unique=1024, max_nodes=1000, max_edges=3000),
     # the reference's shipped YAML dims (hlg.yaml:21-44) -- the tiny-model regime, for orientation
     'hlg_ref': dict(community='hlg', D=16, L=2, B=256, T=8192, unique=1024, max_nodes=1000, max_edges=3000),
+    # BASELINE.json configs[0]: "synthetic grid community, PPO batch 256, policy hidden 64 -- reference CPU path": the
+    # reference YAML dims (grid.yaml:21-33), grid-sized graphs, land-use / road rows mixed (grid.yaml:16-18), pads 1000/3000
+    'grid_ref': dict(community='grid', D=16, L=2, B=256, T=2560, unique=1024, max_nodes=1000, max_edges=3000, road_fraction=0.5),
     # BASELINE.json configs[2]
     'dhm_d256': dict(community='dhm', D=256, L=3, B=4096, T=32768, unique=1024, max_nodes=1000, max_edges=3000),
     # BASELINE.json configs[4], per-GPU share: heterogeneous HLG + DHM graphs in one minibatch (2048 rows per GPU)
@@ -84,10 +87,11 @@ def algorithmic_flops_per_sample(n, e, D, L, F=23, Fn=52, S=(64, 16), H=32):
 def _cpu_row(P, orc, synth, w, Bc, threads, tight, max_steps, budget_s):
     """One timed row of the CPU baseline: `threads` torch threads, Bc rows per optimizer step."""
     torch.set_num_threads(threads)
-    n_c = synth.COMMUNITY_NODES.get(w['community'], 397)
+    n_c = synth.COMMUNITY_NODES.get(w['community'], 397)          # ('mixed' -> the larger community's size)
     pads = (n_c + 1 if w['community'] != 'mixed' else 398, int(round(5.55 * (n_c if w['community'] != 'mixed' else 397))) + 8) \
         if tight else (w['max_nodes'], w['max_edges'])
-    replay = synth.make_replay(Bc, w['community'], max_nodes=pads[0], max_edges=pads[1], seed=77)
+    replay = synth.make_replay(Bc, w['community'], max_nodes=pads[0], max_edges=pads[1], seed=77,
+                               road_fraction=w.get('road_fraction', 0.0))
     up = orc.OracleUpdater(P, mini_batch_size=Bc, num_optim_epoch=1)
     actions = torch.from_numpy(replay.actions).float()
     g = torch.Generator().manual_seed(1)
@@ -165,6 +169,9 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--sub-batches', type=int, default=1, help='2 = overlap the two halves of a minibatch on two streams')
     ap.add_argument('--minibatch', type=int, default=0, help='override the per-GPU PPO minibatch of the workload (exploration)')
+    ap.add_argument('--inclusive-unique', action='store_true',
+                    help='time the update_params_inclusive leg on T DISTINCT host states (default: the replay tiles a pool '
+                         'of `unique` states, so the host packer reads a small working set)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak (default): the minibatch per GPU is fixed; strong: the GLOBAL minibatch is fixed and split')
     args = ap.parse_args()
@@ -204,14 +211,16 @@ def main():
     if glob:
         # the SAME replay on every rank (same seed), one global permutation (same numpy seed), every rank B rows of each
         # global minibatch -- the reference's minibatch sequence, sharded
-        T = max(w['T'], B_step * ((need + 3) // 4))
+        # (two global minibatches per epoch are enough for any step count -- run() starts a new epoch whenever one is used up;
+        # sizing T by the step count made every rank of an 8-GPU run generate and pack ~98 k states before the timed region)
+        T = max(w['T'], 2 * B_step)
         seed_replay, seed_np = 100, 7
     else:
-        T = max(w['T'], w['B'] * ((need + 3) // 4))
+        T = max(w['T'], 2 * w['B'])
         seed_replay, seed_np = 100 + rank, 7 + rank
     t_gen = time.time()
     replay = synth.make_replay(T, w['community'], max_nodes=w['max_nodes'], max_edges=w['max_edges'],
-                               seed=seed_replay, unique=w['unique'])
+                               seed=seed_replay, unique=w['unique'], road_fraction=w.get('road_fraction', 0.0))
     t_gen = time.time() - t_gen
     np.random.seed(seed_np)
     engine = up.attach()
@@ -271,9 +280,15 @@ def main():
     # one whole update_params call as the reference's caller sees it (urban_planning_agent.py:248-271): host packing,
     # the single upload, value / old-log-prob pre-pass, GAE, every optimizer step of every epoch, write-back
     ctx.barrier()
+    replay_incl, unique_incl = replay, min(w['unique'], T)
+    if args.inclusive_unique:       # T distinct host states: the packer's host working set is the full ~150 KB x T
+        replay_incl = synth.make_replay(T, w['community'], max_nodes=w['max_nodes'], max_edges=w['max_edges'],
+                                        seed=seed_replay + 50, unique=None, road_fraction=w.get('road_fraction', 0.0))
+        unique_incl = T
+    host_bytes = unique_incl * sum(int(np.asarray(f).nbytes) for f in replay_incl.states[0])
     np.random.seed(seed_np + 1000)
     t_incl = time.perf_counter()
-    up.update_params(replay, 0)
+    up.update_params(replay_incl, 0)
     torch.cuda.synchronize(dev)
     t_incl = time.perf_counter() - t_incl
     incl = dict(up.last_timing)
@@ -297,9 +312,12 @@ def main():
         'setup_s': {'generate': t_gen, 'pack_upload_prepass_gae': t_prep},
         'update_params_inclusive': {'samples_per_s': incl['steps'] * incl['rows_per_step'] / t_incl, 'seconds': t_incl,
                                     'optimizer_steps': incl['steps'], 'rows_per_step': incl['rows_per_step'],
-                                    'replay_states': T, 'prepare_s': incl['prepare'], 'loop_s': incl['loop'],
+                                    'replay_states': T, 'unique_host_states': unique_incl,
+                                    'host_working_set_bytes': host_bytes, 'prepare_s': incl['prepare'], 'loop_s': incl['loop'],
                                     'note': 'one update_params(batch) call from host numpy states: pack + H2D + pre-pass + '
-                                            'GAE + all epochs + write-back'},
+                                            'GAE + all epochs + write-back; with unique_host_states < replay_states the packer '
+                                            're-reads a small host working set, so the figure is an upper bound '
+                                            '(--inclusive-unique times T distinct states)'},
         'dp_mode': incl.get('dp_mode'),
     }
     flops_sample = algorithmic_flops_per_sample(nodes_per_sample, edges_per_sample, w['D'], w['L'])

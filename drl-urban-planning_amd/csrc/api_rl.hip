@@ -139,6 +139,7 @@ extern "C" int upamd_tune(const char *name, int32_t value) {
     if (!strcmp(name, "fold_layer1")) { set_fold_layer1(value); return UPAMD_OK; }
     if (!strcmp(name, "pq_exp")) { set_pq_exp(value); return UPAMD_OK; }
     if (!strcmp(name, "bwd_nb_global")) { set_bwd_nb_global(value); return UPAMD_OK; }
+    if (!strcmp(name, "gemm_tn_dma")) { set_gemm_tn_dma(value); return UPAMD_OK; }
     if (!strcmp(name, "nt_min_wgs")) { set_gemm_nt_min_wgs(value); return UPAMD_OK; }
     if (!strcmp(name, "gemm_split")) { set_gemm_nt_split(value); return UPAMD_OK; }
     if (!strcmp(name, "he_fused")) { set_he_feat_fused(value); return UPAMD_OK; }

@@ -103,6 +103,7 @@ int64_t gemm_exp_flag_bytes(int64_t M, int N);
 bool gemm_nt_exp_store_ok(const GemmNT &g);      // a launch of g with exp_flags set WILL write them (same choice as the launcher)
 bool gemm_nt_mfma_ok(const GemmNT &g);
 void set_gemm_nt_dma_variant(int v);
+void set_gemm_tn_dma(int on);               // tune knob "gemm_tn_dma" (default on): LDS-DMA staged weight-gradient GEMM tiles
 void set_gemm_nt_min_wgs(int v);            // tune knob "nt_min_wgs": workgroups a launch must have before the 128-wide N tile is used
 void set_gemm_stagger(int mode, int cycles);
 void set_gemm_lds_pad(int bytes);   // first-residency-round stagger of the GEMM workgroups (-1 = keep)       // kernel-lab knob: LDS-DMA configuration of the plain panel-major launches
