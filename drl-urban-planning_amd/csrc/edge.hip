@@ -682,6 +682,11 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     }
 }
 
+// tune knob "edge_min_lds" (bytes, default 0): every message-passing launch asks for at least this much dynamic LDS.  Above
+// 80 KB only ONE of these workgroups fits a CU, which leaves LDS and wave slots for the GEMM workgroups of another stream
+// (PPOUpdater(sub_batches=2): MFMA-bound GEMMs of one half-minibatch next to the VALU-bound walk of the other)
+static int64_t g_edge_min_lds = 0;
+void set_edge_min_lds(int bytes) { g_edge_min_lds = bytes > 0 ? (bytes < LDS_LIMIT ? bytes : LDS_LIMIT) : 0; }
 static int g_bwd_nb_global = 1;  // tune knob "bwd_nb_global", see edge_bwd_kernel (NBG)
 void set_bwd_nb_global(int on) { g_bwd_nb_global = on ? 1 : 0; }
 static int g_fwd_h_hbm = 1;      // tune knob "fwd_h_hbm": the large size class of the forward keeps H in HBM (two workgroups per CU)
@@ -705,6 +710,7 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
     // one launch of a given (stage, lds, fit) configuration
     auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool hlds = true) -> int {
+        if (lds < g_edge_min_lds) lds = g_edge_min_lds;
 #define UPAMD_EF(L_, S_, F_, H_, D_)                                                                                  \
     do {                                                                                                              \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_, H_, D_>), lds)) return rc_;  \
@@ -1063,6 +1069,7 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     const int began = prof_begin(prof, "edge_bwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
     auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool nbg = false) -> int {
+        if (lds < g_edge_min_lds) lds = g_edge_min_lds;
 #define UPAMD_EB(L_, S_, F_, D_, N_)                                                                                  \
     do {                                                                                                              \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_, F_, D_, N_>), lds)) return rc_;  \

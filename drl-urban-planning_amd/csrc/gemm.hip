@@ -830,7 +830,10 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const float *__restric
         }
 }
 
-static int g_tn_dma = 1;              // tune knob "gemm_tn_dma" (default on): LDS-DMA staged 128 x 128 weight-gradient tiles
+// tune knob "gemm_tn_dma" (default OFF): measured 2.3 % slower than the register-staged kernel inside the step (2.545 vs
+// 2.488 ms per step for the two weight-gradient launches, profiles/r03_lab_gemm_tn_dma.log) -- every wave re-reads the whole
+// A panel from LDS, and with one chunk of prefetch the DMA latency is no better hidden than the register loads were
+static int g_tn_dma = 0;
 void set_gemm_tn_dma(int on) { g_tn_dma = on ? 1 : 0; }
 
 __global__ void gemm_tn_generic_kernel(const float *__restrict__ A, int I, const float *__restrict__ Bm, int J,

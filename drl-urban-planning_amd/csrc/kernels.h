@@ -103,7 +103,7 @@ int64_t gemm_exp_flag_bytes(int64_t M, int N);
 bool gemm_nt_exp_store_ok(const GemmNT &g);      // a launch of g with exp_flags set WILL write them (same choice as the launcher)
 bool gemm_nt_mfma_ok(const GemmNT &g);
 void set_gemm_nt_dma_variant(int v);
-void set_gemm_tn_dma(int on);               // tune knob "gemm_tn_dma" (default on): LDS-DMA staged weight-gradient GEMM tiles
+void set_gemm_tn_dma(int on);               // tune knob "gemm_tn_dma" (default off): LDS-DMA staged weight-gradient GEMM tiles
 void set_gemm_nt_min_wgs(int v);            // tune knob "nt_min_wgs": workgroups a launch must have before the 128-wide N tile is used
 void set_gemm_stagger(int mode, int cycles);
 void set_gemm_lds_pad(int bytes);   // first-residency-round stagger of the GEMM workgroups (-1 = keep)       // kernel-lab knob: LDS-DMA configuration of the plain panel-major launches
@@ -133,6 +133,7 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
 
 // ---- graph.hip -------------------------------------------------------------------------
 __host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds = true, bool nblds = true);
+void set_edge_min_lds(int bytes);          // tune knob "edge_min_lds": minimum dynamic LDS of the message-passing launches (co-scheduling lab)
 void set_bwd_nb_global(int on);            // tune knob "bwd_nb_global" (default on): large size class of the backward walks the neighbour ids from global memory
 // First GCN layer folded into the message-passing stage-in (edge.hip: fold_fill): the workgroup computes its P/Q (and
 // H_0) slice from the raw node features.  Xp: panel-major [2][M][16]; W1c = Wcat_1 We [2D][32] (rows in P/Q pair
