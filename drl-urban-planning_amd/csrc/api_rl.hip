@@ -138,7 +138,6 @@ extern "C" int upamd_tune(const char *name, int32_t value) {
     if (!strcmp(name, "gemm_stagger_cycles")) { set_gemm_stagger(-1, value); return UPAMD_OK; }
     if (!strcmp(name, "fold_layer1")) { set_fold_layer1(value); return UPAMD_OK; }
     if (!strcmp(name, "pq_exp")) { set_pq_exp(value); return UPAMD_OK; }
-    if (!strcmp(name, "edge_hub_thr")) { set_edge_hub_thr(value); return UPAMD_OK; }
     if (!strcmp(name, "edge_min_lds")) { set_edge_min_lds(value); return UPAMD_OK; }
     if (!strcmp(name, "bwd_nb_global")) { set_bwd_nb_global(value); return UPAMD_OK; }
     if (!strcmp(name, "gemm_tn_dma")) { set_gemm_tn_dma(value); return UPAMD_OK; }

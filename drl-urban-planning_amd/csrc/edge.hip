@@ -420,7 +420,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                                                                 float *__restrict__ hbarV, float *__restrict__ hbarE,
                                                                 const float *__restrict__ Ccur, float *__restrict__ FE,
                                                                 int aux_cap, int fit, FoldArgs fa, int fe_full,
-                                                                const uint8_t *__restrict__ pqflag, int nfb, int hub_thr) {
+                                                                const uint8_t *__restrict__ pqflag, int nfb) {
     static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
     static_assert(HLDS || (STAGE && !FOLD), "H stays in HBM only next to a staged (not folded) P/Q slice");
     static_assert(!DMA || (STAGE && !FOLD), "the LDS-DMA stage-in belongs to the staged, not folded kernels");
@@ -585,9 +585,29 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         };
         const float2 eb = make_float2(EF ? __builtin_amdgcn_exp2f(bc.x) : bc.x, EF ? __builtin_amdgcn_exp2f(bc.y) : bc.y);
         auto fold = [&](float x, float bb) -> float { return EF ? x * bb : x + bb; };
-        // the end of a node's walk: H_out = H_in + S / (deg + 1e-6) (+ the last layer's per-graph sums), by the lanes with `mine`
-        auto finish = [&](int v, bool mine, float degf, float acc0, float acc1, float2 hpre) {
-            if (mine) {
+        const int nchunks = (n + 7) >> 3;
+        // chunks are dealt to the waves in serpentine order (0..15, 31..16, 32..47, ...): the degree-sorted chunks get
+        // shorter and shorter, so plain round-robin would give wave 0 the longest chunk of every round
+        for (int rnd = 0, j = w; rnd * EDGE_WAVES < nchunks; ++rnd, j = rnd * EDGE_WAVES + ((rnd & 1) ? EDGE_WAVES - 1 - w : w)) {
+            if (j >= nchunks) continue;
+            const int vi = 8 * j + g;
+            const bool valid = vi < n;
+            const int v = L.ord[valid ? vi : n - 1];
+            const float4 own = pq4(v);
+            const float pv0 = fold(own.x, eb.x), qv0 = fold(own.z, eb.x), pv1 = fold(own.y, eb.y), qv1 = fold(own.w, eb.y);
+            int k = L.rp[v];
+            const int k1 = valid ? L.rp[v + 1] : k;
+            const float degf = (float)(k1 - k);
+            // H in HBM: the node's two columns are requested now and consumed after the incidence loop
+            float2 hpre = make_float2(0.f, 0.f);
+            if (STAGE && !HLDS) hpre = *reinterpret_cast<const float2 *>(Hg + v * 16 + ca);
+            float acc0 = 0.f, acc1 = 0.f;          // sums over incidences of r1 + r2, per column
+            for (; k < k1; ++k) {
+                const float4 nb = pq4(L.nb[k]);
+                acc0 += rsum(pv0, nb.z, qv0, nb.x);
+                acc1 += rsum(pv1, nb.w, qv1, nb.y);
+            }
+            if (valid) {
                 const float S0 = degf - acc0, S1 = degf - acc1;     // 1/2 sum (tanh1 + tanh2) = 1/2 (2 deg - 2 acc)
                 const float inv = __builtin_amdgcn_rcpf(degf + 1e-6f);      // 1-ulp reciprocal instead of two IEEE divisions
                 float2 h;
@@ -612,70 +632,6 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                     }
                 }
             }
-        };
-        // ---- hub nodes first.  A node's incidences are walked one after the other by ONE 8-lane group, so a hub of degree 40-50
-        // is a chain of 40-50 dependent LDS round trips (~250 cycles each) -- that chain, not the vector ALU, set the lifetime of
-        // a workgroup (the stamp profile's 12.4 k-cycle walk next to ~24 trips of work per wave).  The nodes whose list is
-        // longer than hub_thr (the first NHUB of the degree-sorted order) are therefore handled one per WAVE: their incidences
-        // are dealt to the wave's eight groups and the eight partial sums combined in a fixed butterfly order.
-        int NHUB = 0;
-        if (hub_thr > 0) {
-            for (int base = 0; base < n; base += 64) {
-                const int i = base + lane;
-                int d = 0;
-                if (i < n) {
-                    const int vv = L.ord[i];
-                    d = L.rp[vv + 1] - L.rp[vv];
-                }
-                const unsigned long long hot = __ballot(d > hub_thr);
-                NHUB += __popcll(hot);
-                if (hot != ~0ull) break;
-            }
-        }
-        for (int i = w; i < NHUB; i += EDGE_WAVES) {
-            const int v = L.ord[i];
-            const float4 own = pq4(v);
-            const float pv0 = fold(own.x, eb.x), qv0 = fold(own.z, eb.x), pv1 = fold(own.y, eb.y), qv1 = fold(own.w, eb.y);
-            const int k0 = L.rp[v], k1 = L.rp[v + 1];
-            float2 hpre = make_float2(0.f, 0.f);
-            if (STAGE && !HLDS) hpre = *reinterpret_cast<const float2 *>(Hg + v * 16 + ca);
-            float acc0 = 0.f, acc1 = 0.f;
-            for (int k = k0 + g; k < k1; k += 8) {
-                const float4 nb = pq4(L.nb[k]);
-                acc0 += rsum(pv0, nb.z, qv0, nb.x);
-                acc1 += rsum(pv1, nb.w, qv1, nb.y);
-            }
-#pragma unroll
-            for (int sft = 8; sft <= 32; sft <<= 1) {
-                acc0 += __shfl_xor(acc0, sft);
-                acc1 += __shfl_xor(acc1, sft);
-            }
-            finish(v, g == 0, (float)(k1 - k0), acc0, acc1, hpre);
-        }
-        // ---- the other nodes, eight per wave visit
-        const int nchunks = (n - NHUB + 7) >> 3;
-        // chunks are dealt to the waves in serpentine order (0..15, 31..16, 32..47, ...): the degree-sorted chunks get
-        // shorter and shorter, so plain round-robin would give wave 0 the longest chunk of every round
-        for (int rnd = 0, j = w; rnd * EDGE_WAVES < nchunks; ++rnd, j = rnd * EDGE_WAVES + ((rnd & 1) ? EDGE_WAVES - 1 - w : w)) {
-            if (j >= nchunks) continue;
-            const int vi = NHUB + 8 * j + g;
-            const bool valid = vi < n;
-            const int v = L.ord[valid ? vi : n - 1];
-            const float4 own = pq4(v);
-            const float pv0 = fold(own.x, eb.x), qv0 = fold(own.z, eb.x), pv1 = fold(own.y, eb.y), qv1 = fold(own.w, eb.y);
-            int k = L.rp[v];
-            const int k1 = valid ? L.rp[v + 1] : k;
-            const float degf = (float)(k1 - k);
-            // H in HBM: the node's two columns are requested now and consumed after the incidence loop
-            float2 hpre = make_float2(0.f, 0.f);
-            if (STAGE && !HLDS) hpre = *reinterpret_cast<const float2 *>(Hg + v * 16 + ca);
-            float acc0 = 0.f, acc1 = 0.f;          // sums over incidences of r1 + r2, per column
-            for (; k < k1; ++k) {
-                const float4 nb = pq4(L.nb[k]);
-                acc0 += rsum(pv0, nb.z, qv0, nb.x);
-                acc1 += rsum(pv1, nb.w, qv1, nb.y);
-            }
-            finish(v, valid, degf, acc0, acc1, hpre);
         }
         if (LAST && FE && nh > 0) {
             // pointer-head inputs of this row's candidate edges (8 candidates per wave pass)
@@ -731,8 +687,6 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
 // (PPOUpdater(sub_batches=2): MFMA-bound GEMMs of one half-minibatch next to the VALU-bound walk of the other)
 static int64_t g_edge_min_lds = 0;
 void set_edge_min_lds(int bytes) { g_edge_min_lds = bytes > 0 ? (bytes < LDS_LIMIT ? bytes : LDS_LIMIT) : 0; }
-static int g_hub_thr = 16;       // tune knob "edge_hub_thr": nodes with more incidences than this are walked by a whole wave (0 = off)
-void set_edge_hub_thr(int v) { g_hub_thr = v > 0 ? v : 0; }
 static int g_bwd_nb_global = 1;  // tune knob "bwd_nb_global", see edge_bwd_kernel (NBG)
 void set_bwd_nb_global(int on) { g_bwd_nb_global = on ? 1 : 0; }
 static int g_fwd_h_hbm = 1;      // tune knob "fwd_h_hbm": the large size class of the forward keeps H in HBM (two workgroups per CU)
@@ -761,7 +715,7 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     do {                                                                                                              \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_, H_, D_>), lds)) return rc_;  \
         hipLaunchKernelGGL((edge_fwd_kernel<L_, S_, F_, H_, D_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, Hin, \
-                           Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa, fe_full, pqflag, nfb, g_hub_thr);          \
+                           Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa, fe_full, pqflag, nfb);                     \
     } while (0)
         const bool dma = pqflag != nullptr;
         if (fold) UPAMD_EF(false, true, true, true, false);
@@ -828,7 +782,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                                                                 const float *__restrict__ dhbarE, int ld_dhbarE,
                                                                 const float *__restrict__ dMhe, float *__restrict__ dPQ,
                                                                 float *__restrict__ dbias_part, int aux_cap, int fit,
-                                                                FoldArgs fa, const uint8_t *__restrict__ pqflag, int nfb, int hub_thr) {
+                                                                FoldArgs fa, const uint8_t *__restrict__ pqflag, int nfb) {
     static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
@@ -1015,16 +969,16 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         auto r = [](float a, float nb) -> float { return EF ? rcp1p_mul(a, nb) : rcp1p_exp2(a + nb); };
         const float2 eb = make_float2(EF ? __builtin_amdgcn_exp2f(bc.x) : bc.x, EF ? __builtin_amdgcn_exp2f(bc.y) : bc.y);
         auto fold = [&](float x, float bb) -> float { return EF ? x * bb : x + bb; };
-        // One node's walk.  HUB = false: the 8-lane group walks all of the node's incidences.  HUB = true (a node with more than
-        // hub_thr incidences, see edge_fwd_kernel): the whole wave is on this node, group g takes incidences g, g + 8, ... and the
-        // eight partial sums are combined in a fixed butterfly order; group 0 adds the pointer-head term and writes.
-        // (`hub` is wave-uniform and a run-time flag on purpose: one copy of the loop and of the pointer-head pass keeps the
-        // last-layer kernel inside its 64 registers)
-        auto node = [&](int v, bool valid, const bool HUB) {
-            const int KS = HUB ? 8 : 1;
-            int k = L.rp[v] + (HUB ? g : 0);
-            const int k1 = valid ? L.rp[v + 1] : 0;
-            const bool mine = valid && (!HUB || g == 0);
+        const int nchunks = (n + 7) >> 3;
+        // chunks are dealt to the waves in serpentine order (0..15, 31..16, 32..47, ...): the degree-sorted chunks get
+        // shorter and shorter, so plain round-robin would give wave 0 the longest chunk of every round
+        for (int rnd = 0, j = w; rnd * EDGE_WAVES < nchunks; ++rnd, j = rnd * EDGE_WAVES + ((rnd & 1) ? EDGE_WAVES - 1 - w : w)) {
+            if (j >= nchunks) continue;
+            const int vi = 8 * j + g;
+            const bool valid = vi < n;
+            const int v = L.ord[valid ? vi : n - 1];
+            int k = L.rp[v];
+            const int k1 = valid ? L.rp[v + 1] : k;
             const float4 own = pq4(v);
             const float pv0 = fold(own.x, eb.x), qv0 = fold(own.z, eb.x), pv1 = fold(own.y, eb.y), qv1 = fold(own.w, eb.y);
             const float2 sv = ds2(v);
@@ -1039,18 +993,18 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             };
             const uint16_t *nb16 = reinterpret_cast<const uint16_t *>(nbg);
             int un = NBG ? nb16[k < k1 ? k : 0] : 0;           // (NBG: the next id is requested one trip ahead)
-            for (; k < k1; k += KS) {
+            for (; k < k1; ++k) {
                 int u;
                 if (NBG) {
                     u = un;
-                    un = nb16[k + KS < k1 ? k + KS : k];
+                    un = nb16[k + 1 < k1 ? k + 1 : k];
                 } else {
                     u = L.nb[k];
                 }
                 const float2 su = ds2(u);
                 add(pq4(u), sv.x + su.x, sv.y + su.y);
             }
-            if (heads_on && mine) {
+            if (heads_on && valid) {
                 // candidate gradients live in global memory: fetch HB of them per trip so their latencies overlap;
                 // a padding entry has dm = 0 and adds exactly nothing
                 constexpr int HB = 3;
@@ -1071,14 +1025,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                     for (int i = 0; i < HB; ++i) add(pq4(uu[i]), dmh[i].x, dmh[i].y);
                 }
             }
-            if (HUB) {
-#pragma unroll
-                for (int sft = 8; sft <= 32; sft <<= 1) {
-                    aP0 += __shfl_xor(aP0, sft); aQ0 += __shfl_xor(aQ0, sft);
-                    aP1 += __shfl_xor(aP1, sft); aQ1 += __shfl_xor(aQ1, sft);
-                }
-            }
-            if (mine) {
+            if (valid) {
                 const float2 dP = make_float2(2.f * aP0, 2.f * aP1), dQ = make_float2(2.f * aQ0, 2.f * aQ1);     // 1/2 * 4
                 // pair order: (dP_ca, dP_ca+1, dQ_ca, dQ_ca+1) is chunk (lane & 3) of the node's row in panel 2p + ((lane >> 2) & 1)
                 *reinterpret_cast<float4 *>(dPQ + ((int64_t)(2 * p + ((lane >> 2) & 1)) * M + o + v) * 16 + 4 * (lane & 3)) =
@@ -1086,42 +1033,6 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                 sumdP.x += dP.x; sumdP.y += dP.y;
                 sumdQ.x += dQ.x; sumdQ.y += dQ.y;
             }
-        };
-        // hub nodes first (the prefix of the degree-sorted order with more than hub_thr incidences), one per wave visit
-        int NHUB = 0;
-        if (hub_thr > 0) {
-            for (int base = 0; base < n; base += 64) {
-                const int i = base + lane;
-                int d = 0;
-                if (i < n) {
-                    const int vv = L.ord[i];
-                    d = L.rp[vv + 1] - L.rp[vv];
-                }
-                const unsigned long long hot = __ballot(d > hub_thr);
-                NHUB += __popcll(hot);
-                if (hot != ~0ull) break;
-            }
-        }
-        const int nchunks = (n - NHUB + 7) >> 3;
-        const int hub_rounds = (NHUB + EDGE_WAVES - 1) / EDGE_WAVES, rounds = hub_rounds + (nchunks + EDGE_WAVES - 1) / EDGE_WAVES;
-        // ONE loop (one inlined copy of `node`): first the hub rounds (wave w takes hub node 16 r + w), then the chunks of eight
-        // nodes, dealt to the waves in serpentine order (0..15, 31..16, 32..47, ...): the degree-sorted chunks get shorter and
-        // shorter, so plain round-robin would give wave 0 the longest chunk of every round
-        for (int it = 0; it < rounds; ++it) {
-            const bool hub = it < hub_rounds;
-            int vi;
-            bool valid;
-            if (hub) {
-                vi = it * EDGE_WAVES + w;
-                valid = vi < NHUB;
-            } else {
-                const int rnd = it - hub_rounds;
-                const int j = rnd * EDGE_WAVES + ((rnd & 1) ? EDGE_WAVES - 1 - w : w);
-                if (j >= nchunks) continue;
-                vi = NHUB + 8 * j + g;
-                valid = vi < n;
-            }
-            node(L.ord[valid ? vi : n - 1], valid, hub);
         }
     };
     if (ef) walk(std::true_type{});
@@ -1163,7 +1074,7 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     do {                                                                                                              \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_, F_, D_, N_>), lds)) return rc_;  \
         hipLaunchKernelGGL((edge_bwd_kernel<L_, S_, F_, D_, N_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G,  \
-                           dhbarE, ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit, fa, pqflag, nfb, g_hub_thr);       \
+                           dhbarE, ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit, fa, pqflag, nfb);                  \
     } while (0)
         const bool dma = pqflag != nullptr;
         if (nbg) {

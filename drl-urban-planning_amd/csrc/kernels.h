@@ -133,7 +133,6 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
 
 // ---- graph.hip -------------------------------------------------------------------------
 __host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds = true, bool nblds = true);
-void set_edge_hub_thr(int v);              // tune knob "edge_hub_thr" (default 16): incidence count above which a node is walked by a whole wave
 void set_edge_min_lds(int bytes);          // tune knob "edge_min_lds": minimum dynamic LDS of the message-passing launches (co-scheduling lab)
 void set_bwd_nb_global(int on);            // tune knob "bwd_nb_global" (default on): large size class of the backward walks the neighbour ids from global memory
 // First GCN layer folded into the message-passing stage-in (edge.hip: fold_fill): the workgroup computes its P/Q (and

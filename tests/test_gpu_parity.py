@@ -68,7 +68,7 @@ def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
 def tune():
     """set native tune knobs for one test; every knob is put back to its default afterwards"""
     from drl_urban_planning_amd import native
-    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1, 'pq_exp': 1, 'nt_min_wgs': 128, 'bwd_nb_global': 1, 'edge_hub_thr': 16}
+    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1, 'pq_exp': 1, 'nt_min_wgs': 128, 'bwd_nb_global': 1}
     touched = []
 
     def _set(name, value):
@@ -406,18 +406,6 @@ def test_dma_stage_in_is_bit_identical_to_the_register_stage_in(D, L, heads, n_r
         for name, a, b in zip(('value', 'logp', 'entropy', 'grads'), ref, out):
             assert torch.equal(a, b), '%s differs from the register-staged path (repetition %d, max |diff| %.3e)' % (
                 name, rep, (a - b).abs().max().item())
-
-
-@pytest.mark.parametrize('thr', [0, 4, 16, 1000])
-@pytest.mark.parametrize('D,L,heads,n_range,T', [(128, 3, 4, (40, 90), 6), (256, 3, 1, (200, 345), 5)])
-def test_hub_node_threshold_matches_oracle(D, L, heads, n_range, T, thr, tune):
-    """Nodes with more than `edge_hub_thr` incidences are walked by a whole wave (their list dealt to the eight lane groups,
-    partial sums combined in a fixed butterfly order) instead of one 8-lane group: 0 / 1000 = never, 4 = most nodes,
-    16 = the default.  Every setting must match the oracle (forward rows, losses, every gradient)."""
-    tune('edge_hub_thr', thr)
-    cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
-                                   int(5.55 * n_range[1]) + 10, seed=37, road_fraction=0.3, n_range=n_range)
-    _check_against_oracle(cfg, sd, replay, heads, T)
 
 
 @pytest.mark.parametrize('gain,bias', [(40.0, 0.0), (1.0, 3.0), (400.0, 0.5), (12.0, 0.0)])
