@@ -58,18 +58,6 @@ __host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, boo
     return b;
 }
 
-// Last layer: how many candidate edges per row can be staged next to the graph slice without giving up the
-// second resident workgroup per CU (<= 80 KB each), or at all (<= 160 KB).  `fixed` = bytes staged regardless of
-// the candidate count (backward: the per-node candidate-incidence pointers), `per_cand` = bytes per candidate.
-static int aux_capacity(int64_t lds, int64_t fixed, int per_cand) {
-    // never trade the second resident workgroup for it (some slack: the allocation granularity is not 1 byte)
-    const int64_t limit = lds <= LDS_HALF ? LDS_HALF : LDS_LIMIT;
-    if (lds + fixed > limit) return -1;                                          // not even the fixed part fits
-    int64_t cap = (limit - lds - fixed) / per_cand / 8 * 8;
-    if (cap > 4096) cap = 4096;
-    return (int)cap;
-}
-
 struct EdgeLds {
     float2 *PQ;
     float *X;          // H (forward) or dS (backward)
@@ -537,9 +525,13 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     // last layer: the row's candidate edges (endpoints, live flag) next to the slice, so the pointer-head pass
     // below does not chase them through global memory
     const int nh = LAST ? m[2] : 0;
-    const bool cand_lds = LAST && FE && nh > 0 && nh <= aux_cap;
-    uint16_t *a_src = reinterpret_cast<uint16_t *>(L.aux), *a_dst = a_src + (aux_cap > 0 ? aux_cap : 0);
-    uint8_t *a_live = reinterpret_cast<uint8_t *>(a_dst + (aux_cap > 0 ? aux_cap : 0));
+    // (decided per WORKGROUP from what its own graph leaves of the launch's dynamic LDS `aux_cap` bytes: a launch is sized for
+    // the largest graph of the minibatch, which used to switch the staging off for every graph of it)
+    const int64_t aux_avail = (int64_t)aux_cap - (L.aux - smem);
+    const int nh8 = (nh + 7) & ~7;
+    const bool cand_lds = LAST && FE && nh > 0 && (int64_t)nh8 * 5 <= aux_avail;
+    uint16_t *a_src = reinterpret_cast<uint16_t *>(L.aux), *a_dst = a_src + nh8;
+    uint8_t *a_live = reinterpret_cast<uint8_t *>(a_dst + nh8);
     if (cand_lds) {
         for (int i = tid; i < nh; i += EDGE_THREADS) {
             a_src[i] = pk.he_src[m[11] + i];
@@ -692,6 +684,13 @@ void set_bwd_nb_global(int on) { g_bwd_nb_global = on ? 1 : 0; }
 static int g_fwd_h_hbm = 1;      // tune knob "fwd_h_hbm": the large size class of the forward keeps H in HBM (two workgroups per CU)
 void set_fwd_h_hbm(int on) { g_fwd_h_hbm = on ? 1 : 0; }
 
+// the folded kernels have no H-in-HBM / list-in-global forms: a minibatch whose largest graph does not fit HALF the LDS would
+// run their large size class at one workgroup per CU (DHM: 2 x 1.38 ms + 2 x 1.51 ms per step against 1.68 + 2.36 ms for the
+// plain kernels, profiles/r03_kernel_trace_dhm_d256.txt) -- such minibatches take the two K = 32 GEMMs instead
+bool edge_fold_pays(const MbView &mb) {
+    return edge_lds_bytes(mb.max_n, mb.max_inc, false, false, true, true) <= LDS_HALF &&
+           edge_lds_bytes(mb.max_n, mb.max_inc, true, false, true, true) <= LDS_HALF;
+}
 bool edge_fold_ok(const MbView &mb) {
     return edge_lds_bytes(mb.max_n, mb.max_inc, false, false, true, true) <= LDS_LIMIT &&
            edge_lds_bytes(mb.max_n, mb.max_inc, true, false, true, true) <= LDS_LIMIT;
@@ -733,29 +732,25 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     int rc = 0;
     if (lds_max <= LDS_HALF) {
         // every graph of the minibatch fits two workgroups per CU: one launch (+ the row's candidate lists on the last layer)
-        int64_t lds = lds_max;
-        int aux_cap = 0;
-        if (last && FE) {
-            aux_cap = std::max(aux_capacity(lds, 0, 5), 0);       // u16 src + u16 dst + u8 live per candidate
-            lds += a16((int64_t)aux_cap * 5);
-        }
-        rc = go(true, lds, aux_cap, 0);
+        // the last layer asks for the whole half: what a graph leaves of it holds its row's candidate lists
+        const int64_t lds = (last && FE) ? LDS_HALF : lds_max;
+        rc = go(true, lds, (int)lds, 0);
     } else {
         // a few large graphs must not cost every workgroup its neighbour on the CU: the graphs that fit in half the
         // LDS run in a two-per-CU launch, the rest in a second launch -- with H left in HBM if that keeps them at two
         // workgroups per CU (DHM-sized graphs: ~350 .. ~530 nodes), else staged with up to the whole LDS, or un-staged;
         // a workgroup of the wrong class exits at once
-        rc = go(true, LDS_HALF, 0, (int)LDS_HALF);
+        rc = go(true, LDS_HALF, (int)LDS_HALF, (int)LDS_HALF);
         if (rc == 0) {
             const int64_t lds_noh = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, true, false);
             if (!fold && g_fwd_h_hbm && lds_noh <= LDS_HALF) {
-                rc = go(true, lds_noh, 0, -(int)LDS_HALF, false);
+                rc = go(true, LDS_HALF, (int)LDS_HALF, -(int)LDS_HALF, false);
             } else if (lds_max <= LDS_LIMIT) {
-                rc = go(true, lds_max, 0, -(int)LDS_HALF);
+                rc = go(true, lds_max, (int)lds_max, -(int)LDS_HALF);
             } else {
                 const int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, false);
                 if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_fwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
-                rc = go(false, lds, 0, -(int)LDS_HALF);
+                rc = go(false, lds, (int)lds, -(int)LDS_HALF);
             }
         }
     }
@@ -897,10 +892,21 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     const int32_t *hpg = pk.hinc_ptr + m[13];
     const uint16_t *hnb = pk.hinc_nbr + 2 * (int64_t)m[11];
     const uint16_t *hhe = pk.hinc_he + 2 * (int64_t)m[11];
-    const bool hp_lds = heads_on && aux_cap >= 0, hl_lds = hp_lds && m[2] <= aux_cap;
+    // Decided per WORKGROUP from what its own graph leaves of the launch's dynamic LDS (`aux_cap` bytes; the launch is sized for
+    // the minibatch's largest graph, which used to switch all of this off for every graph): first the pointers, then the lists,
+    // then -- by LDS-DMA -- the row's slice of the pointer-head gradient dM itself, so that the candidate pass below is LDS-only.
+    const int nhc = heads_on ? m[2] : 0;
+    const int64_t aux_avail = (int64_t)aux_cap - (L.aux - smem);
+    const int64_t aux_fixed = a16(((int64_t)n + 1) * 4), aux_lists = a16((int64_t)nhc * 8);
+    const bool hp_lds = heads_on && aux_avail >= aux_fixed, hl_lds = hp_lds && aux_avail >= aux_fixed + aux_lists;
+    const bool dm_lds = DMA && hl_lds && aux_avail >= aux_fixed + aux_lists + (int64_t)nhc * 64;
     int *a_hp = reinterpret_cast<int *>(L.aux);
-    uint16_t *a_hnb = reinterpret_cast<uint16_t *>(L.aux + ((int64_t)n + 1 + 3) / 4 * 16);
-    uint16_t *a_hhe = a_hnb + 2 * (aux_cap > 0 ? aux_cap : 0);
+    uint16_t *a_hnb = reinterpret_cast<uint16_t *>(L.aux + aux_fixed);
+    uint16_t *a_hhe = a_hnb + 2 * nhc;
+    float *a_dm = reinterpret_cast<float *>(L.aux + aux_fixed + aux_lists);
+    if (DMA && dm_lds) {
+        dma_x_slice(a_dm, dMhe + ((int64_t)p * mb.Nhe + m[15]) * 16, nhc);
+    }
     if (hp_lds)
         for (int i = tid; i <= n; i += EDGE_THREADS) a_hp[i] = hpg[i];
     if (hl_lds) {
@@ -909,6 +915,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             reinterpret_cast<uint32_t *>(a_hhe)[i] = reinterpret_cast<const uint32_t *>(hhe)[i];
         }
     }
+    if (DMA && dm_lds) wait_vmcnt<0>();    // (the barrier below covers the other waves' parts)
     bool ef = false;                       // LDS holds the exp form (workgroup-uniform), see stage_pq_exp
     if (STAGE) {
         if (!batched && !dma) {
@@ -1018,7 +1025,8 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                         const int kk = in ? hk + i : hk;
                         const int he = hl_lds ? a_hhe[kk] : hhe[kk];
                         uu[i] = hl_lds ? a_hnb[kk] : hnb[kk];
-                        dmh[i] = *reinterpret_cast<const float2 *>(dMg + (int64_t)he * 16);
+                        dmh[i] = dm_lds ? *reinterpret_cast<const float2 *>(a_dm + he * 16 + ca)
+                                        : *reinterpret_cast<const float2 *>(dMg + (int64_t)he * 16);
                         if (!in) dmh[i] = make_float2(0.f, 0.f);
                     }
 #pragma unroll
@@ -1093,26 +1101,21 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     const int64_t lds_max = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, true);
     int rc = 0;
     if (lds_max <= LDS_HALF) {
-        int64_t lds = lds_max;
-        int aux_cap = -1;
-        if (last && dMhe) {
-            const int64_t fixed = a16(((int64_t)mb.max_n + 1) * 4);
-            aux_cap = aux_capacity(lds, fixed, 8);               // two u16 lists with two entries per candidate
-            if (aux_cap >= 0) lds += fixed + a16((int64_t)aux_cap * 8);
-        }
-        rc = go(true, lds, aux_cap, 0);
+        // the last layer asks for the whole half: what a graph leaves of it holds its candidate pointers / lists / dM slice
+        const int64_t lds = (last && dMhe) ? LDS_HALF : lds_max;
+        rc = go(true, lds, (int)lds, 0);
     } else {                                                      // size classes, see launch_edge_fwd
-        rc = go(true, LDS_HALF, -1, (int)LDS_HALF);
+        rc = go(true, LDS_HALF, (int)LDS_HALF, (int)LDS_HALF);
         if (rc == 0) {
             const int64_t lds_nonb = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, true, true, false);
             if (pqflag && g_bwd_nb_global && lds_nonb <= LDS_HALF_HARD) {
-                rc = go(true, lds_nonb, -1, -(int)LDS_HALF, true);      // neighbour ids from global memory: still two per CU
+                rc = go(true, LDS_HALF_HARD, (int)LDS_HALF_HARD, -(int)LDS_HALF, true);      // neighbour ids from global memory: still two per CU
             } else if (lds_max <= LDS_LIMIT) {
-                rc = go(true, lds_max, -1, -(int)LDS_HALF);
+                rc = go(true, lds_max, (int)lds_max, -(int)LDS_HALF);
             } else {
                 const int64_t lds = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, false);
                 if (lds > LDS_LIMIT) return fail(UPAMD_E_LIMIT, "edge_bwd: graph too large for LDS (n=%d, 2e=%d)", mb.max_n, mb.max_inc);
-                rc = go(false, lds, -1, -(int)LDS_HALF);
+                rc = go(false, lds, (int)lds, -(int)LDS_HALF);
             }
         }
     }

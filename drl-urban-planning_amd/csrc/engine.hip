@@ -339,7 +339,10 @@ static bool pq_exp_layer(const GemmNT &g, int l, int K) { return g_pq_exp && K =
 // (I % 128 == 0), otherwise one grouped-kernel launch with panel-major operands (narrow models: D = 16 ... 64)
 // tune knob "fold_layer1" (default on): first GCN layer computed inside the message-passing kernels
 static int g_fold_layer1 = 1;
-static bool fold_layer1(const MbView &mb, int L, int K) { return g_fold_layer1 && K == 1 && L >= 2 && edge_fold_ok(mb); }
+// (2 = fold whenever the slices fit the LDS at all, the round-2 rule; 1 = only where every graph fits half of it)
+static bool fold_layer1(const MbView &mb, int L, int K) {
+    return g_fold_layer1 && K == 1 && L >= 2 && (g_fold_layer1 == 2 ? edge_fold_ok(mb) : edge_fold_pays(mb));
+}
 
 int node_tn(const float *A, int I, const float *Bm, int J, int64_t rows, float *slabs, int *S_out, hipStream_t st, Profiler *prof) {
     if (tn_shape_mfma_ok(I, J)) return launch_gemm_tn(A, I, Bm, J, rows, slabs, S_out, st, prof);
@@ -444,7 +447,7 @@ int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch
 
 }  // namespace
 
-void upamd::set_fold_layer1(int on) { g_fold_layer1 = on ? 1 : 0; }
+void upamd::set_fold_layer1(int on) { g_fold_layer1 = on == 2 ? 2 : (on ? 1 : 0); }
 void upamd::set_pq_exp(int on) { g_pq_exp = on ? 1 : 0; }
 void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
 
