@@ -339,9 +339,11 @@ static bool pq_exp_layer(const GemmNT &g, int l, int K) { return g_pq_exp && K =
 // (I % 128 == 0), otherwise one grouped-kernel launch with panel-major operands (narrow models: D = 16 ... 64)
 // tune knob "fold_layer1" (default on): first GCN layer computed inside the message-passing kernels
 static int g_fold_layer1 = 1;
-// (2 = fold whenever the slices fit the LDS at all, the round-2 rule; 1 = only where every graph fits half of it)
+// (1 = fold whenever the slices fit the LDS at all; 2 = only where every graph fits HALF of it.  Measured, round 3: with the
+// K = 32 GEMMs instead of the fold's one-workgroup-per-CU large size class DHM minibatches gain 0.4 %, mixed ones lose 1 %
+// (profiles/r03_lab_fold_rule.log) -- the default stays 1)
 static bool fold_layer1(const MbView &mb, int L, int K) {
-    return g_fold_layer1 && K == 1 && L >= 2 && (g_fold_layer1 == 2 ? edge_fold_ok(mb) : edge_fold_pays(mb));
+    return g_fold_layer1 && K == 1 && L >= 2 && (g_fold_layer1 == 2 ? edge_fold_pays(mb) : edge_fold_ok(mb));
 }
 
 int node_tn(const float *A, int I, const float *Bm, int J, int64_t rows, float *slabs, int *S_out, hipStream_t st, Profiler *prof) {
