@@ -354,6 +354,28 @@ def main():
                                                      'WRITE_SIZE, separate passes over bench.py, averaged over %d launches'
                                                      % k['launches'])
         out['kernel_ms_per_step'] = {k: v['total_ms'] / args.steps for k, v in kern.items()}
+    if 'edge_fwd' in kern and 'edge_bwd' in kern:
+        # the message-passing group (6 launches per step at L = 3): second-largest share of the step, no MFMA work to speak of.
+        # Algorithmic HBM bytes = the slice copies it cannot avoid (per layer: P/Q + H read, H written; backward: P/Q + G read,
+        # dP|dQ written; the folded first layer reads the 128-byte raw feature row instead of P/Q + H; the last layer writes /
+        # reads the candidates' head inputs), measured time from HIP events; the vector-ALU share comes from the committed PMC
+        # pass over this same command (tools/pmc_util.py -> profiles/pmc_util.json), null when absent
+        Mn = w['B'] * nodes_per_sample
+        nhe = float(meta[:, 2].mean()) * w['B']
+        D, L = w['D'], w['L']
+        fwd = (L - 1) * Mn * (2 * D + D + D) * 4 + Mn * (128 + D * 4) + nhe * D * 4
+        bwd = (L - 1) * Mn * (2 * D + D + 2 * D) * 4 + Mn * (128 + D * 4 + 2 * D * 4) + nhe * D * 4
+        ms = (kern['edge_fwd']['total_ms'] + kern['edge_bwd']['total_ms']) / args.steps
+        mp = {'kernels': 'edge_fwd + edge_bwd', 'ms_per_step': ms, 'share_of_step': ms / out['ms_per_step'],
+              'algorithmic_bytes_per_step': fwd + bwd, 'achieved': (fwd + bwd) / (ms * 1e-3) / 1e9, 'unit': 'GB/s',
+              'peak': 8000.0, 'frac_of_hbm_peak': (fwd + bwd) / (ms * 1e-3) / 8e12, 'bound': 'valu', 'valu_busy': None}
+        util = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_util.json')
+        if args.workload == 'hlg_d256' and not args.minibatch and os.path.exists(util):
+            with open(util) as fh:
+                u = json.load(fh).get('kernels', {})
+            mp['valu_busy'] = {k: u[k]['valu_busy'] for k in u if k.startswith('edge_')}
+            mp['valu_busy_source'] = 'profiles/pmc_util.json: rocprofv3 --pmc SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE, one pass over bench.py'
+        out['message_passing'] = mp
     if ctx.world == 1 and not args.no_cpu_baseline and args.cpu_baseline != 'off':
         out['cpu_baseline'] = cpu_baseline(w, args.cpu_baseline)
     print(json.dumps(out))

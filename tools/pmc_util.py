@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('directory')
     ap.add_argument('--md')
+    ap.add_argument('--json')
     args = ap.parse_args()
     names = ('GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU')
     data = {c: read_counter(args.directory, c) for c in names}
@@ -29,6 +30,7 @@ def main():
             agg[short_name(k)]['n_' + c] += len(vals)
     lines = ['| kernel | launches | duration (k cycles) | MFMA pipe busy | VALU busy |', '|---|---|---|---|---|']
     rows = []
+    js = {}
     for name, a in agg.items():
         n = max(a['n_GRBM_GUI_ACTIVE'], 1)
         dur = a['GRBM_GUI_ACTIVE'] / 8.0 / n
@@ -37,6 +39,7 @@ def main():
         mfma = a['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / n / dur
         valu = a['SQ_ACTIVE_INST_VALU'] * 4.0 / 1024.0 / n / dur
         rows.append((dur * n, '| %s | %d | %.0f | %.0f %% | %.0f %% |' % (name, n, dur / 1e3, 100 * mfma, 100 * valu)))
+        js[name] = {'launches': int(n), 'duration_cycles': dur, 'mfma_busy': mfma, 'valu_busy': valu}
     lines += [r for _, r in sorted(rows, reverse=True)]
     text = '\n'.join(lines)
     if args.md:
@@ -44,6 +47,11 @@ def main():
             fh.write('# Pipe utilisation per kernel of one PPO step (rocprofv3 PMC, one pass)\n\n'
                      'rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace '
                      '(hlg_d256, bench.py --steps 4 --warmup 1)\n\n%s\n' % text)
+    if args.json:
+        import json
+        with open(args.json, 'w') as fh:
+            json.dump({'kernels': js, 'source': 'rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES '
+                                                'SQ_ACTIVE_INST_VALU --kernel-trace over bench.py (hlg_d256)'}, fh, indent=1)
     print(text)
 
 
