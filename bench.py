@@ -176,6 +176,13 @@ def main():
                     help='weak (default): the minibatch per GPU is fixed; strong: the GLOBAL minibatch is fixed and split')
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1 behind Python's back (RCCL prints
+    # its WARN / version lines there, from its own threads, and they were found spliced INTO the JSON line) are sent to stderr
+    # for the rest of the process; the result goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from drl_urban_planning_amd import PPOUpdater, synth, DistContext
 
     w = dict(WORKLOADS[args.workload])
@@ -378,7 +385,9 @@ def main():
         out['message_passing'] = mp
     if ctx.world == 1 and not args.no_cpu_baseline and args.cpu_baseline != 'off':
         out['cpu_baseline'] = cpu_baseline(w, args.cpu_baseline)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + '\n').encode())
+    os.close(json_fd)
 
 
 if __name__ == '__main__':
