@@ -18,7 +18,7 @@ using namespace upamd;
 // side stream of the forked step (see fork_side) + its fork / join events
 struct SideCtx {
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
 };
 
 struct upamd_engine {
@@ -276,6 +276,8 @@ static int side_ready(upamd_engine *eng, hipStream_t st, SideCtx **out) {
         UPAMD_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+        UPAMD_HIP(hipEventCreateWithFlags(&c.ev_a, hipEventDisableTiming));
+        UPAMD_HIP(hipEventCreateWithFlags(&c.ev_b, hipEventDisableTiming));
     }
     *out = &c;
     return 0;
@@ -292,6 +294,18 @@ static int join_side(SideCtx *c, hipStream_t st) {
     UPAMD_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
     return 0;
 }
+
+// `to` continues after everything enqueued on `from` so far (ev is re-recorded: the host enqueues in order)
+static int stream_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
+    UPAMD_HIP(hipEventRecord(ev, from));
+    UPAMD_HIP(hipStreamWaitEvent(to, ev, 0));
+    return 0;
+}
+// tune knob "side_heads" (default on, needs side_stream): the land-use pointer-head chain -- forward: its first Linear next to the
+// attention; backward: softmax / second-Linear backward, feature backward and weight gradient next to the value-head chain and
+// the attention backward -- runs on the side stream.  All of these are HBM-bound kernels of 0.1-0.3 ms that used to queue one
+// behind the other; the two chains only meet at the last GCN layer's backward (dS from the attention side, dM from the head side).
+static int g_side_heads = 1;
 
 // An error return between fork and join must not leave side-stream work running on a workspace the caller may free next:
 // the guard drains the side stream unless the join was reached
@@ -452,6 +466,7 @@ int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch
 void upamd::set_fold_layer1(int on) { g_fold_layer1 = on == 2 ? 2 : (on ? 1 : 0); }
 void upamd::set_pq_exp(int on) { g_pq_exp = on ? 1 : 0; }
 void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
+void upamd::set_side_heads(int on) { g_side_heads = on ? 1 : 0; }
 
 extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
     if (!out) return fail(UPAMD_E_INVALID, "upamd_engine_create: out is null");
@@ -485,6 +500,8 @@ extern "C" void upamd_engine_destroy(upamd_engine *eng) {
         (void)hipStreamSynchronize(c.side);
         (void)hipEventDestroy(c.ev_fork);
         (void)hipEventDestroy(c.ev_join);
+        (void)hipEventDestroy(c.ev_a);
+        (void)hipEventDestroy(c.ev_b);
         (void)hipStreamDestroy(c.side);
     }
     delete eng;
@@ -574,6 +591,15 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     // head.hip: the land-use head's first Linear works on the m half of FE alone (the m*c half is then never written)
     const bool fe_half = head_fe_half_ok(D, x.h0l);
     const int fe_full = fe_half ? 0 : 1;
+    bool head_on_side = false;            // the land-use head's first Linear was launched on the side stream (joined below)
+    // (launch-bound small models gain nothing from the fork: its two event round trips cost more than they hide)
+    const bool forked = !x.mlp && g_side_stream != 0 && !defer_node_tn(x.D);
+    SideGuard side_guard;
+    SideCtx *sc = nullptr;
+    if (forked) {
+        CK(side_ready(eng, st, &sc));
+        side_guard.c = sc;
+    }
 
     if (x.mlp) {
         // ===== rl-mlp encoder (MLPStateEncoder, state_encoder.py:217-308): node encoder only, pooled means, no attention
@@ -664,14 +690,6 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     }
     // ---- 3. per-sample chain before the graph part (+ row descriptors, + node-feature gather)
     const ChainDims cd = chain_dims(d, x, B);
-    // (launch-bound small models gain nothing from the fork: its two event round trips cost more than they hide)
-    const bool forked = g_side_stream != 0 && !defer_node_tn(x.D);
-    SideGuard side_guard;
-    SideCtx *sc = nullptr;
-    if (forked) {
-        CK(side_ready(eng, st, &sc));
-        side_guard.c = sc;
-    }
     {
         ChainFwdPre a;
         memset(&a, 0, sizeof(a));
@@ -759,6 +777,13 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
         CK(launch_edge_fwd(pk, mb, D, l == x.L, W(S_PQ + l), PR(P.edge_b[l - 1]), W(S_H + l - 1), W(S_H + l), W(S_HBARV), W(S_HBARE),
                            W(S_C), (l == x.L && land) ? W(S_FE) : nullptr, st, prof, (l == 1 && fold) ? &fa : nullptr, fe_full, pqflag));
     }
+    // the land-use head's first Linear (needs FE of the last layer, C, constb) goes to the side stream next to the attention
+    if (forked && g_side_heads && land && !road && fe_half) {
+        CK(fork_side(sc, st));
+        side_guard.armed = true;
+        CK(launch_head_hidden_fwd(pk, mb, D, W(S_FE), W(S_C), W(S_W1F), W(S_CONSTB), W(S_HIDL), sc->side));
+        head_on_side = true;
+    }
     // ---- 5. attention core, then the per-sample chain after it (out-projection, state_value, value head)
     CK(launch_attn_fwd(pk, mb, D, x.heads, W(S_H + x.L), W(S_R), W(S_ALPHA), W(S_S), st));
     {
@@ -776,7 +801,7 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     }
     const float *HL = W(S_H + x.L);
     // ---- 6. pointer heads (policy.py:19-65)
-    if (land) {
+    if (land && !head_on_side) {
         // factorised first Linear: hid = tanh(FE [Wa+Wd | Wc]^T + ((Wb-Wd) c_b + b1)), the bias rows are
         // pre-written into hid and accumulated in place
         if (fe_half) {
@@ -790,6 +815,10 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     if (road) {
         CK(launch_road_gather(pk, mb, D, HL, W(S_XR), st));
         CK(launch_gemm_nt(W(S_XR), mb.Nrn, D, PR(P.road_w[0]), x.h0r, PR(P.road_b0), nullptr, W(S_HIDR), 1, st, prof));
+    }
+    if (head_on_side) {
+        CK(join_side(sc, st));
+        side_guard.armed = false;
     }
     // second (bias-free) Linear + masked softmax + log-prob / entropy in one kernel; the entropy is kept for the backward
     CK(launch_pointer_fwd2(pk, mb, W(S_HIDL), PR(P.land_w[1]), x.h0l, W(S_HIDR), PR(P.road_w[1]), x.h0r, W(S_Z_HE), W(S_Z_RN), W(S_P_HE),
@@ -957,6 +986,23 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(red2.flush());
         return UPAMD_OK;
     }
+    // The forked step: side stream next to the caller's.  With `heads_side` the fork happens HERE and the pointer-head chain
+    // (softmax / second-Linear backward -> feature backward -> weight gradient) runs on the side stream next to the value-head
+    // chain and the attention backward on the caller's; the two meet at the last GCN layer's backward (ev_b: dM is ready) and
+    // at the per-sample chain (ev_a: dr is ready).  Otherwise the fork is where round 2 had it (step 4).
+    const bool forked = g_side_stream != 0 && !defer;
+    const bool heads_side = forked && g_side_heads && land && !road && fe_half && he_feat_bwd_fused_ok(D, x.h0l);
+    SideGuard side_guard;
+    SideCtx *sc = nullptr;
+    if (forked) {
+        CK(side_ready(eng, st, &sc));
+        side_guard.c = sc;
+    }
+    if (heads_side) {
+        CK(fork_side(sc, st));
+        side_guard.armed = true;
+    }
+    hipStream_t hs = heads_side ? sc->side : st;      // the stream of the pointer-head chain
     // ---- 1. per-sample chain, the part after the attention: value head, numerical encoder, out-projection, Wvv
     {
         ChainBwdPost a;
@@ -976,19 +1022,25 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // ---- 2. attention core: writes G^L (mean + attention terms) and dr
     float *G = W(S_G0), *Gn = W(S_G1);
     CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W(S_R), W(S_ALPHA), W(S_S), W(S_DS), dhbarV, x.Wp, G, W(S_DR), st));
+    if (heads_side) UPAMD_HIP(hipEventRecord(sc->ev_a, st));      // dr + everything chain_bwd_post wrote: the side chain waits for it below
     // ---- 3. pointer heads: softmax backward + second-Linear backward fused
     CK(launch_pointer_bwd2(pk, mb, W(S_Z_HE), W(S_Z_RN), W(S_P_HE), W(S_P_RN), W(S_ENTK), W(S_LSE), dlogp_dev, dent_dev, W(S_HIDL),
                            PR(P.land_w[1]), x.h0l, W(S_HIDR), PR(P.road_w[1]), x.h0r, W(S_DZ_HE), W(S_DZ_RN), W(S_DPREL), W(S_DPRER),
-                               land ? W(S_CSP0) : nullptr, land ? W(S_DCONST) : nullptr, road ? W(S_CSP2) : nullptr, road ? W(S_CSP3) : nullptr, st));
+                               land ? W(S_CSP0) : nullptr, land ? W(S_DCONST) : nullptr, road ? W(S_CSP2) : nullptr, road ? W(S_CSP3) : nullptr, hs));
     if (land) {
         // dw2 = sum_rows (sum_k dz hid), db1 = sum_rows dconst: the row sums come out of pointer_bwd2
         CK(red1.add(W(S_CSP0), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
         CK(red1.add(W(S_DCONST), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
+        if (heads_side) {
+            // feature backward first (the last GCN layer's backward on the caller's stream waits for its dM), then the weight gradient
+            CK(launch_he_feat_bwd_fused(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_W1FT), W(S_DMHE), W(S_DC_HEAD), hs));
+            CK(stream_after(st, hs, sc->ev_b));
+        }
         // dW1f = dpre^T FE (mapped back onto [Wa|Wb|Wc|Wd] after the reduction, together with dWbd = dconst^T C)
         // (with FE = m only: per-graph products, the c part weighted by c_b inside the kernel -- head.hip)
         if (fe_half) {
             int Sn = 1;
-            CK(launch_head_wgrad(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_SLAB_FE), &Sn, st));
+            CK(launch_head_wgrad(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_SLAB_FE), &Sn, hs));
             CK(red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
         } else {
             CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
@@ -997,7 +1049,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         }
         // dFE = dpre W1f, then the feature backward (dMhe for the last GCN layer, dC from the m*c term); with the shipped
         // head width (h0 = 32) one kernel does both and dFE never exists in HBM
-        if (he_feat_bwd_fused_ok(D, x.h0l)) {
+        if (heads_side) {
+            // (launched above)
+        } else if (he_feat_bwd_fused_ok(D, x.h0l)) {
             CK(launch_he_feat_bwd_fused(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_W1FT), W(S_DMHE), W(S_DC_HEAD), st));
         } else {
             CK(launch_gemm_nt(W(S_DPREL), mb.Nhe, x.h0l, W(S_W1FT), 2 * D, nullptr, nullptr, W(S_DFE), 0, st, prof));
@@ -1066,12 +1120,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         return 0;
     };
     // ---- 4. per-sample chain, the part before the graph: dr -> dq1 -> dq0 -> dC (+ the land-use head's two dC terms)
-    const bool forked = g_side_stream != 0 && !defer;
-    SideGuard side_guard;
-    SideCtx *sc = nullptr;
-    if (forked) {
-        CK(side_ready(eng, st, &sc));
-        side_guard.c = sc;
+    if (heads_side) {
+        UPAMD_HIP(hipStreamWaitEvent(sc->side, sc->ev_a, 0));      // dr, datt, do, ... of the caller's stream
+    } else if (forked) {
         CK(fork_side(sc, st));
         side_guard.armed = true;
     }
