@@ -19,6 +19,8 @@ using namespace upamd;
 struct SideCtx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipEvent_t pool[8] = {};             // round-robin events of the finer-grained hand-overs (stream_after / event_on)
+    int pool_next = 0;
 };
 
 struct upamd_engine {
@@ -33,6 +35,9 @@ struct upamd_engine {
 
 namespace {
 
+// tune knob "side_wgrad" (default off, lab): the weight-gradient GEMM of GCN layer l on the side stream, i.e. next to the same
+// layer's dgrad GEMM and the NEXT layer's (vector-ALU-bound) message-passing backward; dP|dQ alternates between two buffers
+static int g_side_wgrad = 0;
 constexpr int MAXL = 16;
 constexpr int MAXK = UPAMD_MAX_EDGE_FC;
 static inline int LK(int l, int k) { return (l - 1) * (MAXK + 1) + k; }      // l = 1 .. L, k = 0 .. MAXK
@@ -44,7 +49,7 @@ enum Slot : int {
     S_XR, S_HIDR, S_Z_RN, S_P_RN, S_LSE, S_ENTK,
     // backward
     S_DSV, S_DATT, S_DO, S_DS, S_DR, S_DQ1, S_DQ0, S_DC, S_DC_HEAD, S_DCONST, S_DWKK, S_DWVV, S_DBVV, S_DW1F, S_DWBD, S_TN, S_DWC1,
-    S_DZ_HE, S_DZ_RN, S_DPREL, S_DFE, S_DMHE, S_DPRER, S_DXR, S_G0, S_G1, S_DPQ, S_SLAB_SMALL, S_SLAB_XP1, S_SLAB_XP2, S_SLAB_FE,
+    S_DZ_HE, S_DZ_RN, S_DPREL, S_DFE, S_DMHE, S_DPRER, S_DXR, S_G0, S_G1, S_DPQ, S_DPQ2, S_SLAB_SMALL, S_SLAB_XP1, S_SLAB_XP2, S_SLAB_FE,
     S_SLAB_XR, S_CSP0, S_CSP1, S_CSP2, S_CSP3,
     S_WCAT,                               // + l (0 .. L-1)
     S_WCATT = S_WCAT + MAXL,              // + l
@@ -180,6 +185,7 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     add(S_DZ_HE, NH); add(S_DZ_RN, NR); add(S_DPREL, NH * x.h0l); add(S_DFE, NH * 2 * D); add(S_DMHE, NH * D);
     add(S_DPRER, NR * x.h0r); add(S_DXR, NR * D);
     add(S_G0, M * D); add(S_G1, M * D); add(S_DPQ, M * 2 * D);
+    if (g_side_wgrad) add(S_DPQ2, M * 2 * D);      // second dP|dQ buffer: layer l's weight gradient may still read its own
     // small models (no MFMA-tiled weight-gradient shapes): the node-level dY^T X products join the step's one grouped
     // launch at the end, so every layer's dP | dQ has to survive until then
     if (defer_node_tn(D))
@@ -278,6 +284,7 @@ static int side_ready(upamd_engine *eng, hipStream_t st, SideCtx **out) {
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_a, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_b, hipEventDisableTiming));
+        for (hipEvent_t &e : c.pool) UPAMD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     *out = &c;
     return 0;
@@ -306,6 +313,7 @@ static int stream_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
 // the attention backward -- runs on the side stream.  All of these are HBM-bound kernels of 0.1-0.3 ms that used to queue one
 // behind the other; the two chains only meet at the last GCN layer's backward (dS from the attention side, dM from the head side).
 static int g_side_heads = 1;
+static hipEvent_t next_event(SideCtx *c) { return c->pool[c->pool_next++ & 7]; }
 
 // An error return between fork and join must not leave side-stream work running on a workspace the caller may free next:
 // the guard drains the side stream unless the join was reached
@@ -467,6 +475,7 @@ void upamd::set_fold_layer1(int on) { g_fold_layer1 = on == 2 ? 2 : (on ? 1 : 0)
 void upamd::set_pq_exp(int on) { g_pq_exp = on ? 1 : 0; }
 void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
 void upamd::set_side_heads(int on) { g_side_heads = on ? 1 : 0; }
+void upamd::set_side_wgrad(int on) { g_side_wgrad = on ? 1 : 0; }
 
 extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
     if (!out) return fail(UPAMD_E_INVALID, "upamd_engine_create: out is null");
@@ -502,6 +511,7 @@ extern "C" void upamd_engine_destroy(upamd_engine *eng) {
         (void)hipEventDestroy(c.ev_join);
         (void)hipEventDestroy(c.ev_a);
         (void)hipEventDestroy(c.ev_b);
+        for (hipEvent_t e : c.pool) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(c.side);
     }
     delete eng;
@@ -863,6 +873,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     std::vector<std::function<int()>> after_gtn;
     const bool defer = defer_node_tn(x.D);
     // slabs = A[rows, I]^T Bm[rows, J] (panel-major operands) followed by red_add(S) -- at once, or as a grouped job
+    hipStream_t tn_stream = st;          // (the side stream for the GCN weight gradients under tune knob side_wgrad)
     auto node_tn_red = [&](const float *A, int I, const float *Bm, int J, int64_t rows, float *slabs,
                            std::function<int(int)> red_add) -> int {
         int Sn = 1;
@@ -871,7 +882,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             after_gtn.push_back([red_add, Sn]() { return red_add(Sn); });
             return 0;
         }
-        CK(node_tn(A, I, Bm, J, rows, slabs, &Sn, st, prof));
+        CK(node_tn(A, I, Bm, J, rows, slabs, &Sn, tn_stream, prof));
         return red_add(Sn);
     };
     red1.st = st; red2.st = st;
@@ -1139,9 +1150,13 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // ---- 5. GCN layers, last to first
     const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
+    const bool wgrad_side = forked && g_side_wgrad && !defer && x.K == 1 && pl.off[S_DPQ2] >= 0;
+    hipEvent_t wgrad_done[MAXL + 2] = {};
     for (int l = x.L; l >= 1; --l) {
         const bool last = (l == x.L);
-        float *dPQ = defer ? W(S_DPQL + l) : W(S_DPQ);
+        float *dPQ = defer ? W(S_DPQL + l) : ((wgrad_side && ((x.L - l) & 1)) ? W(S_DPQ2) : W(S_DPQ));
+        // this layer's dP|dQ goes into the buffer layer l + 2 used: its weight gradient (side stream) must have read it
+        if (wgrad_side && l + 2 <= x.L && wgrad_done[l + 2]) UPAMD_HIP(hipStreamWaitEvent(st, wgrad_done[l + 2], 0));
         if (x.K > 1) {
             // backward through the sub-layers on the per-incidence rows (deep_edge.hip), top to bottom:
             //   dpre_K = 1/2 (dS_src + dS_dst [+ head term]) (1 - A_K^2);  for j = K-1 .. 1 (linear_j: A_j -> A_j+1):
@@ -1171,9 +1186,18 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
         CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
         if (l > 1) {
+            if (wgrad_side) {
+                CK(stream_after(sc->side, st, next_event(sc)));      // dP|dQ of this layer is complete
+                tn_stream = sc->side;
+            }
             CK(node_tn_red(dPQ, 2 * D, W(S_H + l - 1), D, mb.M, W(S_SLAB_W + l), [&, l](int Sn) {
                 return red1.add(W(S_SLAB_W + l), Sn, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D);
             }));
+            if (wgrad_side) {
+                tn_stream = st;
+                wgrad_done[l] = next_event(sc);
+                UPAMD_HIP(hipEventRecord(wgrad_done[l], sc->side));
+            }
             CK(launch_gemm_nt(dPQ, mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
             std::swap(G, Gn);
         } else {
