@@ -35,9 +35,15 @@ struct upamd_engine {
 
 namespace {
 
-// tune knob "side_wgrad" (default off, lab): the weight-gradient GEMM of GCN layer l on the side stream, i.e. next to the same
-// layer's dgrad GEMM and the NEXT layer's (vector-ALU-bound) message-passing backward; dP|dQ alternates between two buffers
-static int g_side_wgrad = 0;
+// tune knob "side_wgrad": the weight-gradient GEMM of GCN layer l on the side stream next to the same layer's dgrad GEMM (dP|dQ
+// alternates between two buffers).  Measured (profiles/r03_lab_side_streams.log): two big GEMMs sharing the matrix pipe lose 2.5 %
+// of the 2048-row step, but at <= 256 rows per step neither GEMM fills the chip (2.9 rounds of workgroups) and running them
+// together gains 3 % -- so the default (1) applies it to minibatches of at most SIDE_WGRAD_MAX_NODES nodes; 2 = always, with the
+// weight gradient BEHIND the dgrad, i.e. next to the next layer's message passing (-2 %: the walk and the GEMM slow each other
+// more than they overlap); 3 = always next to the dgrad; 0 = never
+static int g_side_wgrad = 1;
+constexpr int64_t SIDE_WGRAD_MAX_NODES = 98304;
+static bool side_wgrad_on(int64_t M) { return g_side_wgrad >= 2 || (g_side_wgrad == 1 && M <= SIDE_WGRAD_MAX_NODES); }
 constexpr int MAXL = 16;
 constexpr int MAXK = UPAMD_MAX_EDGE_FC;
 static inline int LK(int l, int k) { return (l - 1) * (MAXK + 1) + k; }      // l = 1 .. L, k = 0 .. MAXK
@@ -185,7 +191,7 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     add(S_DZ_HE, NH); add(S_DZ_RN, NR); add(S_DPREL, NH * x.h0l); add(S_DFE, NH * 2 * D); add(S_DMHE, NH * D);
     add(S_DPRER, NR * x.h0r); add(S_DXR, NR * D);
     add(S_G0, M * D); add(S_G1, M * D); add(S_DPQ, M * 2 * D);
-    if (g_side_wgrad) add(S_DPQ2, M * 2 * D);      // second dP|dQ buffer: layer l's weight gradient may still read its own
+    if (side_wgrad_on(M)) add(S_DPQ2, M * 2 * D);      // second dP|dQ buffer: layer l's weight gradient may still read its own
     // small models (no MFMA-tiled weight-gradient shapes): the node-level dY^T X products join the step's one grouped
     // launch at the end, so every layer's dP | dQ has to survive until then
     if (defer_node_tn(D))
@@ -475,7 +481,7 @@ void upamd::set_fold_layer1(int on) { g_fold_layer1 = on == 2 ? 2 : (on ? 1 : 0)
 void upamd::set_pq_exp(int on) { g_pq_exp = on ? 1 : 0; }
 void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
 void upamd::set_side_heads(int on) { g_side_heads = on ? 1 : 0; }
-void upamd::set_side_wgrad(int on) { g_side_wgrad = on ? 1 : 0; }
+void upamd::set_side_wgrad(int on) { g_side_wgrad = (on >= 0 && on <= 3) ? on : 1; }
 
 extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
     if (!out) return fail(UPAMD_E_INVALID, "upamd_engine_create: out is null");
@@ -1150,7 +1156,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // ---- 5. GCN layers, last to first
     const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
-    const bool wgrad_side = forked && g_side_wgrad && !defer && x.K == 1 && pl.off[S_DPQ2] >= 0;
+    bool g1_done = false;
+    const bool wgrad_side = forked && side_wgrad_on(mb.M) && !defer && x.K == 1 && pl.off[S_DPQ2] >= 0;
     hipEvent_t wgrad_done[MAXL + 2] = {};
     for (int l = x.L; l >= 1; --l) {
         const bool last = (l == x.L);
@@ -1186,8 +1193,14 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
         CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
         if (l > 1) {
+            // side_wgrad = 1: the weight gradient starts next to this layer's dgrad; 2: behind it, i.e. next to the NEXT layer's
+            // message-passing backward (the dgrad is launched first and the side stream waits for it)
+            if (wgrad_side && g_side_wgrad == 2) {
+                CK(launch_gemm_nt(dPQ, mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
+                std::swap(G, Gn);
+            }
             if (wgrad_side) {
-                CK(stream_after(sc->side, st, next_event(sc)));      // dP|dQ of this layer is complete
+                CK(stream_after(sc->side, st, next_event(sc)));      // dP|dQ of this layer is complete (2: and its dgrad has run)
                 tn_stream = sc->side;
             }
             CK(node_tn_red(dPQ, 2 * D, W(S_H + l - 1), D, mb.M, W(S_SLAB_W + l), [&, l](int Sn) {
@@ -1198,8 +1211,21 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                 wgrad_done[l] = next_event(sc);
                 UPAMD_HIP(hipEventRecord(wgrad_done[l], sc->side));
             }
-            CK(launch_gemm_nt(dPQ, mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
-            std::swap(G, Gn);
+            if (!(wgrad_side && g_side_wgrad == 2)) {
+                CK(launch_gemm_nt(dPQ, mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
+                std::swap(G, Gn);
+            }
+            if (l == 2 && forked && g_side_heads && !defer && x.K == 1) {
+                // G^1 is complete: the node encoder's HBM-bound G^1^T Xp product (J = 32) goes to the side stream, next to the
+                // first layer's message-passing backward and its own dPQ_1^T Xp product
+                CK(stream_after(sc->side, st, next_event(sc)));
+                tn_stream = sc->side;
+                CK(node_tn_red(G, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), [&](int Sn) {
+                    return red1.add(W(S_SLAB_XP2), Sn, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b));
+                }));
+                tn_stream = st;
+                g1_done = true;
+            }
         } else {
             // layer 1: H_0 = Xp We^T + be, so dWcat_1 = dPQ_1^T H_0 = (dPQ_1^T Xp) We^T + colsum(dPQ_1) (x) be --
             // a J = 32 reduction over the nodes instead of a full-size weight-gradient GEMM.  Tn = dPQ_1^T Xp
@@ -1211,9 +1237,11 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // ---- 6. node encoder.  G^0 = G^1 + dPQ_1 Wcat_1 is never formed (it is only needed for the encoder's own
     // gradients): dWe = G^0^T X = G^1^T X + Wcat_1^T (dPQ_1^T X),  dbe = colsum(G^1) + Wcat_1^T colsum(dPQ_1).
     // G holds G^1 here.  Xp's column 31 is all ones, so column 31 of G^1^T Xp is colsum(G^1): straight into dbe
-    CK(node_tn_red(G, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), [&](int Sn) {
-        return red1.add(W(S_SLAB_XP2), Sn, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b));
-    }));
+    // (forked step: launched on the side stream inside the layer loop, as soon as G^1 existed)
+    if (!g1_done)
+        CK(node_tn_red(G, D, W(S_XP), 32, mb.M, W(S_SLAB_XP2), [&](int Sn) {
+            return red1.add(W(S_SLAB_XP2), Sn, (int64_t)D * 32, D, 32, 0, x.F, GR(P.node_w), x.F, GR(P.node_b));
+        }));
     // ---- 7. (not forked: the grouped launch here) then its slab reductions, and the deferred node-level ones
     if (forked) {
         CK(join_side(sc, st));
