@@ -892,6 +892,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         return red_add(Sn);
     };
     red1.st = st; red2.st = st;
+    // forked step: the big slab sets (the GCN layers' weight gradients, the land-use head's) are reduced on the side stream as
+    // soon as their producer has run, underneath the following GEMM / message-passing launches, instead of in the final flush
+    Reducer redS;
 
     if (x.mlp) {
         // ===== rl-mlp encoder: value head / numerical encoder -> pooled means + pointer heads -> node encoder
@@ -1058,7 +1061,13 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         if (fe_half) {
             int Sn = 1;
             CK(launch_head_wgrad(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_SLAB_FE), &Sn, hs));
-            CK(red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+            if (heads_side) {
+                redS.st = hs;
+                CK(redS.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+                CK(redS.flush());
+            } else {
+                CK(red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+            }
         } else {
             CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
                 return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
@@ -1157,6 +1166,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
     bool g1_done = false;
+    hipEvent_t tn_done = nullptr;
     const bool wgrad_side = forked && side_wgrad_on(mb.M) && !defer && x.K == 1 && pl.off[S_DPQ2] >= 0;
     hipEvent_t wgrad_done[MAXL + 2] = {};
     for (int l = x.L; l >= 1; --l) {
@@ -1203,7 +1213,16 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                 CK(stream_after(sc->side, st, next_event(sc)));      // dP|dQ of this layer is complete (2: and its dgrad has run)
                 tn_stream = sc->side;
             }
+            const bool red_side = forked && g_side_heads && !defer && tn_shape_mfma_ok(2 * D, D);
+            if (red_side && !wgrad_side) tn_done = next_event(sc);
             CK(node_tn_red(dPQ, 2 * D, W(S_H + l - 1), D, mb.M, W(S_SLAB_W + l), [&, l](int Sn) {
+                if (red_side) {
+                    // (the slabs are complete once the product has run: reduce them on the side stream right behind it)
+                    if (!wgrad_side) CK(stream_after(sc->side, st, tn_done));
+                    redS.st = sc->side;
+                    CK(redS.add(W(S_SLAB_W + l), Sn, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D));
+                    return redS.flush();
+                }
                 return red1.add(W(S_SLAB_W + l), Sn, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D);
             }));
             if (wgrad_side) {
