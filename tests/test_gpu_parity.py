@@ -68,7 +68,7 @@ def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
 def tune():
     """set native tune knobs for one test; every knob is put back to its default afterwards"""
     from drl_urban_planning_amd import native
-    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1, 'pq_exp': 1, 'nt_min_wgs': 128, 'bwd_nb_global': 1, 'side_heads': 1}
+    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1, 'pq_exp': 1, 'nt_min_wgs': 128, 'bwd_nb_global': 1, 'side_heads': 1, 'side_wgrad': 1}
     touched = []
 
     def _set(name, value):
@@ -347,8 +347,9 @@ def test_wide_model_matches_oracle(D, L, heads, n_range, T):
     _check_against_oracle(cfg, sd, replay, heads, T)
 
 
-@pytest.mark.parametrize('D,L,heads,n_range,T', [(256, 3, 1, (200, 345), 24), (64, 2, 2, (30, 60), 16)])
-def test_forked_step_is_bit_identical_to_the_single_stream_step(D, L, heads, n_range, T, tune):
+@pytest.mark.parametrize('D,L,heads,n_range,T,wgrad', [(256, 3, 1, (200, 345), 24, 1), (64, 2, 2, (30, 60), 16, 1),
+                                                          (256, 3, 1, (200, 345), 24, 3), (128, 3, 4, (40, 90), 12, 2)])
+def test_forked_step_is_bit_identical_to_the_single_stream_step(D, L, heads, n_range, T, wgrad, tune):
     """The per-sample chains and the grouped weight-gradient launch run on the engine's side stream underneath the GCN
     layers (tune knob side_stream, default on).  Same kernels, same reduction orders: values and every gradient must equal
     the single-stream step BIT FOR BIT, on every repetition (a missing fork / join dependency would show up as a mismatch)."""
@@ -364,6 +365,9 @@ def test_forked_step_is_bit_identical_to_the_single_stream_step(D, L, heads, n_r
         eng.backward(pk, mb, flat, seeds[0], seeds[1], seeds[2], grads)
         torch.cuda.synchronize()
         return [value.clone(), logp.clone(), ent.clone(), grads]
+    # side_wgrad: 1 = the default (weight-gradient GEMMs on the side stream for minibatches of <= 98 k nodes: all of these),
+    # 3 = always next to the dgrad, 2 = behind it; side_heads (default on) puts the pointer-head chain there as well
+    tune('side_wgrad', wgrad)
     tune('side_stream', 0)
     ref = run()
     tune('side_stream', 1)

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r03l
+O=gpurun_out/r03m
 mkdir -p $O
 (timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_mlp.py tests/test_gpu_deep_edge.py -m gpu -x -q 2>&1 | tail -6) > $O/tests.log 2>&1
 tail -4 $O/tests.log
