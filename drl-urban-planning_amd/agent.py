@@ -270,9 +270,13 @@ class PPOUpdater:
         count = lambda rows: [len(rows), int((it.exps_np[rows] != 0).sum()), int((stage_np[rows] == 0).sum()),
                               int((stage_np[rows] == 1).sum())]
         if self._mode == 'global':
-            if not d.same_everywhere([order_fingerprint(it.order)], dev):
-                raise RuntimeError("dp_mode='global': the ranks drew different permutations -- seed numpy's global RNG "
-                                   'identically on every rank (np.random.seed) before update_params')
+            # checked on the first epoch of an iteration only (it synchronises host and device): ranks that agree there hold the
+            # same numpy RNG state and keep agreeing
+            if not getattr(it, 'order_checked', False):
+                if not d.same_everywhere([order_fingerprint(it.order)], dev):
+                    raise RuntimeError("dp_mode='global': the ranks drew different permutations -- seed numpy's global RNG "
+                                       'identically on every rank (np.random.seed) before update_params')
+                it.order_checked = True
             B = self.mini_batch_size
             nb = int(math.floor(T / B))
             glob = [it.order[i * B:(i + 1) * B] for i in range(nb)]
@@ -294,8 +298,11 @@ class PPOUpdater:
         else:
             sched = packer.Schedule(it.packed, row_lists, dev) if nb else None
         flat_rows = (np.concatenate(row_lists) if nb else np.zeros(0)).astype(np.int64)
-        order_dev = torch.from_numpy(np.ascontiguousarray(flat_rows)).to(dev)
-        return Epoch(sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob)
+        host_rows = torch.from_numpy(np.ascontiguousarray(flat_rows)).pin_memory()
+        order_dev = host_rows.to(dev, non_blocking=True)
+        ep = Epoch(sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob)
+        ep._host_rows = host_rows            # (kept until the asynchronous upload has certainly run)
+        return ep
 
     # ------------------------------------------------------------------ one optimizer step
     def step(self, it, ep, k, loss_out=None):

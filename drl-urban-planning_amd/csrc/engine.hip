@@ -282,10 +282,21 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
 // per-sample weight gradients only by the final reduction.  They run on an engine-owned side stream, forked from / joined to the
 // caller's stream with events, underneath the GCN layers' GEMM / message-passing launches (tune knob "side_stream", default on).
 static int g_side_stream = 1;
+static int g_side_priority = 1;
 static int side_ready(upamd_engine *eng, hipStream_t st, SideCtx **out) {
     SideCtx &c = eng->sides[st];
     if (!c.side) {
-        UPAMD_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        // The runtime multiplexes the streams of one priority level onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in
+        // creation order: with RCCL initialised (its own streams come first) the side stream landed on the SAME hardware queue as
+        // the caller's stream and the forked step ran serialised (measured: no overlap, -3 %).  A stream of another priority
+        // level lives in that level's own queues; high priority also suits what runs here -- short kernels that gate the caller's
+        // stream (tune knob "side_priority": 1 = high (default), 0 = normal, 2 = low).
+        int least = 0, greatest = 0;
+        UPAMD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (g_side_priority == 0 || least == greatest)
+            UPAMD_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        else
+            UPAMD_HIP(hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, g_side_priority == 1 ? greatest : least));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_a, hipEventDisableTiming));
@@ -480,6 +491,7 @@ int slot_of_name(const upamd_model_desc &d, const Dims &x, const upamd_minibatch
 void upamd::set_fold_layer1(int on) { g_fold_layer1 = on == 2 ? 2 : (on ? 1 : 0); }
 void upamd::set_pq_exp(int on) { g_pq_exp = on ? 1 : 0; }
 void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
+void upamd::set_side_priority(int v) { g_side_priority = (v >= 0 && v <= 2) ? v : 1; }
 void upamd::set_side_heads(int on) { g_side_heads = on ? 1 : 0; }
 void upamd::set_side_wgrad(int on) { g_side_wgrad = (on >= 0 && on <= 3) ? on : 1; }
 

@@ -145,6 +145,7 @@ bool edge_fold_ok(const MbView &mb);        // every graph of the minibatch fits
 bool edge_fold_pays(const MbView &mb);      // ... and fits half the LDS (two workgroups per CU), where the fold beats the K = 32 GEMMs
 void set_fwd_h_hbm(int on);                // tune knob: large-graph size class of the forward with H left in HBM (default on)
 void set_side_wgrad(int on);               // tune knob "side_wgrad" (default off): GCN weight-gradient GEMMs on the side stream
+void set_side_priority(int v);             // tune knob "side_priority": priority level of the side streams created from now on (1 high, 0 normal, 2 low)
 void set_side_heads(int on);               // tune knob "side_heads" (default on): the land-use pointer-head chain on the side stream
 void set_side_stream(int on);              // tune knob "side_stream" (default on): per-sample chains + grouped weight gradients on an engine-owned side stream
 void set_pq_exp(int on);                   // tune knob "pq_exp" (default on): exp-form P/Q from the GEMM epilogue + LDS-DMA stage-in

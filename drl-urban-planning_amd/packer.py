@@ -343,7 +343,12 @@ class Schedule:
                                    n_road=int((meta[rows, M_STAGE] == 1).sum())))
             cursor += arr.size + pad
         flat = np.concatenate(chunks)
-        self.dev = torch.from_numpy(flat).to(device, non_blocking=False)
+        # pinned + asynchronous: a pageable, blocking upload made the host wait for every kernel queued before it -- one
+        # pipeline drain per epoch (the staging tensor lives as long as the schedule, i.e. beyond the copy)
+        self._host = torch.from_numpy(flat)
+        if torch.device(device).type == 'cuda':
+            self._host = self._host.pin_memory()
+        self.dev = self._host.to(device, non_blocking=True)
 
     def minibatch(self, k):
         it = self.items[k]

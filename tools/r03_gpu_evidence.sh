@@ -2,7 +2,7 @@
 # multi-rank functional runs on the one GPU -> gpurun_out/r03z (copied to profiles/ afterwards)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r03z
+O=gpurun_out/r03y
 mkdir -p $O
 (timeout 2400 python -m pytest tests -m gpu -q --durations=12 2>&1 | tail -30) > $O/gpu_tests.log 2>&1
 python __graft_entry__.py smoke > $O/smoke.log 2>&1
