@@ -83,9 +83,10 @@ def test_gemm_tn_lds_dma_kernel(M, I, J):
     scratch = torch.empty(int(lib.upamd_gemm_tn_scratch_floats(I, J, M)), device=DEV)
     out = torch.empty(I, J, device=DEV)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    A_in, B_in = to_pm(A), to_pm(B)       # (named: a temporary would be freed -- and its block reused -- before the launch)
     native.check(lib.upamd_tune(b'gemm_tn_dma', 1))
     try:
-        native.check(lib.upamd_gemm_tn(P(to_pm(A)), I, I, P(to_pm(B)), J, J, M, 0, P(scratch), P(out), st))
+        native.check(lib.upamd_gemm_tn(P(A_in), I, I, P(B_in), J, J, M, 0, P(scratch), P(out), st))
         torch.cuda.synchronize()
     finally:
         native.check(lib.upamd_tune(b'gemm_tn_dma', 0))
