@@ -146,6 +146,7 @@ extern "C" int upamd_tune(const char *name, int32_t value) {
     if (!strcmp(name, "he_fused")) { set_he_feat_fused(value); return UPAMD_OK; }
     if (!strcmp(name, "side_wgrad")) { set_side_wgrad(value); return UPAMD_OK; }
     if (!strcmp(name, "side_priority")) { set_side_priority(value); return UPAMD_OK; }
+    if (!strcmp(name, "virtual_g")) { set_virtual_g(value); return UPAMD_OK; }
     if (!strcmp(name, "side_heads")) { set_side_heads(value); return UPAMD_OK; }
     if (!strcmp(name, "side_stream")) { set_side_stream(value); return UPAMD_OK; }
     if (!strcmp(name, "fwd_h_hbm")) { set_fwd_h_hbm(value); return UPAMD_OK; }

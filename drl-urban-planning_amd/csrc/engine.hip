@@ -56,7 +56,7 @@ enum Slot : int {
     // backward
     S_DSV, S_DATT, S_DO, S_DS, S_DR, S_DQ1, S_DQ0, S_DC, S_DC_HEAD, S_DCONST, S_DWKK, S_DWVV, S_DBVV, S_DW1F, S_DWBD, S_TN, S_DWC1,
     S_DZ_HE, S_DZ_RN, S_DPREL, S_DFE, S_DMHE, S_DPRER, S_DXR, S_G0, S_G1, S_DPQ, S_DPQ2, S_SLAB_SMALL, S_SLAB_XP1, S_SLAB_XP2, S_SLAB_FE,
-    S_SLAB_XR, S_CSP0, S_CSP1, S_CSP2, S_CSP3,
+    S_SLAB_XR, S_CSP0, S_CSP1, S_CSP2, S_CSP3, S_DSCORE,
     S_WCAT,                               // + l (0 .. L-1)
     S_WCATT = S_WCAT + MAXL,              // + l
     S_H = S_WCATT + MAXL,                 // + l (0 .. L)
@@ -191,6 +191,7 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     add(S_DZ_HE, NH); add(S_DZ_RN, NR); add(S_DPREL, NH * x.h0l); add(S_DFE, NH * 2 * D); add(S_DMHE, NH * D);
     add(S_DPRER, NR * x.h0r); add(S_DXR, NR * D);
     add(S_G0, M * D); add(S_G1, M * D); add(S_DPQ, M * 2 * D);
+    add(S_DSCORE, (int64_t)x.heads * M);
     if (side_wgrad_on(M)) add(S_DPQ2, M * 2 * D);      // second dP|dQ buffer: layer l's weight gradient may still read its own
     // small models (no MFMA-tiled weight-gradient shapes): the node-level dY^T X products join the step's one grouped
     // launch at the end, so every layer's dP | dQ has to survive until then
@@ -330,6 +331,10 @@ static int stream_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
 // the attention backward -- runs on the side stream.  All of these are HBM-bound kernels of 0.1-0.3 ms that used to queue one
 // behind the other; the two chains only meet at the last GCN layer's backward (dS from the attention side, dM from the head side).
 static int g_side_heads = 1;
+// tune knob "virtual_g" (default on; with side_heads, one attention head, LDS-DMA stage-in of the last layer): the attention backward
+// hands the last layer's message-passing backward two scalars per node instead of G^L; G^L itself (the residual of that layer's
+// dgrad GEMM) is materialised by a small kernel on the side stream, off the critical path
+static int g_virtual_g = 1;
 static hipEvent_t next_event(SideCtx *c) { return c->pool[c->pool_next++ & 7]; }
 
 // An error return between fork and join must not leave side-stream work running on a workspace the caller may free next:
@@ -493,6 +498,7 @@ void upamd::set_pq_exp(int on) { g_pq_exp = on ? 1 : 0; }
 void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
 void upamd::set_side_priority(int v) { g_side_priority = (v >= 0 && v <= 2) ? v : 1; }
 void upamd::set_side_heads(int on) { g_side_heads = on ? 1 : 0; }
+void upamd::set_virtual_g(int on) { g_virtual_g = on ? 1 : 0; }
 void upamd::set_side_wgrad(int on) { g_side_wgrad = (on >= 0 && on <= 3) ? on : 1; }
 
 extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
@@ -1053,7 +1059,14 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     const float *dhbarE = dSV + x.S_last + D;
     // ---- 2. attention core: writes G^L (mean + attention terms) and dr
     float *G = W(S_G0), *Gn = W(S_G1);
-    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W(S_R), W(S_ALPHA), W(S_S), W(S_DS), dhbarV, x.Wp, G, W(S_DR), st));
+    // "virtual G": only the per-node scalars now; G^L follows on the side stream (below), the last layer's backward does not need it
+    const bool vgmode = heads_side && g_virtual_g && x.heads == 1 && x.K == 1 && x.L >= 2 && !defer && attn_bwd_single_pass_ok(mb, D, x.heads) &&
+                        edge_bwd_all_staged(mb, true) &&
+                        pq_exp_layer(pq_gemm(W(S_H + x.L - 1), mb.M, D, W(S_WCAT + x.L - 1), W(S_PQ + x.L)), x.L, x.K);
+    const VirtualG vg{W(S_ALPHA), W(S_DSCORE), W(S_DS), W(S_R)};
+    hipEvent_t g_ready = nullptr;
+    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W(S_R), W(S_ALPHA), W(S_S), W(S_DS), dhbarV, x.Wp, vgmode ? nullptr : G, W(S_DR), st,
+                       vgmode ? W(S_DSCORE) : nullptr));
     if (heads_side) UPAMD_HIP(hipEventRecord(sc->ev_a, st));      // dr + everything chain_bwd_post wrote: the side chain waits for it below
     // ---- 3. pointer heads: softmax backward + second-Linear backward fused
     CK(launch_pointer_bwd2(pk, mb, W(S_Z_HE), W(S_Z_RN), W(S_P_HE), W(S_P_RN), W(S_ENTK), W(S_LSE), dlogp_dev, dent_dev, W(S_HIDL),
@@ -1174,6 +1187,11 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_chain_bwd_pre(a, forked ? sc->side : st));
     }
     if (forked) CK(grouped_launch(sc->side));
+    if (vgmode) {
+        CK(launch_attn_g(pk, mb, D, x.heads, W(S_ALPHA), W(S_DSCORE), W(S_DS), W(S_R), dhbarV, x.Wp, G, sc->side));
+        g_ready = next_event(sc);
+        UPAMD_HIP(hipEventRecord(g_ready, sc->side));
+    }
     // ---- 5. GCN layers, last to first
     const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
@@ -1210,7 +1228,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             const bool expf = l >= 2 && pq_exp_layer(pq_gemm(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), W(S_PQ + l)), l, x.K);
             CK(launch_edge_bwd(pk, mb, D, last, W(S_PQ + l), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp, (last && land) ? W(S_DMHE) : nullptr,
                                dPQ, W(S_DBIAS + l), st, prof, (l == 1 && fold) ? &fa : nullptr,
-                               expf ? reinterpret_cast<const uint8_t *>(W(S_PQF + l)) : nullptr));
+                               expf ? reinterpret_cast<const uint8_t *>(W(S_PQF + l)) : nullptr, (last && vgmode) ? &vg : nullptr));
+
         }
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
         CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
@@ -1218,6 +1237,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             // side_wgrad = 1: the weight gradient starts next to this layer's dgrad; 2: behind it, i.e. next to the NEXT layer's
             // message-passing backward (the dgrad is launched first and the side stream waits for it)
             if (wgrad_side && g_side_wgrad == 2) {
+                // (virtual G: G^L, the residual of the last layer's dgrad, is materialised on the side stream)
+                if (last && vgmode) UPAMD_HIP(hipStreamWaitEvent(st, g_ready, 0));
                 CK(launch_gemm_nt(dPQ, mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
                 std::swap(G, Gn);
             }
@@ -1243,6 +1264,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                 UPAMD_HIP(hipEventRecord(wgrad_done[l], sc->side));
             }
             if (!(wgrad_side && g_side_wgrad == 2)) {
+                // (virtual G: G^L, the residual of the last layer's dgrad, is materialised on the side stream)
+                if (last && vgmode) UPAMD_HIP(hipStreamWaitEvent(st, g_ready, 0));
                 CK(launch_gemm_nt(dPQ, mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
                 std::swap(G, Gn);
             }

@@ -141,6 +141,13 @@ void set_bwd_nb_global(int on);            // tune knob "bwd_nb_global" (default
 struct FoldArgs {
     const float *Xp, *W1c, *b1c, *We, *be;
 };
+// "virtual G" of the last layer's backward (one attention head): G^L_j = live_j dhbarV / n + alpha_j ds + dscore_j r is rebuilt in
+// the kernel's stage-in from the attention backward's per-node scalars (alpha, dscore: [M]) and per-graph vectors (ds, r: [B][D];
+// dhbarV is read in front of dhbarE) instead of being written to and read from HBM (4 D bytes per node each way)
+struct VirtualG {
+    const float *alpha, *dscore, *ds, *r;
+};
+bool edge_bwd_all_staged(const MbView &mb, bool last);
 bool edge_fold_ok(const MbView &mb);        // every graph of the minibatch fits the staged (LDS-resident) size classes
 bool edge_fold_pays(const MbView &mb);      // ... and fits half the LDS (two workgroups per CU), where the fold beats the K = 32 GEMMs
 void set_fwd_h_hbm(int on);                // tune knob: large-graph size class of the forward with H left in HBM (default on)
@@ -155,12 +162,18 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
                     hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, int fe_full = 1, const uint8_t *pqflag = nullptr);
 int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
-                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, const uint8_t *pqflag = nullptr);
+                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, const uint8_t *pqflag = nullptr,
+                    const VirtualG *virt = nullptr);
 int launch_attn_fwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     float *alpha, float *s, hipStream_t st);
 int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     const float *alpha, const float *s, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL, float *dr,
-                    hipStream_t st);
+                    hipStream_t st, float *dscore_out = nullptr);
+// the single-pass attention backward covers this shape (then GL may be null and dscore_out given: "virtual G", see edge.hip)
+bool attn_bwd_single_pass_ok(const MbView &mb, int D, int heads);
+int launch_attn_g(const PackedView &pk, const MbView &mb, int D, int heads, const float *alpha, const float *dscore, const float *ds,
+                  const float *r, const float *dhbarV, int ld_dhbarV, float *GL, hipStream_t st);
+void set_virtual_g(int on);                // tune knob "virtual_g" (default on, needs side_heads): see VirtualG
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
                        const float *dFE, float *dMhe, float *dC_head, hipStream_t st, int keep_dead = 0);
 // the same with dFE = dpre W1f (h0 == 32) computed inside the kernel on the matrix cores: no dFE tensor in HBM
