@@ -18,7 +18,10 @@ using namespace upamd;
 // side stream of the forked step (see fork_side) + its fork / join events
 struct SideCtx {
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
+    // a second, NORMAL-priority stream for the weight-gradient GEMMs of small minibatches (side_wgrad): on the high-priority
+    // stream they ran ahead of the caller's dgrad GEMM, which is the one on the critical path (256 rows: 2.36 -> 2.47 ms)
+    hipStream_t side2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_join2 = nullptr;
     hipEvent_t pool[8] = {};             // round-robin events of the finer-grained hand-overs (stream_after / event_on)
     int pool_next = 0;
 };
@@ -298,6 +301,8 @@ static int side_ready(upamd_engine *eng, hipStream_t st, SideCtx **out) {
             UPAMD_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
         else
             UPAMD_HIP(hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, g_side_priority == 1 ? greatest : least));
+        UPAMD_HIP(hipStreamCreateWithFlags(&c.side2, hipStreamNonBlocking));
+        UPAMD_HIP(hipEventCreateWithFlags(&c.ev_join2, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_a, hipEventDisableTiming));
@@ -331,10 +336,12 @@ static int stream_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
 // the attention backward -- runs on the side stream.  All of these are HBM-bound kernels of 0.1-0.3 ms that used to queue one
 // behind the other; the two chains only meet at the last GCN layer's backward (dS from the attention side, dM from the head side).
 static int g_side_heads = 1;
-// tune knob "virtual_g" (default on; with side_heads, one attention head, LDS-DMA stage-in of the last layer): the attention backward
+// tune knob "virtual_g" (default OFF; with side_heads, one attention head, LDS-DMA stage-in of the last layer): the attention backward
 // hands the last layer's message-passing backward two scalars per node instead of G^L; G^L itself (the residual of that layer's
-// dgrad GEMM) is materialised by a small kernel on the side stream, off the critical path
-static int g_virtual_g = 1;
+// dgrad GEMM) is materialised by a small kernel on the side stream, off the critical path.  Measured -1.5 % at 2048 rows (the
+// valley in front of the last layer's backward shrinks, but its stage-in now chases two scalars per node and the materialising
+// kernel competes with it: edge_bwd 3.41 -> 3.76 ms), profiles/r03_lab_virtual_g.log
+static int g_virtual_g = 0;
 static hipEvent_t next_event(SideCtx *c) { return c->pool[c->pool_next++ & 7]; }
 
 // An error return between fork and join must not leave side-stream work running on a workspace the caller may free next:
@@ -344,6 +351,7 @@ struct SideGuard {
     bool armed = false;
     ~SideGuard() {
         if (armed && c && c->side) (void)hipStreamSynchronize(c->side);
+        if (armed && c && c->side2) (void)hipStreamSynchronize(c->side2);
     }
 };
 
@@ -531,6 +539,11 @@ extern "C" void upamd_engine_destroy(upamd_engine *eng) {
         SideCtx &c = kv.second;
         if (!c.side) continue;
         (void)hipStreamSynchronize(c.side);
+        if (c.side2) {
+            (void)hipStreamSynchronize(c.side2);
+            (void)hipStreamDestroy(c.side2);
+            (void)hipEventDestroy(c.ev_join2);
+        }
         (void)hipEventDestroy(c.ev_fork);
         (void)hipEventDestroy(c.ev_join);
         (void)hipEventDestroy(c.ev_a);
@@ -1195,7 +1208,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // ---- 5. GCN layers, last to first
     const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
-    bool g1_done = false;
+    bool g1_done = false, used_side2 = false;
     hipEvent_t tn_done = nullptr;
     const bool wgrad_side = forked && side_wgrad_on(mb.M) && !defer && x.K == 1 && pl.off[S_DPQ2] >= 0;
     hipEvent_t wgrad_done[MAXL + 2] = {};
@@ -1243,8 +1256,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                 std::swap(G, Gn);
             }
             if (wgrad_side) {
-                CK(stream_after(sc->side, st, next_event(sc)));      // dP|dQ of this layer is complete (2: and its dgrad has run)
-                tn_stream = sc->side;
+                CK(stream_after(sc->side2, st, next_event(sc)));     // dP|dQ of this layer is complete (2: and its dgrad has run)
+                tn_stream = sc->side2;
+                used_side2 = true;
             }
             const bool red_side = forked && g_side_heads && !defer && tn_shape_mfma_ok(2 * D, D);
             if (red_side && !wgrad_side) tn_done = next_event(sc);
@@ -1252,7 +1266,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                 if (red_side) {
                     // (the slabs are complete once the product has run: reduce them on the side stream right behind it)
                     if (!wgrad_side) CK(stream_after(sc->side, st, tn_done));
-                    redS.st = sc->side;
+                    redS.st = wgrad_side ? sc->side2 : sc->side;
                     CK(redS.add(W(S_SLAB_W + l), Sn, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D));
                     return redS.flush();
                 }
@@ -1261,7 +1275,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             if (wgrad_side) {
                 tn_stream = st;
                 wgrad_done[l] = next_event(sc);
-                UPAMD_HIP(hipEventRecord(wgrad_done[l], sc->side));
+                UPAMD_HIP(hipEventRecord(wgrad_done[l], sc->side2));
             }
             if (!(wgrad_side && g_side_wgrad == 2)) {
                 // (virtual G: G^L, the residual of the last layer's dgrad, is materialised on the side stream)
@@ -1299,6 +1313,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // ---- 7. (not forked: the grouped launch here) then its slab reductions, and the deferred node-level ones
     if (forked) {
         CK(join_side(sc, st));
+        if (used_side2) CK(stream_after(st, sc->side2, sc->ev_join2));
         side_guard.armed = false;
     } else {
         CK(grouped_launch(st));

@@ -173,7 +173,7 @@ int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, co
 bool attn_bwd_single_pass_ok(const MbView &mb, int D, int heads);
 int launch_attn_g(const PackedView &pk, const MbView &mb, int D, int heads, const float *alpha, const float *dscore, const float *ds,
                   const float *r, const float *dhbarV, int ld_dhbarV, float *GL, hipStream_t st);
-void set_virtual_g(int on);                // tune knob "virtual_g" (default on, needs side_heads): see VirtualG
+void set_virtual_g(int on);                // tune knob "virtual_g" (default off, needs side_heads): see VirtualG
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
                        const float *dFE, float *dMhe, float *dC_head, hipStream_t st, int keep_dead = 0);
 // the same with dFE = dpre W1f (h0 == 32) computed inside the kernel on the matrix cores: no dFE tensor in HBM
