@@ -18,8 +18,11 @@ using namespace upamd;
 // side stream of the forked step (see fork_side) + its fork / join events
 struct SideCtx {
     hipStream_t side = nullptr;
-    // a second, NORMAL-priority stream for the weight-gradient GEMMs of small minibatches (side_wgrad): on the high-priority
-    // stream they ran ahead of the caller's dgrad GEMM, which is the one on the critical path (256 rows: 2.36 -> 2.47 ms)
+    // a second stream of the same (high) priority for the weight-gradient GEMMs of small minibatches (side_wgrad).  Measured at 256
+    // rows (profiles/r03_lab_virtual_g.log): at NORMAL priority it is the fastest form without a process group (2.39 ms; at high
+    // priority the weight gradient runs ahead of the caller's dgrad GEMM, the one on the critical path: 2.47 ms) -- but with RCCL
+    // initialised a normal-priority stream shares the caller's hardware queue and the cross-stream events then stall it (3.08 ms
+    // against 2.55 ms without side_wgrad).  High priority is the setting that holds in both worlds (2.46-2.47 ms).
     hipStream_t side2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_join2 = nullptr;
     hipEvent_t pool[8] = {};             // round-robin events of the finer-grained hand-overs (stream_after / event_on)
@@ -301,7 +304,10 @@ static int side_ready(upamd_engine *eng, hipStream_t st, SideCtx **out) {
             UPAMD_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
         else
             UPAMD_HIP(hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, g_side_priority == 1 ? greatest : least));
-        UPAMD_HIP(hipStreamCreateWithFlags(&c.side2, hipStreamNonBlocking));
+        if (g_side_priority == 0 || least == greatest)
+            UPAMD_HIP(hipStreamCreateWithFlags(&c.side2, hipStreamNonBlocking));
+        else
+            UPAMD_HIP(hipStreamCreateWithPriority(&c.side2, hipStreamNonBlocking, g_side_priority == 1 ? greatest : least));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_join2, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
