@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r03r
+O=gpurun_out/r03s
 mkdir -p $O
 (timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "forked or virtual or update_params or loss_and_gradients or wide_model_matches" 2>&1 | tail -4) > $O/tests.log 2>&1
 tail -3 $O/tests.log
