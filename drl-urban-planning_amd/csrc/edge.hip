@@ -410,7 +410,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                                                                 int aux_cap, int fit, FoldArgs fa, int fe_full,
                                                                 const uint8_t *__restrict__ pqflag, int nfb) {
     static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
-    static_assert(HLDS || (STAGE && !FOLD), "H stays in HBM only next to a staged (not folded) P/Q slice");
+    static_assert(HLDS || STAGE, "H stays in HBM only next to a staged or folded P/Q slice");
     static_assert(!DMA || (STAGE && !FOLD), "the LDS-DMA stage-in belongs to the staged, not folded kernels");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
@@ -466,7 +466,11 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                 L.nm[i] = nmg[i];
             }
         }
-        const float mx = fold_end<true>(fa, M, o, n, p, role, ops, L.PQ, L.X, true);
+        // HLDS = false (large size class, round 3): the H_0 tiles go straight to the layer's OUTPUT slice in HBM and a node's row is
+        // updated in place at the end of its walk -- 128 instead of 192 bytes of LDS per node, two workgroups per CU for DHM-sized
+        // graphs.  (Rows written here are read by other waves of this workgroup only behind the barrier below: workgroup-scope
+        // release / acquire, one CU, one L1.)
+        const float mx = fold_end<true>(fa, M, o, n, p, role, ops, L.PQ, HLDS ? L.X : Ho, true);
         ok = mx <= EF_LIMIT_FWD && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
     } else if (DMA) {
         // LDS-DMA stage-in: the slices as raw 16-byte chunks, the lists through registers, one round trip for everything
@@ -555,6 +559,9 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         __syncthreads();
     }
 
+    // where a node's H row is read when it is not staged: the layer input -- or, for the folded layer, the output slice that
+    // already holds H_0
+    const float *Hsrc = (FOLD && !HLDS) ? Ho : Hg;
     // (P_ca, P_ca+1, Q_ca, Q_ca+1) of node u: exp form or scaled linear form
     auto pq4 = [&](int u) -> float4 {
         if (STAGE) return *reinterpret_cast<const float4 *>(L.PQ + u * 16 + ca);
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             const float degf = (float)(k1 - k);
             // H in HBM: the node's two columns are requested now and consumed after the incidence loop
             float2 hpre = make_float2(0.f, 0.f);
-            if (STAGE && !HLDS) hpre = *reinterpret_cast<const float2 *>(Hg + v * 16 + ca);
+            if (STAGE && !HLDS) hpre = *reinterpret_cast<const float2 *>(Hsrc + v * 16 + ca);
             float acc0 = 0.f, acc1 = 0.f;          // sums over incidences of r1 + r2, per column
             for (; k < k1; ++k) {
                 const float4 nb = pq4(L.nb[k]);
@@ -684,9 +691,10 @@ void set_bwd_nb_global(int on) { g_bwd_nb_global = on ? 1 : 0; }
 static int g_fwd_h_hbm = 1;      // tune knob "fwd_h_hbm": the large size class of the forward keeps H in HBM (two workgroups per CU)
 void set_fwd_h_hbm(int on) { g_fwd_h_hbm = on ? 1 : 0; }
 
-// the folded kernels have no H-in-HBM / list-in-global forms: a minibatch whose largest graph does not fit HALF the LDS would
-// run their large size class at one workgroup per CU (DHM: 2 x 1.38 ms + 2 x 1.51 ms per step against 1.68 + 2.36 ms for the
-// plain kernels, profiles/r03_kernel_trace_dhm_d256.txt) -- such minibatches take the two K = 32 GEMMs instead
+// tune knob fold_layer1 = 2 (lab rule, not the default): fold only when the minibatch's largest graph fits HALF the LDS.  It
+// dates from when the folded kernels had no H-in-HBM / list-in-global forms and ran their large size class at one workgroup
+// per CU; they have both now (edge_fwd_kernel<.., FOLD, HLDS = false>, edge_bwd_kernel<.., FOLD, .., NBG>): DHM 115.5k ->
+// 119.0k samples/s, profiles/r03_lab_fold_two_per_cu.log
 bool edge_fold_pays(const MbView &mb) {
     return edge_lds_bytes(mb.max_n, mb.max_inc, false, false, true, true) <= LDS_HALF &&
            edge_lds_bytes(mb.max_n, mb.max_inc, true, false, true, true) <= LDS_HALF;
@@ -721,7 +729,8 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
                            Hout, hbarV, hbarE, Ccur, FE, aux_cap, fit, fa, fe_full, pqflag, nfb);                     \
     } while (0)
         const bool dma = pqflag != nullptr;
-        if (fold) UPAMD_EF(false, true, true, true, false);
+        if (fold && !hlds) UPAMD_EF(false, true, true, false, false);
+        else if (fold) UPAMD_EF(false, true, true, true, false);
         else if (last && stage && !hlds) { if (dma) UPAMD_EF(true, true, false, false, true); else UPAMD_EF(true, true, false, false, false); }
         else if (last && stage) { if (dma) UPAMD_EF(true, true, false, true, true); else UPAMD_EF(true, true, false, true, false); }
         else if (last) UPAMD_EF(true, false, false, true, false);
@@ -747,7 +756,7 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
         rc = go(true, LDS_HALF, (int)LDS_HALF, (int)LDS_HALF);
         if (rc == 0) {
             const int64_t lds_noh = edge_lds_bytes(mb.max_n, mb.max_inc, false, last, true, false);
-            if (!fold && g_fwd_h_hbm && lds_noh <= LDS_HALF) {
+            if (g_fwd_h_hbm && lds_noh <= LDS_HALF) {      // (the folded layer too: its H_0 tiles then go straight to the output slice)
                 rc = go(true, LDS_HALF, (int)LDS_HALF, -(int)LDS_HALF, false);
             } else if (lds_max <= LDS_LIMIT) {
                 rc = go(true, lds_max, (int)lds_max, -(int)LDS_HALF);
@@ -804,7 +813,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     const uint16_t *og = pk.order + m[9];
     const float2 bc = make_float2(C2 * bias[p * 16 + ca], C2 * bias[p * 16 + ca + 1]);
     static_assert(!DMA || (STAGE && !FOLD), "the LDS-DMA stage-in belongs to the staged, not folded kernels");
-    static_assert(!NBG || DMA, "the list-in-global walk is built on the LDS-DMA stage-in");
+    static_assert(!NBG || DMA || FOLD, "the list-in-global walk belongs to the LDS-DMA and the folded kernels");
     constexpr bool dma = DMA;                                  // LDS-DMA stage-in (see dma_pq_slice)
     const bool batched = STAGE && !dma && fits_batched(n, e);
     bool ok = false;
@@ -881,7 +890,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         }
         const int d00 = rpg[c0 >> 2], d01 = rpg[(c0 >> 2) + 1];     // row pointers of the G rows (their degrees)
         const int d10 = rpg[c1 >> 2], d11 = rpg[(c1 >> 2) + 1];
-        const uint32_t nb0 = nbg[i0 < e ? i0 : 0], nb1 = nbg[i1 < e ? i1 : 0];
+        const uint32_t nb0 = nbg[(!NBG && i0 < e) ? i0 : 0], nb1 = nbg[(!NBG && i1 < e) ? i1 : 0];
         const int rRp = rpg[tid <= n ? tid : 0];
         const uint32_t rOrd = og[tid < n ? tid : 0];
         float4 ex4 = z4;                                      // the thread's four columns are the same on both trips
@@ -903,14 +912,14 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             reinterpret_cast<float4 *>(L.X)[i1] = make_float4(fmaf(g1.x, inv, ex4.x), fmaf(g1.y, inv, ex4.y),
                                                               fmaf(g1.z, inv, ex4.z), fmaf(g1.w, inv, ex4.w));
         }
-        if (i0 < e) reinterpret_cast<uint32_t *>(L.nb)[i0] = nb0;
-        if (i1 < e) reinterpret_cast<uint32_t *>(L.nb)[i1] = nb1;
+        if (!NBG && i0 < e) reinterpret_cast<uint32_t *>(L.nb)[i0] = nb0;
+        if (!NBG && i1 < e) reinterpret_cast<uint32_t *>(L.nb)[i1] = nb1;
         if (tid <= n) L.rp[tid] = rRp;
         if (tid < n) L.ord[tid] = (uint16_t)rOrd;
         ok = mx <= EF_LIMIT && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
     } else {
         for (int i = tid; i <= n; i += EDGE_THREADS) L.rp[i] = rpg[i];
-        for (int i = tid; i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
+        for (int i = tid; !NBG && i < e; i += EDGE_THREADS) reinterpret_cast<uint32_t *>(L.nb)[i] = nbg[i];
         for (int i = tid; i < n; i += EDGE_THREADS) L.ord[i] = og[i];
     }
     // last layer: the per-node candidate-incidence pointers (aux_cap >= 0) and, when they fit, the lists themselves
@@ -1117,7 +1126,8 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     } while (0)
         const bool dma = pqflag != nullptr;
         if (nbg) {
-            if (last) UPAMD_EB(true, true, false, true, true);
+            if (fold) UPAMD_EB(false, true, true, false, true);
+            else if (last) UPAMD_EB(true, true, false, true, true);
             else UPAMD_EB(false, true, false, true, true);
         } else
         if (fold) UPAMD_EB(false, true, true, false, false);
@@ -1139,7 +1149,7 @@ int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, co
         rc = go(true, LDS_HALF, (int)LDS_HALF, (int)LDS_HALF);
         if (rc == 0) {
             const int64_t lds_nonb = edge_lds_bytes(mb.max_n, mb.max_inc, true, last, true, true, false);
-            if (pqflag && g_bwd_nb_global && lds_nonb <= LDS_HALF_HARD) {
+            if ((pqflag || fold) && g_bwd_nb_global && lds_nonb <= LDS_HALF_HARD) {
                 rc = go(true, LDS_HALF_HARD, (int)LDS_HALF_HARD, -(int)LDS_HALF, true);      // neighbour ids from global memory: still two per CU
             } else if (lds_max <= LDS_LIMIT) {
                 rc = go(true, lds_max, (int)lds_max, -(int)LDS_HALF);

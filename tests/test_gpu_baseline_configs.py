@@ -120,6 +120,40 @@ def test_dhm_graphs_with_h_staged_in_lds_match_oracle():
         native.check(native.lib().upamd_tune(b'fwd_h_hbm', 1), 'upamd_tune')
 
 
+@pytest.mark.parametrize('family', ['dhm', 'mixed'])
+def test_two_per_cu_forms_of_the_large_size_class_are_bit_identical_to_the_one_per_cu_forms(family):
+    """The > 350-node graphs run the message-passing kernels with H left in HBM (forward; the folded first layer writes its
+    H_0 tiles straight to the output slice) and the neighbour ids walked from global memory (backward): the same arithmetic in
+    the same order as the one-workgroup-per-CU forms behind fwd_h_hbm = 0 / bwd_nb_global = 0 -- every output and every
+    parameter gradient must agree to the bit."""
+    from drl_urban_planning_amd import native, synth
+    cfg, sd = _model()
+    replay = synth.make_replay(24, family, max_nodes=1000, max_edges=3000, seed=37)
+    T = len(replay.states)
+    g = torch.Generator().manual_seed(9)
+    dv, dl, de = (torch.randn(T, generator=g).to(DEV) for _ in range(3))
+
+    def run(hbm, nbg):
+        native.check(native.lib().upamd_tune(b'fwd_h_hbm', hbm), 'upamd_tune')
+        native.check(native.lib().upamd_tune(b'bwd_nb_global', nbg), 'upamd_tune')
+        _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, replay.states, replay.actions)
+        assert pk.meta[:, 0].max() > 350
+        outs = [t.clone() for t in _forward(eng, pk, mb, flat)]
+        grads = torch.zeros(eng.n_floats, device=DEV)
+        eng.backward(pk, mb, flat, dv, dl, de, grads)
+        torch.cuda.synchronize()
+        return outs + [grads]
+
+    try:
+        new, old = run(1, 1), run(0, 0)
+    finally:
+        native.check(native.lib().upamd_tune(b'fwd_h_hbm', 1), 'upamd_tune')
+        native.check(native.lib().upamd_tune(b'bwd_nb_global', 1), 'upamd_tune')
+    for a, b in zip(new, old):
+        assert torch.equal(a, b)
+    assert float(new[-1].abs().max()) > 0
+
+
 def test_b2048_minibatch_rows_match_oracle_on_a_subsample():
     """BASELINE cfg-2 at full size (2048 HLG-shaped graphs, D = 256, L = 3): 64 of its rows are compared with the
     oracle evaluated on those rows alone -- forward rows directly; the backward through seeds that are zero outside the
