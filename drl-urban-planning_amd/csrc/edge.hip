@@ -258,6 +258,7 @@ __device__ __forceinline__ float rcp1p_mul(float a, float b) {      // 1 / (1 + 
 // (bit-identical to the forward's).  Everything stays within the 64 VGPRs of a two-workgroups-per-CU kernel.
 // ------------------------------------------------------------------------------------------
 typedef float f32x16e __attribute__((ext_vector_type(16)));
+typedef float f32x2e __attribute__((ext_vector_type(2)));
 
 // Operands of one 32-node tile, all loaded up front (ONE memory round trip per tile): the node features and the weight
 // rows of either the tile's 32 P/Q floats or its 16 H_0 columns.  The bias rides along as a 13th k step (bias x 1, the
@@ -601,8 +602,9 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             float2 hpre = make_float2(0.f, 0.f);
             if (STAGE && !HLDS) hpre = *reinterpret_cast<const float2 *>(Hsrc + v * 16 + ca);
             float acc0 = 0.f, acc1 = 0.f;          // sums over incidences of r1 + r2, per column
-            for (; k < k1; ++k) {
-                const float4 nb = pq4(L.nb[k]);
+            // (one induction variable: the list pointer is also the loop's counter)
+            for (const uint16_t *q = L.nb + k, *qe = L.nb + k1; q < qe; ++q) {
+                const float4 nb = pq4(*q);
                 acc0 += rsum(pv0, nb.z, qv0, nb.x);
                 acc1 += rsum(pv1, nb.w, qv1, nb.y);
             }
@@ -1027,25 +1029,48 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             const float2 sv = ds2(v);
             // sums of dm * (r - r^2) per column; 1 - tanh^2 = 4 (r - r^2)
             float aP0 = 0.f, aQ0 = 0.f, aP1 = 0.f, aQ1 = 0.f;
+            // Exp form: everything NEGATED -- nr = rcp(-(1 + E)) = -r from the negated own-side factors, nr^2 + nr = -(r - r^2) is then
+            // a plain FMA, the sums come out as -sum and the sign goes into the final scale.  Bit-identical to r - r^2 summed
+            // with the positive sign (negation is exact), and four v_xor_b32 per incidence less: the packed FMAs take no
+            // negation modifier, and the walk is bound by its VALU instruction count (profiles/r03_lab_shared_reciprocal.log)
+            // The own-side factors are kept as (column ca, column ca + 1) PAIRS: the neighbour's (Q, Q) and (P, P) are register
+            // pairs of its ds_read_b128, so t, nr^2 + nr and the sums are two-wide v_pk_fma_f32 each (16 VALU instructions per
+            // incidence instead of 22).
+            const f32x2e nP = {-pv0, -pv1}, nQ = {-qv0, -qv1}, m1 = {-1.0f, -1.0f};
+            f32x2e accP = {0.f, 0.f}, accQ = {0.f, 0.f};
             auto add = [&](const float4 &nb, float dm0, float dm1) {
-                const float r1 = r(pv0, nb.z), r2 = r(qv0, nb.x), r3 = r(pv1, nb.w), r4 = r(qv1, nb.y);
-                aP0 = fmaf(dm0, fmaf(-r1, r1, r1), aP0);
-                aQ0 = fmaf(dm0, fmaf(-r2, r2, r2), aQ0);
-                aP1 = fmaf(dm1, fmaf(-r3, r3, r3), aP1);
-                aQ1 = fmaf(dm1, fmaf(-r4, r4, r4), aQ1);
+                if (EF) {
+                    const f32x2e tP = __builtin_elementwise_fma(nP, (f32x2e){nb.z, nb.w}, m1);
+                    const f32x2e tQ = __builtin_elementwise_fma(nQ, (f32x2e){nb.x, nb.y}, m1);
+                    const f32x2e rP = {__builtin_amdgcn_rcpf(tP.x), __builtin_amdgcn_rcpf(tP.y)};
+                    const f32x2e rQ = {__builtin_amdgcn_rcpf(tQ.x), __builtin_amdgcn_rcpf(tQ.y)};
+                    const f32x2e dm = {dm0, dm1};
+                    accP = __builtin_elementwise_fma(dm, __builtin_elementwise_fma(rP, rP, rP), accP);
+                    accQ = __builtin_elementwise_fma(dm, __builtin_elementwise_fma(rQ, rQ, rQ), accQ);
+                } else {
+                    const float r1 = r(pv0, nb.z), r2 = r(qv0, nb.x), r3 = r(pv1, nb.w), r4 = r(qv1, nb.y);
+                    aP0 = fmaf(dm0, fmaf(-r1, r1, r1), aP0);
+                    aQ0 = fmaf(dm0, fmaf(-r2, r2, r2), aQ0);
+                    aP1 = fmaf(dm1, fmaf(-r3, r3, r3), aP1);
+                    aQ1 = fmaf(dm1, fmaf(-r4, r4, r4), aQ1);
+                }
             };
             const uint16_t *nb16 = reinterpret_cast<const uint16_t *>(nbg);
             int un = NBG ? nb16[k < k1 ? k : 0] : 0;           // (NBG: the next id is requested one trip ahead)
-            for (; k < k1; ++k) {
-                int u;
-                if (NBG) {
-                    u = un;
+            if (NBG) {
+                for (; k < k1; ++k) {
+                    const int u = un;
                     un = nb16[k + 1 < k1 ? k + 1 : k];
-                } else {
-                    u = L.nb[k];
+                    const float2 su = ds2(u);
+                    add(pq4(u), sv.x + su.x, sv.y + su.y);
                 }
-                const float2 su = ds2(u);
-                add(pq4(u), sv.x + su.x, sv.y + su.y);
+            } else {
+                // (one induction variable: the list pointer is also the loop's counter)
+                for (const uint16_t *q = L.nb + k, *qe = L.nb + k1; q < qe; ++q) {
+                    const int u = *q;
+                    const float2 su = ds2(u);
+                    add(pq4(u), sv.x + su.x, sv.y + su.y);
+                }
             }
             if (heads_on && valid) {
                 // candidate gradients live in global memory: fetch HB of them per trip so their latencies overlap;
@@ -1069,8 +1094,13 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                     for (int i = 0; i < HB; ++i) add(pq4(uu[i]), dmh[i].x, dmh[i].y);
                 }
             }
+            if (EF) {
+                aP0 = accP.x; aP1 = accP.y;
+                aQ0 = accQ.x; aQ1 = accQ.y;
+            }
             if (valid) {
-                const float2 dP = make_float2(2.f * aP0, 2.f * aP1), dQ = make_float2(2.f * aQ0, 2.f * aQ1);     // 1/2 * 4
+                constexpr float SC = EF ? -2.f : 2.f;                                     // 1/2 * 4 (exp form: of the negated sums)
+                const float2 dP = make_float2(SC * aP0, SC * aP1), dQ = make_float2(SC * aQ0, SC * aQ1);
                 // pair order: (dP_ca, dP_ca+1, dQ_ca, dQ_ca+1) is chunk (lane & 3) of the node's row in panel 2p + ((lane >> 2) & 1)
                 *reinterpret_cast<float4 *>(dPQ + ((int64_t)(2 * p + ((lane >> 2) & 1)) * M + o + v) * 16 + 4 * (lane & 3)) =
                     make_float4(dP.x, dP.y, dQ.x, dQ.y);
