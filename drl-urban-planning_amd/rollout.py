@@ -132,27 +132,36 @@ class ActionServer:
                 conn.close()
         if not reqs:
             return 0
+        # From here on every request has been taken off its pipe: whatever happens, its worker gets an answer
         t0 = time.perf_counter()
         states, owner = [], []
-        for i, conn, sizes, mean in reqs:
-            slot = self._slot(i)
-            cursor = _align(8 * ActionClient.MAX_ROWS)
-            for sz in sizes:
-                states.append(slot[cursor:cursor + sz])
-                owner.append(mean)
-                cursor = _align(cursor + sz)
         try:
+            for i, conn, sizes, mean in reqs:
+                slot = self._slot(i)
+                cursor = _align(8 * ActionClient.MAX_ROWS)
+                if len(sizes) > ActionClient.MAX_ROWS:
+                    raise ValueError('request of client %d: more than %d states' % (i, ActionClient.MAX_ROWS))
+                for sz in sizes:
+                    if sz <= 0 or cursor + sz > self.slot_bytes:
+                        raise ValueError('request of client %d does not fit its slot' % i)
+                    states.append(slot[cursor:cursor + sz])
+                    owner.append(mean)
+                    cursor = _align(cursor + sz)
             actions = self._actions(states, np.asarray(owner, dtype=bool))
             status = 'ok'
         except Exception as exc:                    # report to the workers instead of dying silently
             actions, status = None, '%s: %s' % (type(exc).__name__, exc)
+            self.last_error = status
         row = 0
         for i, conn, sizes, mean in reqs:
             if actions is not None:
                 out = actions[row:row + len(sizes)]
                 self._slot(i)[:8 * len(sizes)] = np.ascontiguousarray(out, dtype=np.float32).view(np.uint8).reshape(-1)
             row += len(sizes)
-            conn.send(status)
+            try:
+                conn.send(status)
+            except (BrokenPipeError, OSError):      # that worker is gone; the others still get their answers
+                conn.close()
         st = self.stats
         st['batches'] += 1
         st['requests'] += len(reqs)

@@ -127,6 +127,47 @@ def test_server_batches_concurrent_requests_and_reports_errors():
     server.close()
 
 
+def test_a_silent_server_times_the_client_out_and_a_dead_client_does_not_stall_the_others():
+    policy_net, _, _ = _policy(seed=6)
+    server = rollout.ActionServer(policy_net, 3, slot_bytes=1 << 18, linger_s=0.0)
+    rep = _states(3, 11)
+    import threading
+    import time
+    # nobody serves: the client gives up instead of blocking the sampling phase for ever
+    slow = server.client(0)
+    slow.timeout_s = 0.3
+    t0 = time.perf_counter()
+    with pytest.raises(TimeoutError):
+        slow.select_action([rep.states[0]], True)
+    assert time.perf_counter() - t0 < 5.0
+    assert server.serve_once(timeout=0.5) == 1          # the stale request is still answered (nobody reads it) ...
+    slow.conn.recv()                                     # ... drain it so the pipe is clean again
+    # client 1 dies after sending its request (its pipe end is closed); client 2 must still get its answer
+    dead = server.client(1)
+    rec = packer.compact_state(rep.states[1])
+    dead._slot()[rollout._align(8 * rollout.ActionClient.MAX_ROWS):][:rec.size] = rec
+    dead.conn.send(([int(rec.size)], True))
+    dead.conn.close()
+    out = []
+    t = threading.Thread(target=lambda: out.append(server.client(2).select_action([rep.states[2]], True)))
+    t.start()
+    time.sleep(0.2)
+    served = 0
+    for _ in range(20):
+        served += server.serve_once(timeout=0.5)
+        if out:
+            break
+    t.join(timeout=10)
+    want = policy_net.select_action([[torch.from_numpy(f) for f in rep.states[2]]], True)
+    assert out and torch.equal(out[0], want)
+    # a request whose sizes do not fit the slot is refused with an error string, not an exception in the serving thread
+    bad = server.client(0)
+    bad.conn.send(([1 << 30], True))
+    assert server.serve_once(timeout=0.5) == 1
+    assert 'does not fit' in bad.conn.recv() and 'does not fit' in server.last_error
+    server.close()
+
+
 def test_arena_overflow_is_loud():
     arena = rollout.SharedArena(2, 1 << 16)
     rep = _states(3, 9)
