@@ -1,3 +1,4 @@
+# (lab script of the shared-reciprocal experiment: needs profiles/r03_lab_shared_reciprocal.diff applied -- the edge_rcp4 knob does not exist at HEAD)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r03x
