@@ -158,3 +158,23 @@ def test_two_rank_agreements_and_batch_broadcast(tmp_path):
     port = _free_port()
     mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), 'ok.npy'))
+
+
+def test_auto_mode_fingerprint_tells_replays_with_equal_scalars_apart():
+    """dp_mode='auto' calls a replay 'the same on every rank' only if the per-row scalars AND what the packer extracted
+    from the states agree: two synthetic replays with the same actions / rewards / masks / exps but different graphs
+    (equal action seeds on rank-local shards) must not be mistaken for one shared batch; a replay of compact wire
+    records and the padded tuples it was made from are the same replay."""
+    from drl_urban_planning_amd import dist, packer, synth
+    a = synth.make_replay(12, 'hlg', max_nodes=64, max_edges=200, seed=3, road_fraction=0.4, n_range=(20, 55))
+    b = synth.make_replay(12, 'hlg', max_nodes=64, max_edges=200, seed=4, road_fraction=0.4, n_range=(20, 55))
+    b = synth.Replay(b.states, a.actions, a.masks, a.rewards, a.exps)          # other graphs, the same per-row scalars
+    assert dist.batch_fingerprint(a) == dist.batch_fingerprint(b)
+    nd, num = a.states[0][1].shape[1], a.states[0][0].shape[0]
+
+    def fp(states, actions):
+        return dist.states_fingerprint(packer.pack_replay(states, actions, nd, num))
+    assert fp(a.states, a.actions) != fp(b.states, b.actions)
+    assert fp(a.states, a.actions) == fp(a.states, a.actions)
+    records = [packer.compact_state(s) for s in a.states]
+    assert fp(records, a.actions) == fp(a.states, a.actions)
