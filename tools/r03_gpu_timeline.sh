@@ -1,4 +1,4 @@
-# kernel timelines of the 256-row and the 2048-row step (idle gaps, concurrency) -> gpurun_out/r03z/timeline_*.txt
+# kernel timelines of the 256-row and the 2048-row step (idle gaps, concurrency, per-stream kernel time) -> gpurun_out/r03z/timeline_*.txt
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r03z
@@ -8,5 +8,4 @@ rocprofv3 --kernel-trace -d /tmp/p_t1 -o tr -- python bench.py --minibatch 256 -
 python tools/timeline_rocpd.py $(find /tmp/p_t1 -name "*.db" | head -1) $O/timeline_hlg_d256_minibatch256.txt 12
 rocprofv3 --kernel-trace -d /tmp/p_t2 -o tr -- python bench.py --cpu-baseline off --steps 12 --warmup 3 --no-kernel-events > /dev/null 2>&1
 python tools/timeline_rocpd.py $(find /tmp/p_t2 -name "*.db" | head -1) $O/timeline_hlg_d256.txt 4
-head -40 $O/timeline_hlg_d256_minibatch256.txt
-head -12 $O/timeline_hlg_d256.txt
+head -50 $O/timeline_hlg_d256.txt

@@ -37,6 +37,7 @@ def main():
     gaps = []
     lanes = defaultdict(float)
     per_step = []
+    by_lane = defaultdict(lambda: [0.0, 0])
     for t0, t1 in steps:
         ks = [r for r in rows if r[1] >= t0 and r[2] <= t1]
         busy, cur_s, cur_e = 0, None, None
@@ -54,6 +55,8 @@ def main():
                 cur_e, last_end_name = r[2], r[0]
             if lane:
                 lanes[r[3]] += r[2] - r[1]
+                by_lane[(r[3], short(r[0]))][0] += r[2] - r[1]
+                by_lane[(r[3], short(r[0]))][1] += 1
         if cur_e is not None:
             busy += cur_e - cur_s
         summed = sum(r[2] - r[1] for r in ks)
@@ -70,6 +73,12 @@ def main():
     if lane:
         print('summed kernel time per %s (us/step): %s' % (lane, ', '.join('%s: %.0f' % (k, v / n / 1e3) for k, v in
                                                                              sorted(lanes.items(), key=lambda kv: -kv[1]))), file=out)
+    if lane:
+        for ln in sorted(lanes, key=lambda k: -lanes[k]):
+            print('%s %s, us/step (launches/step x average us):' % (lane, ln), file=out)
+            for (l2, k), (v, c) in sorted(by_lane.items(), key=lambda kv: -kv[1][0]):
+                if l2 == ln and v / n / 1e3 >= 5.0:
+                    print('  %8.1f  (%4.1f x %7.1f)  %s' % (v / n / 1e3, c / n, v / c / 1e3, k), file=out)
     agg = defaultdict(lambda: [0.0, 0])
     for g, a, b in gaps:
         agg[(a, b)][0] += g
