@@ -289,6 +289,36 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(PackedView pk, MbView m
     // consumer, rebuilds the slice it needs from them (edge.hip) and the 4 D bytes per node of G^L are neither written nor read
     if (!GL) return;
     const float inv_nm = 1.f / (float)m[6];
+    if constexpr (NP % 4 == 0) {
+        // 16-byte stores: lane (pg = c / 4, q = c % 4) of a node slot owns columns 4q .. 4q+3 of the panels pg, pg + 4, ... -- a
+        // quarter of the store instructions of the column-per-lane form below for the same bytes and the same per-element
+        // expression (element-wise: bit-identical)
+        const int pg = c >> 2, q4 = 4 * (c & 3);
+        float4 dhv4[NP >= 4 ? NP / 4 : 1];
+#pragma unroll
+        for (int i = 0; i < NP / 4; ++i) {
+            const float *x = dhbarV + (int64_t)b * ld_dhbarV + (pg + 4 * i) * 16 + q4;      // (a column slice: no alignment promise)
+            dhv4[i] = make_float4(x[0] * inv_nm, x[1] * inv_nm, x[2] * inv_nm, x[3] * inv_nm);
+        }
+        for (int j = slot; j < n; j += 16) {
+            const bool live = nmask[j] != 0;
+#pragma unroll
+            for (int i = 0; i < NP / 4; ++i) {
+                const int p = pg + 4 * i, d = p * 16 + q4;
+                float4 v = live ? dhv4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int h = 0; h < heads; ++h) {
+                    const float a = al[h * mb.max_n + j], dsc = dscl[h * mb.max_n + j];
+                    const float4 dv = *reinterpret_cast<const float4 *>(dsl + h * D + d), rv = *reinterpret_cast<const float4 *>(rl + h * D + d);
+                    v.x += a * dv.x + dsc * rv.x;
+                    v.y += a * dv.y + dsc * rv.y;
+                    v.z += a * dv.z + dsc * rv.z;
+                    v.w += a * dv.w + dsc * rv.w;
+                }
+                *reinterpret_cast<float4 *>(GL + ((int64_t)p * M + o + j) * 16 + q4) = v;
+            }
+        }
+        return;
+    }
     float dhv[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) dhv[p] = dhbarV[(int64_t)b * ld_dhbarV + p * 16 + c] * inv_nm;
