@@ -3,7 +3,8 @@
 
 Sub-modules are imported lazily: ``synth`` (synthetic replay), ``native`` (ctypes binding of
 the C-ABI library ``csrc/libupamd.so``), ``packer`` (ragged/CSR replay packer), ``models``
-(nn.Module surface), ``agent`` (PPO update surface), ``dist`` (data-parallel helpers).
+(nn.Module surface), ``agent`` (PPO update surface), ``dist`` (data-parallel helpers), ``binding`` (the reference-side
+binding: ``bind_reference_agent``), ``launch`` (``python -m drl_urban_planning_amd.launch -m urban_planning.train ...``).
 """
 __version__ = '0.1.0'
 
@@ -15,6 +16,8 @@ _LAZY = {
     'PPOUpdater': ('agent', 'PPOUpdater'),
     'HipUpdateMixin': ('agent', 'HipUpdateMixin'),
     'install': ('agent', 'install'),
+    'bind_reference_agent': ('binding', 'bind_reference_agent'),
+    'patch_reference_module': ('binding', 'patch_reference_module'),
     'DistContext': ('dist', 'DistContext'),
 }
 

@@ -40,7 +40,7 @@ import numpy as np
 import torch
 
 from . import packer
-from .dist import DistContext, batch_fingerprint, global_counts, order_fingerprint, split_minibatch, states_fingerprint
+from .dist import DistContext, batch_fingerprint, global_counts, split_minibatch, states_fingerprint
 from .models import backend_of
 
 
@@ -256,6 +256,11 @@ class PPOUpdater:
         T, dev, d = it.T, self.engine.device, self.dist
         perm = np.arange(T)
         np.random.shuffle(perm)
+        if self._mode == 'global':
+            # every rank draws (so identically seeded ranks stay aligned), rank 0's draw -- the reference's numpy stream
+            # (:306-312) -- is the one all of them use: no rank-local np.random use (env code, another thread) between two
+            # epochs can make the ranks slice different global minibatches
+            perm = d.broadcast_array(perm, dev)
         it.order = it.order[perm]
         meta = it.packed.meta
         stage_np = meta[:, packer.M_STAGE]
@@ -270,13 +275,6 @@ class PPOUpdater:
         count = lambda rows: [len(rows), int((it.exps_np[rows] != 0).sum()), int((stage_np[rows] == 0).sum()),
                               int((stage_np[rows] == 1).sum())]
         if self._mode == 'global':
-            # checked on the first epoch of an iteration only (it synchronises host and device): ranks that agree there hold the
-            # same numpy RNG state and keep agreeing
-            if not getattr(it, 'order_checked', False):
-                if not d.same_everywhere([order_fingerprint(it.order)], dev):
-                    raise RuntimeError("dp_mode='global': the ranks drew different permutations -- seed numpy's global RNG "
-                                       'identically on every rank (np.random.seed) before update_params')
-                it.order_checked = True
             B = self.mini_batch_size
             nb = int(math.floor(T / B))
             glob = [it.order[i * B:(i + 1) * B] for i in range(nb)]

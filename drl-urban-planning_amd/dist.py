@@ -42,7 +42,13 @@ class DistContext:
 
     @classmethod
     def from_env(cls, backend=None, device=None):
-        """Initialise from torchrun's environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+        """Initialise from torchrun's environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+
+        The rendezvous store is opened first (``torch.distributed.rendezvous('env://')``: the launcher's agent store
+        under ``torch.distributed.run``, a TCP store otherwise) and, for RCCL, used to prove that no two ranks of a
+        host resolved to the same physical GPU BEFORE any communicator exists -- the reference's entry point pins
+        every process to ``--gpu_index`` (urban_planning/train.py:50,54), so a plain ``torchrun -m urban_planning.train``
+        lands all ranks on one device; ``drl_urban_planning_amd.launch`` maps LOCAL_RANK to a device first."""
         world = int(os.environ.get('WORLD_SIZE', '1'))
         forced = world == 1 and os.environ.get('UPAMD_DIST_FORCE_INIT') == '1' and 'RANK' in os.environ
         if world == 1 and not forced:
@@ -52,10 +58,13 @@ class DistContext:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             if backend is None:
                 backend = os.environ.get('UPAMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            store, rank, world = next(iter(dist.rendezvous('env://', rank=rank, world_size=world)))
+            if backend == 'nccl':
+                assert_one_rank_per_device(exchange_idents(store, rank, world, device_ident(device)), rank)
             kwargs = {}
             if device is not None and backend == 'nccl':
                 kwargs['device_id'] = device
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+            dist.init_process_group(backend=backend, store=store, rank=rank, world_size=world, **kwargs)
         return cls(rank, world, active=True)
 
     @property
@@ -105,6 +114,32 @@ class DistContext:
                 dist.broadcast(tensor, src=src, group=self.group)
         return tensor
 
+    def broadcast_array(self, array, device='cpu', src=0):
+        """Rank ``src``'s integer numpy array on every rank (same shape everywhere), e.g. an epoch's permutation."""
+        if not self.active or self.world == 1:
+            return array
+        on = device if self.backend == 'nccl' else 'cpu'
+        t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.int64)).to(on)
+        dist.broadcast(t, src=src, group=self.group)
+        return t.cpu().numpy()
+
+    def broadcast_object(self, obj, device='cpu', src=0):
+        """Rank ``src``'s picklable object on every rank (rollout logs, numpy RNG state)."""
+        if not self.active or self.world == 1:
+            return obj
+        box = [obj if self.rank == src else None]
+        dist.broadcast_object_list(box, src=src, group=self.group,
+                                   device=torch.device(device) if self.backend == 'nccl' else None)
+        return box[0]
+
+    def gather_objects(self, obj):
+        """Every rank's picklable object, in rank order, on every rank."""
+        if not self.active or self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
     # ---- small host-side agreements (float64 on the host for gloo, on `device` for nccl)
     def _scalar_tensor(self, values, device):
         on = device if (self.active and self.backend == 'nccl') else 'cpu'
@@ -128,6 +163,45 @@ class DistContext:
         self.all_reduce_min(lo)
         self.all_reduce_max(hi)
         return bool(torch.equal(lo, hi))
+
+
+def device_ident(device):
+    """'<host>/<physical id>' of the GPU a rank computes on (uuid, else PCI address, of the torch device)."""
+    import socket
+    host = socket.gethostname()
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if device is None or torch.device(device).type != 'cuda':
+        return '%s/cpu' % host
+    props = torch.cuda.get_device_properties(device)
+    uuid = getattr(props, 'uuid', None)
+    if uuid is not None and str(uuid).strip('0-'):
+        return '%s/%s' % (host, uuid)
+    pci = [getattr(props, k, None) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')]
+    if any(x is not None for x in pci):
+        return '%s/pci-%s' % (host, ':'.join(str(x) for x in pci))
+    vis = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('CUDA_VISIBLE_DEVICES') or ''
+    return '%s/visible[%s]#%d' % (host, vis, torch.device(device).index or 0)
+
+
+def exchange_idents(store, rank, world, ident):
+    """Every rank's ``ident`` through the rendezvous store (no collective, no communicator needed)."""
+    store.set('upamd/device/%d' % rank, ident)
+    return [store.get('upamd/device/%d' % r).decode() for r in range(world)]
+
+
+def assert_one_rank_per_device(idents, rank=0):
+    """RCCL needs one GPU per rank: raise when two ranks resolved to the same physical device."""
+    seen = {}
+    for r, ident in enumerate(idents):
+        if ident in seen:
+            raise RuntimeError(
+                'ranks %d and %d both resolved to GPU %s: RCCL needs one device per rank.  The reference pins every '
+                'process to --gpu_index (urban_planning/train.py:50,54); launch through `python -m torch.distributed.run '
+                '... -m drl_urban_planning_amd.launch -m urban_planning.train ...`, which maps LOCAL_RANK to a device '
+                'before the reference picks one (or set UPAMD_DIST_BACKEND=gloo to let test ranks share a GPU)'
+                % (seen[ident], r, ident))
+        seen[ident] = r
 
 
 def shard_rows(rows, rank, world):
