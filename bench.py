@@ -167,7 +167,6 @@ def main():
                     help='global (default): every rank holds the replay, one global permutation, rank slices of each '
                          'global minibatch; local: per-rank shards shuffled locally')
     ap.add_argument('--no-kernel-events', action='store_true')
-    ap.add_argument('--sub-batches', type=int, default=1, help='2 = overlap the two halves of a minibatch on two streams')
     ap.add_argument('--minibatch', type=int, default=0, help='override the per-GPU PPO minibatch of the workload (exploration)')
     ap.add_argument('--inclusive-unique', action='store_true',
                     help='time the update_params_inclusive leg on T DISTINCT host states (default: the replay tiles a pool '
@@ -212,7 +211,7 @@ def main():
     B_step = w['B'] * ctx.world                                          # rows one optimizer step consumes over all ranks
     up = PPOUpdater(policy_net, value_net, lr=4e-4, eps=1e-5, weight_decay=0.0, gamma=1.0, tau=0.0, clip_epsilon=0.2,
                     value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4,
-                    mini_batch_size=B_step if glob else w['B'], dist_ctx=ctx, sub_batches=args.sub_batches,
+                    mini_batch_size=B_step if glob else w['B'], dist_ctx=ctx,
                     dp_mode=args.dp_mode)
     need = args.steps + args.warmup
     if glob:

@@ -77,7 +77,7 @@ class PPOUpdater:
     def __init__(self, policy_net, value_net, lr=4e-4, eps=1e-5, weight_decay=0.0, betas=(0.9, 0.999), gamma=1.0,
                  tau=0.0, clip_epsilon=0.2, value_pred_coef=0.5, entropy_coef=0.01, num_optim_epoch=4,
                  mini_batch_size=256, batch_stage=False, max_grad_norm=1.0, dist_ctx=None, pack_threads=0,
-                 sub_batches=1, dp_mode='auto', dp_balance='edges', legacy_zero_grad=None):
+                 dp_mode='auto', dp_balance='edges', legacy_zero_grad=None):
         self.policy_net, self.value_net = policy_net, value_net
         self.backend = backend_of(policy_net)
         self.lr, self.eps, self.weight_decay, self.betas = lr, eps, weight_decay, betas
@@ -95,12 +95,6 @@ class PPOUpdater:
         self.legacy_zero_grad = torch_zero_grad_zero_fills() if legacy_zero_grad is None else bool(legacy_zero_grad)
         self._group_seen = [False, False, False]
         self.pack_threads = pack_threads
-        # sub_batches = 2: the two halves of every minibatch run on two HIP streams so the MFMA-bound GEMMs of
-        # one half overlap the VALU-bound message passing of the other; their gradients are summed afterwards
-        # (same arithmetic as two data-parallel ranks on one GPU)
-        self.sub_batches = int(sub_batches)
-        if self.sub_batches not in (1, 2) or mini_batch_size % self.sub_batches != 0:
-            raise ValueError('sub_batches must be 1 or 2 and divide mini_batch_size')
         self.loss_iter = 0
         self.clip_pending = True              # the generator lists are live until the first call
         self.group_steps = [0, 0, 0]          # Adam step counts: encoder+value / land head / road head
@@ -131,9 +125,6 @@ class PPOUpdater:
         self.engine = engine
         self._named = self.backend.named_params()
         engine.flatten(self._named, out=self.flat)
-        if self.sub_batches > 1 and getattr(self, '_streams', None) is None:
-            self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.sub_batches)]
-            self._sub_grads = [torch.zeros_like(self.grads) for _ in range(self.sub_batches)]
         return engine
 
     def _ensure_rowbufs(self, rows):
@@ -219,8 +210,6 @@ class PPOUpdater:
         self._mode = self._resolve_mode(batch, packed)       # (the fingerprint reads the packed host buffer)
         packed.to(dev)
         R = self.local_rows()
-        if self.sub_batches > 1 and R % self.sub_batches:
-            raise ValueError('sub_batches must divide the %d rows a rank processes per step' % R)
         self._ensure_rowbufs(R)
         torch.cuda.current_stream(dev).synchronize()      # the pinned staging buffer may be refilled next iteration
         rewards = self._to_f32(batch.rewards, dev)
@@ -289,12 +278,7 @@ class PPOUpdater:
             local = [list(c) for c in zip(*[count(r) for r in row_lists])] if nb else [[], [], [], []]
             counts = global_counts(d, local, dev) if nb else local
         rows_glob, ind_glob, land_glob, road_glob = counts
-        S = self.sub_batches
-        if S > 1:      # schedule items S*k + j = the j-th part of this rank's rows of minibatch k
-            h = self.local_rows() // S
-            sched = packer.Schedule(it.packed, [r[j * h:(j + 1) * h] for r in row_lists for j in range(S)], dev)
-        else:
-            sched = packer.Schedule(it.packed, row_lists, dev) if nb else None
+        sched = packer.Schedule(it.packed, row_lists, dev) if nb else None
         flat_rows = (np.concatenate(row_lists) if nb else np.zeros(0)).astype(np.int64)
         host_rows = torch.from_numpy(np.ascontiguousarray(flat_rows)).pin_memory()
         order_dev = host_rows.to(dev, non_blocking=True)
@@ -312,37 +296,14 @@ class PPOUpdater:
         nflt = engine.n_floats
         inv_rows = 1.0 / ep.rows_glob[k]
         inv_ind = 1.0 / ep.ind_glob[k] if ep.ind_glob[k] > 0 else float('nan')
-        if self.sub_batches == 1:
-            mb, _ = ep.sched.minibatch(k)
-            idx = ep.order_dev[k * B:(k + 1) * B]
-            engine.forward(it.packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
-            # gathers of the minibatch rows, the loss and zero_grad in one launch
-            engine.ppo_loss_rows(B, value_b, logp_b, ent_b, idx, it.adv, it.ret, it.old_logp, it.exps,
-                                 self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
-                                 dvalue, dlogp, dent, self.grads[nflt:], zero=self.grads[:nflt])
-            engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
-        else:
-            S, h = self.sub_batches, B // self.sub_batches
-            main = torch.cuda.current_stream(dev)
-            ready = main.record_event()
-            for j in range(S):
-                st = self._streams[j]
-                st.wait_event(ready)
-                with torch.cuda.stream(st):
-                    mb, _ = ep.sched.minibatch(S * k + j)
-                    lo, hi = j * h, (j + 1) * h
-                    idx = ep.order_dev[k * B + lo:k * B + hi]
-                    g = self._sub_grads[j]
-                    engine.forward(it.packed, mb, self.flat, value_b[lo:hi], logp_b[lo:hi], ent_b[lo:hi], keep=True, slot=j)
-                    engine.ppo_loss(h, value_b[lo:hi], logp_b[lo:hi], ent_b[lo:hi], it.adv[idx], it.ret[idx],
-                                    it.old_logp[idx], it.exps[idx], self.clip_epsilon, self.value_pred_coef,
-                                    self.entropy_coef, inv_rows, inv_ind, dvalue[lo:hi], dlogp[lo:hi], dent[lo:hi],
-                                    g[nflt:])
-                    g[:nflt].zero_()
-                    engine.backward(it.packed, mb, self.flat, dvalue[lo:hi], dlogp[lo:hi], dent[lo:hi], g, slot=j)
-            for j in range(S):
-                main.wait_stream(self._streams[j])
-            torch.add(self._sub_grads[0], self._sub_grads[1], out=self.grads)
+        mb, _ = ep.sched.minibatch(k)
+        idx = ep.order_dev[k * B:(k + 1) * B]
+        engine.forward(it.packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
+        # gathers of the minibatch rows, the loss and zero_grad in one launch
+        engine.ppo_loss_rows(B, value_b, logp_b, ent_b, idx, it.adv, it.ret, it.old_logp, it.exps,
+                             self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
+                             dvalue, dlogp, dent, self.grads[nflt:], zero=self.grads[:nflt])
+        engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
         self.dist.all_reduce_sum(self.grads)              # ONE collective per optimizer step (no-op for one rank)
         if self.clip_pending:
             engine.clip_first_step(self.grads, self.max_grad_norm, self.scratch)

@@ -138,15 +138,12 @@ extern "C" int upamd_tune(const char *name, int32_t value) {
     if (!strcmp(name, "gemm_stagger_cycles")) { set_gemm_stagger(-1, value); return UPAMD_OK; }
     if (!strcmp(name, "fold_layer1")) { set_fold_layer1(value); return UPAMD_OK; }
     if (!strcmp(name, "pq_exp")) { set_pq_exp(value); return UPAMD_OK; }
-    if (!strcmp(name, "edge_min_lds")) { set_edge_min_lds(value); return UPAMD_OK; }
     if (!strcmp(name, "bwd_nb_global")) { set_bwd_nb_global(value); return UPAMD_OK; }
-    if (!strcmp(name, "gemm_tn_dma")) { set_gemm_tn_dma(value); return UPAMD_OK; }
     if (!strcmp(name, "nt_min_wgs")) { set_gemm_nt_min_wgs(value); return UPAMD_OK; }
     if (!strcmp(name, "gemm_split")) { set_gemm_nt_split(value); return UPAMD_OK; }
     if (!strcmp(name, "he_fused")) { set_he_feat_fused(value); return UPAMD_OK; }
     if (!strcmp(name, "side_wgrad")) { set_side_wgrad(value); return UPAMD_OK; }
     if (!strcmp(name, "side_priority")) { set_side_priority(value); return UPAMD_OK; }
-    if (!strcmp(name, "virtual_g")) { set_virtual_g(value); return UPAMD_OK; }
     if (!strcmp(name, "side_heads")) { set_side_heads(value); return UPAMD_OK; }
     if (!strcmp(name, "side_stream")) { set_side_stream(value); return UPAMD_OK; }
     if (!strcmp(name, "fwd_h_hbm")) { set_fwd_h_hbm(value); return UPAMD_OK; }

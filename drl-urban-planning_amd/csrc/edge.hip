@@ -683,11 +683,6 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     }
 }
 
-// tune knob "edge_min_lds" (bytes, default 0): every message-passing launch asks for at least this much dynamic LDS.  Above
-// 80 KB only ONE of these workgroups fits a CU, which leaves LDS and wave slots for the GEMM workgroups of another stream
-// (PPOUpdater(sub_batches=2): MFMA-bound GEMMs of one half-minibatch next to the VALU-bound walk of the other)
-static int64_t g_edge_min_lds = 0;
-void set_edge_min_lds(int bytes) { g_edge_min_lds = bytes > 0 ? (bytes < LDS_LIMIT ? bytes : LDS_LIMIT) : 0; }
 static int g_bwd_nb_global = 1;  // tune knob "bwd_nb_global", see edge_bwd_kernel (NBG)
 void set_bwd_nb_global(int on) { g_bwd_nb_global = on ? 1 : 0; }
 static int g_fwd_h_hbm = 1;      // tune knob "fwd_h_hbm": the large size class of the forward keeps H in HBM (two workgroups per CU)
@@ -700,10 +695,6 @@ void set_fwd_h_hbm(int on) { g_fwd_h_hbm = on ? 1 : 0; }
 bool edge_fold_pays(const MbView &mb) {
     return edge_lds_bytes(mb.max_n, mb.max_inc, false, false, true, true) <= LDS_HALF &&
            edge_lds_bytes(mb.max_n, mb.max_inc, true, false, true, true) <= LDS_HALF;
-}
-// every size class of this minibatch's backward runs a staged (LDS-resident) kernel
-bool edge_bwd_all_staged(const MbView &mb, bool last) {
-    return edge_lds_bytes(mb.max_n, mb.max_inc, true, last, true, true) <= LDS_LIMIT;
 }
 bool edge_fold_ok(const MbView &mb) {
     return edge_lds_bytes(mb.max_n, mb.max_inc, false, false, true, true) <= LDS_LIMIT &&
@@ -723,7 +714,6 @@ int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, co
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
     // one launch of a given (stage, lds, fit) configuration
     auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool hlds = true) -> int {
-        if (lds < g_edge_min_lds) lds = g_edge_min_lds;
 #define UPAMD_EF(L_, S_, F_, H_, D_)                                                                                  \
     do {                                                                                                              \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_fwd_kernel<L_, S_, F_, H_, D_>), lds)) return rc_;  \
@@ -792,7 +782,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
                                                                 const float *__restrict__ dhbarE, int ld_dhbarE,
                                                                 const float *__restrict__ dMhe, float *__restrict__ dPQ,
                                                                 float *__restrict__ dbias_part, int aux_cap, int fit,
-                                                                FoldArgs fa, const uint8_t *__restrict__ pqflag, int nfb, VirtualG vg) {
+                                                                FoldArgs fa, const uint8_t *__restrict__ pqflag, int nfb) {
     static_assert(!FOLD || STAGE, "the folded first layer computes its slice into LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / NP, p = blockIdx.x % NP;
@@ -820,37 +810,14 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
     const bool batched = STAGE && !dma && fits_batched(n, e);
     bool ok = false;
     if (dma) {
-        // "virtual G" (last layer, one attention head): G^L was never written; a node's row is rebuilt from two scalars of the
-        // attention backward and three per-graph vectors (graph.hip: attn_bwd16_kernel)
-        const bool virt = LAST && vg.alpha != nullptr;
         dma_pq_slice(L.PQ, Pg, Qg, n);
-        if (!virt) dma_x_slice(L.X, Gg, n);                    // raw G; turned into dS in place below
+        dma_x_slice(L.X, Gg, n);                               // raw G; turned into dS in place below
         ListRegs lr;
         lists_load(lr, rpg, nbg, og, nullptr, n, NBG ? 0 : e);
         // degrees of the G rows whose chunks THIS lane has requested (wave-instruction t = w, w + 16: node 16 t + lane / 4)
         const int v0 = 16 * w + (lane >> 2), v1 = v0 + 16 * EDGE_WAVES;
         const int d00 = rpg[v0 < n ? v0 : 0], d01 = rpg[v0 < n ? v0 + 1 : 0];
         const int d10 = rpg[v1 < n ? v1 : 0], d11 = rpg[v1 < n ? v1 + 1 : 0];
-        float va0 = 0.f, vd0 = 0.f, va1 = 0.f, vd1 = 0.f;      // alpha, dscore of the lane's two nodes
-        uint32_t vm0 = 0, vm1 = 0;                             // their node-mask bytes
-        float4 vdh = make_float4(0.f, 0.f, 0.f, 0.f), vds = vdh, vr = vdh;
-        if (LAST && virt) {
-            const uint8_t *nmg = pk.nmask + m[9];
-            va0 = vg.alpha[o + (v0 < n ? v0 : 0)]; vd0 = vg.dscore[o + (v0 < n ? v0 : 0)]; vm0 = nmg[v0 < n ? v0 : 0];
-            va1 = vg.alpha[o + (v1 < n ? v1 : 0)]; vd1 = vg.dscore[o + (v1 < n ? v1 : 0)]; vm1 = nmg[v1 < n ? v1 : 0];
-            const int col = p * 16 + (tid & 3) * 4;
-            // dhbarV sits D floats in front of dhbarE in the state-value gradient row
-            vdh = *reinterpret_cast<const float4 *>(dhbarE + (int64_t)b * ld_dhbarE - NP * 16 + col);
-            const float inv_nm = 1.f / (float)m[6];
-            vdh = make_float4(vdh.x * inv_nm, vdh.y * inv_nm, vdh.z * inv_nm, vdh.w * inv_nm);
-            vds = *reinterpret_cast<const float4 *>(vg.ds + (int64_t)b * (NP * 16) + col);
-            vr = *reinterpret_cast<const float4 *>(vg.r + (int64_t)b * (NP * 16) + col);
-        }
-        auto vrow = [&](float a, float dsc, uint32_t live) -> float4 {
-            const float lv = live ? 1.f : 0.f;
-            return make_float4(fmaf(dsc, vr.x, fmaf(a, vds.x, lv * vdh.x)), fmaf(dsc, vr.y, fmaf(a, vds.y, lv * vdh.y)),
-                               fmaf(dsc, vr.z, fmaf(a, vds.z, lv * vdh.z)), fmaf(dsc, vr.w, fmaf(a, vds.w, lv * vdh.w)));
-        };
         float4 ex4 = make_float4(0.f, 0.f, 0.f, 0.f);          // the lane's four columns are the same on every trip
         if (LAST) {
             const float4 dh = *reinterpret_cast<const float4 *>(dhbarE + (int64_t)b * ld_dhbarE + p * 16 + (tid & 3) * 4);
@@ -862,17 +829,17 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
         float4 *x4 = reinterpret_cast<float4 *>(L.X);
         if (v0 < n) {
             const float inv = __builtin_amdgcn_rcpf((float)(d01 - d00) + 1e-6f);
-            const float4 g0 = virt ? vrow(va0, vd0, vm0) : x4[4 * v0 + (lane & 3)];
+            const float4 g0 = x4[4 * v0 + (lane & 3)];
             x4[4 * v0 + (lane & 3)] = make_float4(fmaf(g0.x, inv, ex4.x), fmaf(g0.y, inv, ex4.y), fmaf(g0.z, inv, ex4.z), fmaf(g0.w, inv, ex4.w));
         }
         if (v1 < n) {
             const float inv = __builtin_amdgcn_rcpf((float)(d11 - d10) + 1e-6f);
-            const float4 g1 = virt ? vrow(va1, vd1, vm1) : x4[4 * v1 + (lane & 3)];
+            const float4 g1 = x4[4 * v1 + (lane & 3)];
             x4[4 * v1 + (lane & 3)] = make_float4(fmaf(g1.x, inv, ex4.x), fmaf(g1.y, inv, ex4.y), fmaf(g1.z, inv, ex4.z), fmaf(g1.w, inv, ex4.w));
         }
         for (int v = v1 + 16 * EDGE_WAVES; v < n; v += 16 * EDGE_WAVES) {      // graphs above 512 nodes
             const float inv = __builtin_amdgcn_rcpf((float)(rpg[v + 1] - rpg[v]) + 1e-6f);
-            const float4 gg = virt ? vrow(vg.alpha[o + v], vg.dscore[o + v], (pk.nmask + m[9])[v]) : x4[4 * v + (lane & 3)];
+            const float4 gg = x4[4 * v + (lane & 3)];
             x4[4 * v + (lane & 3)] = make_float4(fmaf(gg.x, inv, ex4.x), fmaf(gg.y, inv, ex4.y), fmaf(gg.z, inv, ex4.z), fmaf(gg.w, inv, ex4.w));
         }
         ok = !bad && fmaxf(fabsf(bc.x), fabsf(bc.y)) <= EF_BIAS_LIMIT;
@@ -1133,26 +1100,21 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
 
 int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
-                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold, const uint8_t *pqflag,
-                    const VirtualG *virt) {
+                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold, const uint8_t *pqflag) {
     const int NP = D / 16;
     const int nfb = 2 * D / 64;
     if (fold) pqflag = nullptr;
-    const VirtualG vg = virt ? *virt : VirtualG{nullptr, nullptr, nullptr, nullptr};
-    if (virt && !(last && pqflag && edge_bwd_all_staged(mb, true)))
-        return fail(UPAMD_E_INVALID, "edge_bwd: the virtual-G form needs the last layer, the LDS-DMA stage-in and staged size classes");
     const FoldArgs fa = fold ? *fold : FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (fold && (last || !edge_fold_ok(mb)))
         return fail(UPAMD_E_LIMIT, "edge_bwd: the folded first layer needs the staged size class and a later layer behind it");
     const int began = prof_begin(prof, "edge_bwd", st, 0.0, 0.0);
     dim3 grid((unsigned)(mb.B * NP)), block(EDGE_THREADS);
     auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool nbg = false) -> int {
-        if (lds < g_edge_min_lds) lds = g_edge_min_lds;
 #define UPAMD_EB(L_, S_, F_, D_, N_)                                                                                  \
     do {                                                                                                              \
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void *>(&edge_bwd_kernel<L_, S_, F_, D_, N_>), lds)) return rc_;  \
         hipLaunchKernelGGL((edge_bwd_kernel<L_, S_, F_, D_, N_>), grid, block, (size_t)lds, st, pk, mb, NP, PQ, bias, G,  \
-                           dhbarE, ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit, fa, pqflag, nfb, vg);              \
+                           dhbarE, ld_dhbarE, dMhe, dPQ, dbias_part, aux_cap, fit, fa, pqflag, nfb);                 \
     } while (0)
         const bool dma = pqflag != nullptr;
         if (nbg) {

@@ -19,7 +19,7 @@ using namespace upamd;
 struct SideCtx {
     hipStream_t side = nullptr;
     // a second stream of the same (high) priority for the weight-gradient GEMMs of small minibatches (side_wgrad).  Measured at 256
-    // rows (profiles/r03_lab_virtual_g.log): at NORMAL priority it is the fastest form without a process group (2.39 ms; at high
+    // rows (profiles/r03_lab_rccl_side_stream.log): at NORMAL priority it is the fastest form without a process group (2.39 ms; at high
     // priority the weight gradient runs ahead of the caller's dgrad GEMM, the one on the critical path: 2.47 ms) -- but with RCCL
     // initialised a normal-priority stream shares the caller's hardware queue and the cross-stream events then stall it (3.08 ms
     // against 2.55 ms without side_wgrad).  High priority is the setting that holds in both worlds (2.46-2.47 ms).
@@ -34,7 +34,7 @@ struct upamd_engine {
     ParamLayout P;
     Profiler prof;
     // one side context per CALLER stream (created on first use, on the device of that stream): two callers that drive
-    // the engine on two streams (PPOUpdater(sub_batches=2), an action server next to the learner) do not queue their
+    // the engine on two streams (an action server next to the learner) do not queue their
     // side chains behind each other.  The engine's entry points are not re-entrant: the host wrapper serialises them.
     std::unordered_map<hipStream_t, SideCtx> sides;
 };
@@ -62,7 +62,7 @@ enum Slot : int {
     // backward
     S_DSV, S_DATT, S_DO, S_DS, S_DR, S_DQ1, S_DQ0, S_DC, S_DC_HEAD, S_DCONST, S_DWKK, S_DWVV, S_DBVV, S_DW1F, S_DWBD, S_TN, S_DWC1,
     S_DZ_HE, S_DZ_RN, S_DPREL, S_DFE, S_DMHE, S_DPRER, S_DXR, S_G0, S_G1, S_DPQ, S_DPQ2, S_SLAB_SMALL, S_SLAB_XP1, S_SLAB_XP2, S_SLAB_FE,
-    S_SLAB_XR, S_CSP0, S_CSP1, S_CSP2, S_CSP3, S_DSCORE,
+    S_SLAB_XR, S_CSP0, S_CSP1, S_CSP2, S_CSP3,
     S_WCAT,                               // + l (0 .. L-1)
     S_WCATT = S_WCAT + MAXL,              // + l
     S_H = S_WCATT + MAXL,                 // + l (0 .. L)
@@ -197,8 +197,6 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     add(S_DZ_HE, NH); add(S_DZ_RN, NR); add(S_DPREL, NH * x.h0l); add(S_DFE, NH * 2 * D); add(S_DMHE, NH * D);
     add(S_DPRER, NR * x.h0r); add(S_DXR, NR * D);
     add(S_G0, M * D); add(S_G1, M * D); add(S_DPQ, M * 2 * D);
-    add(S_DSCORE, (int64_t)x.heads * M);
-    if (side_wgrad_on(M)) add(S_DPQ2, M * 2 * D);      // second dP|dQ buffer: layer l's weight gradient may still read its own
     // small models (no MFMA-tiled weight-gradient shapes): the node-level dY^T X products join the step's one grouped
     // launch at the end, so every layer's dP | dQ has to survive until then
     if (defer_node_tn(D))
@@ -232,6 +230,10 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     // per-row sums of the pointer heads' backward (pointer_bwd2): [B][h0] each, reduced over the rows afterwards;
     // 0: land dz*hid, 1: (free), 2: road dz*hid, 3: road dpre  (the land dpre sums are S_DCONST)
     for (int k = 0; k < 4; ++k) add(S_CSP0 + k, B * std::max(std::max(x.h0l, x.h0r), 16));
+    // second dP|dQ buffer (layer l's weight gradient on the side stream may still read its own).  LAST slot of the plan on
+    // purpose: whether it exists depends on a process-wide knob, and a knob change between a forward and its backward must not
+    // move any other slot (it only changes the size the backward asks for, which check_args verifies)
+    if (side_wgrad_on(M)) add(S_DPQ2, M * 2 * D);
     pl->total = off;
 }
 
@@ -342,12 +344,6 @@ static int stream_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
 // the attention backward -- runs on the side stream.  All of these are HBM-bound kernels of 0.1-0.3 ms that used to queue one
 // behind the other; the two chains only meet at the last GCN layer's backward (dS from the attention side, dM from the head side).
 static int g_side_heads = 1;
-// tune knob "virtual_g" (default OFF; with side_heads, one attention head, LDS-DMA stage-in of the last layer): the attention backward
-// hands the last layer's message-passing backward two scalars per node instead of G^L; G^L itself (the residual of that layer's
-// dgrad GEMM) is materialised by a small kernel on the side stream, off the critical path.  Measured -1.5 % at 2048 rows (the
-// valley in front of the last layer's backward shrinks, but its stage-in now chases two scalars per node and the materialising
-// kernel competes with it: edge_bwd 3.41 -> 3.76 ms), profiles/r03_lab_virtual_g.log
-static int g_virtual_g = 0;
 static hipEvent_t next_event(SideCtx *c) { return c->pool[c->pool_next++ & 7]; }
 
 // An error return between fork and join must not leave side-stream work running on a workspace the caller may free next:
@@ -420,9 +416,17 @@ struct Reducer {
     RedJobs jobs;
     int blocks = 0;
     hipStream_t st;
+    // forked step: some sources of a reducer that flushes on `st` are produced on the side streams and are ordered only by the
+    // step's final join.  A flush forced EARLY by a full job table (deep models: 2 + L (1 + 2 (K - 1)) jobs can pass
+    // RED_MAX_JOBS before the join) first makes `st` wait for everything the side streams have been given so far.
+    SideCtx *side = nullptr;
     int add(const float *slab, int S, int64_t sstride, int I, int J, int mode, int jkeep, float *dst, int ldd, float *dst2 = nullptr,
             int overwrite = 0) {
-        if (jobs.n >= RED_MAX_JOBS) CK(flush());
+        if (jobs.n >= RED_MAX_JOBS) {
+            if (side && side->side != st) CK(stream_after(st, side->side, next_event(side)));
+            if (side && side->side2 && side->side2 != st) CK(stream_after(st, side->side2, next_event(side)));
+            CK(flush());
+        }
         return red_add(&jobs, &blocks, slab, S, sstride, I, J, mode, jkeep, dst, ldd, dst2, overwrite);
     }
     int flush() {
@@ -512,7 +516,6 @@ void upamd::set_pq_exp(int on) { g_pq_exp = on ? 1 : 0; }
 void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
 void upamd::set_side_priority(int v) { g_side_priority = (v >= 0 && v <= 2) ? v : 1; }
 void upamd::set_side_heads(int on) { g_side_heads = on ? 1 : 0; }
-void upamd::set_virtual_g(int on) { g_virtual_g = on ? 1 : 0; }
 void upamd::set_side_wgrad(int on) { g_side_wgrad = (on >= 0 && on <= 3) ? on : 1; }
 
 extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
@@ -1054,6 +1057,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     if (forked) {
         CK(side_ready(eng, st, &sc));
         side_guard.c = sc;
+        red1.side = sc;
+        red2.side = sc;
     }
     if (heads_side) {
         CK(fork_side(sc, st));
@@ -1078,14 +1083,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     const float *dhbarE = dSV + x.S_last + D;
     // ---- 2. attention core: writes G^L (mean + attention terms) and dr
     float *G = W(S_G0), *Gn = W(S_G1);
-    // "virtual G": only the per-node scalars now; G^L follows on the side stream (below), the last layer's backward does not need it
-    const bool vgmode = heads_side && g_virtual_g && x.heads == 1 && x.K == 1 && x.L >= 2 && !defer && attn_bwd_single_pass_ok(mb, D, x.heads) &&
-                        edge_bwd_all_staged(mb, true) &&
-                        pq_exp_layer(pq_gemm(W(S_H + x.L - 1), mb.M, D, W(S_WCAT + x.L - 1), W(S_PQ + x.L)), x.L, x.K);
-    const VirtualG vg{W(S_ALPHA), W(S_DSCORE), W(S_DS), W(S_R)};
-    hipEvent_t g_ready = nullptr;
-    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W(S_R), W(S_ALPHA), W(S_S), W(S_DS), dhbarV, x.Wp, vgmode ? nullptr : G, W(S_DR), st,
-                       vgmode ? W(S_DSCORE) : nullptr));
+    CK(launch_attn_bwd(pk, mb, D, x.heads, HL, W(S_R), W(S_ALPHA), W(S_S), W(S_DS), dhbarV, x.Wp, G, W(S_DR), st));
     if (heads_side) UPAMD_HIP(hipEventRecord(sc->ev_a, st));      // dr + everything chain_bwd_post wrote: the side chain waits for it below
     // ---- 3. pointer heads: softmax backward + second-Linear backward fused
     CK(launch_pointer_bwd2(pk, mb, W(S_Z_HE), W(S_Z_RN), W(S_P_HE), W(S_P_RN), W(S_ENTK), W(S_LSE), dlogp_dev, dent_dev, W(S_HIDL),
@@ -1206,11 +1204,6 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_chain_bwd_pre(a, forked ? sc->side : st));
     }
     if (forked) CK(grouped_launch(sc->side));
-    if (vgmode) {
-        CK(launch_attn_g(pk, mb, D, x.heads, W(S_ALPHA), W(S_DSCORE), W(S_DS), W(S_R), dhbarV, x.Wp, G, sc->side));
-        g_ready = next_event(sc);
-        UPAMD_HIP(hipEventRecord(g_ready, sc->side));
-    }
     // ---- 5. GCN layers, last to first
     const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
@@ -1247,8 +1240,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             const bool expf = l >= 2 && pq_exp_layer(pq_gemm(W(S_H + l - 1), mb.M, D, W(S_WCAT + l - 1), W(S_PQ + l)), l, x.K);
             CK(launch_edge_bwd(pk, mb, D, last, W(S_PQ + l), PR(P.edge_b[l - 1]), G, dhbarE, x.Wp, (last && land) ? W(S_DMHE) : nullptr,
                                dPQ, W(S_DBIAS + l), st, prof, (l == 1 && fold) ? &fa : nullptr,
-                               expf ? reinterpret_cast<const uint8_t *>(W(S_PQF + l)) : nullptr, (last && vgmode) ? &vg : nullptr));
-
+                               expf ? reinterpret_cast<const uint8_t *>(W(S_PQF + l)) : nullptr));
         }
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
         CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
@@ -1256,8 +1248,6 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             // side_wgrad = 1: the weight gradient starts next to this layer's dgrad; 2: behind it, i.e. next to the NEXT layer's
             // message-passing backward (the dgrad is launched first and the side stream waits for it)
             if (wgrad_side && g_side_wgrad == 2) {
-                // (virtual G: G^L, the residual of the last layer's dgrad, is materialised on the side stream)
-                if (last && vgmode) UPAMD_HIP(hipStreamWaitEvent(st, g_ready, 0));
                 CK(launch_gemm_nt(dPQ, mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
                 std::swap(G, Gn);
             }
@@ -1284,8 +1274,6 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                 UPAMD_HIP(hipEventRecord(wgrad_done[l], sc->side2));
             }
             if (!(wgrad_side && g_side_wgrad == 2)) {
-                // (virtual G: G^L, the residual of the last layer's dgrad, is materialised on the side stream)
-                if (last && vgmode) UPAMD_HIP(hipStreamWaitEvent(st, g_ready, 0));
                 CK(launch_gemm_nt(dPQ, mb.M, 2 * D, W(S_WCATT + l - 1), D, nullptr, G, Gn, 0, st, prof));
                 std::swap(G, Gn);
             }

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 4 ? 2 : 1)) void gemm_nt_d
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[i][j][r]));
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
-        const bool lin = !(mx * PQ_C2 <= PQ_EXP_LIMIT);       // (a NaN anywhere keeps the block linear)
+        const bool lin = !(mx * PQ_C2 <= PQ_EXP_LIMIT);       // (fmaxf drops NaNs, so a NaN does not force the linear form; exp2(NaN) is NaN either way)
         if (lane == 0) exp_flags[(int64_t)(mt * (BM / 64) + wr) * (N >> 6) + (n0 >> 6) + wc] = lin ? 1 : 0;
         if (!lin) {
 #pragma unroll
@@ -734,108 +734,6 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float *__restri
 }
 
 
-// ------------------------------------------------------------------------------------------ TN, LDS-DMA staging (round 3)
-// slab[i][j] = sum over the split's rows of A[r][i] B[r][j], both operands panel-major, 128 x 128 tile per workgroup.
-//   * A 16-row chunk of one 16-column panel is ONE contiguous KiB in HBM (rows r .. r+15 of the panel): it goes to LDS with a
-//     single global_load_lds_dwordx4 wave-instruction (lane = row lane/4, 16-byte column quad lane%4) -- 16 instructions per
-//     chunk and workgroup (8 A panels + 8 B panels), 4 per wave, no staging VGPRs, no ds_write pass.  Panels are 272 floats
-//     apart in LDS (16-float pad: consecutive panels start 16 banks apart).
-//   * The contraction runs over ROWS, so a lane cannot read "its" column for several k with one wide load.  Instead the 16-byte
-//     quad (row k, columns 4c .. 4c+3) a lane reads with one ds_read_b128 feeds FOUR MFMAs as their A operand: MFMA m of the
-//     wave handles the output rows i = 4 c + m (c = the lane's index in the MFMA's row dimension) -- a permutation of the
-//     tile's rows that only the store has to know about.  A wave owns all 128 rows x 32 columns of the tile: per chunk
-//     8 ds_read_b128 (A) + 8 ds_read_b32 (B) for 32 MFMAs (the register-staged kernel: 32 ds_read_b32 + 4 global loads +
-//     4 ds_write_b128 per thread).
-//   * two LDS stages, the next chunk requested behind the fragment reads; rows past the split's end are clamped at the
-//     source and masked at the fragments of the last chunk.
-__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const float *__restrict__ A, int I, const float *__restrict__ Bm, int J,
-                                                          int64_t M, int64_t chunk, float *__restrict__ slabs, int IT, int JT, int S) {
-    constexpr int PS = 272, NPAN = 8, STAGE = 2 * NPAN * PS;      // floats
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tiles = IT * JT;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
-    if (split >= S) return;
-    const int it = tile / JT, jt = tile % JT;
-    const int i0 = it * 128, j0 = jt * 128;
-    const int64_t r0 = (int64_t)split * chunk;
-    const int64_t r1 = (r0 + chunk < M) ? r0 + chunk : M;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, lhi = lane >> 5;
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
-    // DMA instruction q = 4 w + u of a chunk: panel q of the stage (0..7 = A panels, 8..15 = B panels)
-    const float *src[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int q = 4 * w + u;
-        const float *base = q < NPAN ? A + (int64_t)(i0 / 16 + q) * M * 16 : Bm + (int64_t)(j0 / 16 + q - NPAN) * M * 16;
-        src[u] = base + (lane & 3) * 4;
-    }
-    auto issue = [&](int64_t rr, int s) {
-        int64_t gr = rr + (lane >> 2);
-        if (gr >= M) gr = M - 1;                   // valid address; the fragment masks below discard these rows
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[u] + gr * 16), (lptr_t)(smem + s * STAGE + (4 * w + u) * PS), 16, 0, 0);
-    };
-    // fragment addresses (floats, within a stage): A quad c = l31 at row 2 s + lhi;  B column w * 32 + l31
-    const int aoff = (l31 >> 2) * PS + lhi * 16 + (l31 & 3) * 4;
-    const int cj = w * 32 + l31;
-    const int boff = (NPAN + (cj >> 4)) * PS + lhi * 16 + (cj & 15);
-
-    int stage = 0;
-    if (r0 < r1) issue(r0, 0);
-    for (int64_t rr = r0; rr < r1; rr += 16, stage ^= 1) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        const float *st = smem + stage * STAGE;
-        float4 a4[8];
-        float b[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            a4[s] = *reinterpret_cast<const float4 *>(st + aoff + 32 * s);
-            b[s] = st[boff + 32 * s];
-        }
-        if (rr + 16 < r1) issue(rr + 16, stage ^ 1);
-        if (rr + 16 > r1) {                        // last, partial chunk: rows >= r1 contribute nothing
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (rr + 2 * s + lhi >= r1) {
-                    a4[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    b[s] = 0.f;
-                }
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].x, b[s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].y, b[s], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].z, b[s], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].w, b[s], acc[3], 0, 0, 0);
-        }
-    }
-    float *slab = slabs + (int64_t)split * I * J;
-    const int gj = j0 + cj;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;      // index in the MFMA's row dimension = the A lane's quad c
-            slab[(int64_t)(i0 + 4 * row + m) * J + gj] = acc[m][r];
-        }
-}
-
-// tune knob "gemm_tn_dma" (default OFF): measured 2.3 % slower than the register-staged kernel inside the step (2.545 vs
-// 2.488 ms per step for the two weight-gradient launches, profiles/r03_lab_gemm_tn_dma.log) -- every wave re-reads the whole
-// A panel from LDS, and with one chunk of prefetch the DMA latency is no better hidden than the register loads were
-static int g_tn_dma = 0;
-void set_gemm_tn_dma(int on) { g_tn_dma = on ? 1 : 0; }
-
 __global__ void gemm_tn_generic_kernel(const float *__restrict__ A, int I, const float *__restrict__ Bm, int J,
                                        int64_t M, int64_t chunk, float *__restrict__ slabs) {
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
@@ -881,12 +779,7 @@ bool gemm_tn_mfma_ok(const GemmTN &g) {
 template <bool IN_RM>
 static void launch_tn_layout(const GemmTN &g, int S, int64_t chunk, hipStream_t st) {
     const int IT = g.I / 128;
-    if (!IN_RM && g_tn_dma && g.J % 128 == 0) {
-        const int JT = g.J / 128;
-        const size_t lds = sizeof(float) * 2 * 2 * 8 * 272;
-        hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3((S + 7) / 8 * 8 * IT * JT), dim3(256), lds, st, g.A, g.I, g.Bm, g.J, g.M, chunk,
-                           g.slabs, IT, JT, S);
-    } else if (g.J % 128 == 0) {
+    if (g.J % 128 == 0) {
         const int JT = g.J / 128;
         hipLaunchKernelGGL((gemm_tn_mfma_kernel<128, 64, 64, IN_RM>), dim3((S + 7) / 8 * 8 * IT * JT), dim3(256), 0, st, g.A, g.I, g.lda, g.Bm, g.J,
                            g.ldb, g.M, chunk, g.slabs, IT, JT, S);

@@ -213,8 +213,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(PackedView pk, MbView m
                                                          const float *__restrict__ r, const float *__restrict__ alpha,
                                                          const float *__restrict__ s, const float *__restrict__ ds,
                                                          const float *__restrict__ dhbarV, int ld_dhbarV,
-                                                         float *__restrict__ GL, float *__restrict__ dr,
-                                                         float *__restrict__ dscore_out) {
+                                                         float *__restrict__ GL, float *__restrict__ dr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int D = NP * 16;
     float *sacc = reinterpret_cast<float *>(smem);         // [16 slots][D]
@@ -278,16 +277,9 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(PackedView pk, MbView m
             for (int q = 0; q < 16; ++q) tot += sacc[q * D + d];
             dr[((int64_t)b * heads + h) * D + d] = tot - T * s[((int64_t)b * heads + h) * D + d];
         }
-        for (int j = threadIdx.x; j < n; j += 256) {
-            d_h[j] = a_h[j] * (d_h[j] - T);
-            if (dscore_out) dscore_out[(int64_t)h * M + o + j] = d_h[j];
-        }
+        for (int j = threadIdx.x; j < n; j += 256) d_h[j] = a_h[j] * (d_h[j] - T);
         __syncthreads();
     }
-    // "virtual G" (dscore_out given, GL null): G^L_j = live_j dhbarV / n + sum_h (alpha_hj ds_h + dscore_hj r_h) is a function of
-    // two scalars per node and head and three vectors per graph -- the last GCN layer's message-passing backward, its only
-    // consumer, rebuilds the slice it needs from them (edge.hip) and the 4 D bytes per node of G^L are neither written nor read
-    if (!GL) return;
     const float inv_nm = 1.f / (float)m[6];
     if constexpr (NP % 4 == 0) {
         // 16-byte stores: lane (pg = c / 4, q = c % 4) of a node slot owns columns 4q .. 4q+3 of the panels pg, pg + 4, ... -- a
@@ -346,11 +338,11 @@ static int launch_attn_fwd16(const PackedView &pk, const MbView &mb, int heads, 
 template <int NP>
 static int launch_attn_bwd16(const PackedView &pk, const MbView &mb, int heads, const float *HL, const float *r,
                              const float *alpha, const float *s, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL,
-                             float *dr, hipStream_t st, float *dscore_out) {
+                             float *dr, hipStream_t st) {
     const size_t lds = sizeof(float) * (size_t)(16 * NP * 16 + 16 + 2 * heads * NP * 16 + 2 * heads * mb.max_n);
     if (lds > 64 * 1024) return -1;
     hipLaunchKernelGGL((attn_bwd16_kernel<NP>), dim3(mb.B), dim3(256), lds, st, pk, mb, heads, HL, r, alpha, s, ds, dhbarV,
-                       ld_dhbarV, GL, dr, dscore_out);
+                       ld_dhbarV, GL, dr);
     UPAMD_HIP(hipGetLastError());
     return 0;
 }
@@ -428,62 +420,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(PackedView pk, MbView mb,
     }
 }
 
-// G^L from the attention backward's per-node scalars (the "virtual G" form keeps this 4 D bytes-per-node write off the critical path:
-// the last layer's message-passing backward rebuilds its slices itself, and G^L is only needed as the residual of that layer's dgrad
-// GEMM two launches later -- this kernel runs on the side stream in between)
-__global__ __launch_bounds__(256) void attn_g_kernel(PackedView pk, MbView mb, int NP, int heads, const float *__restrict__ alpha,
-                                                     const float *__restrict__ dscore, const float *__restrict__ ds,
-                                                     const float *__restrict__ r, const float *__restrict__ dhbarV, int ld_dhbarV,
-                                                     float *__restrict__ GL) {
-    const int b = blockIdx.x;
-    const int32_t *m = mb.rows + (int64_t)b * UPAMD_META_STRIDE;
-    const int n = m[0], D = NP * 16;
-    const int64_t o = m[14], M = mb.M;
-    const uint8_t *nmask = pk.nmask + m[9];
-    const int c = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    const float inv_nm = 1.f / (float)m[6];
-    for (int j = slot; j < n; j += 16) {
-        const bool live = nmask[j] != 0;
-        for (int p = 0; p < NP; ++p) {
-            const int d = p * 16 + c;
-            float v = live ? dhbarV[(int64_t)b * ld_dhbarV + d] * inv_nm : 0.f;
-            for (int h = 0; h < heads; ++h)
-                v += alpha[(int64_t)h * M + o + j] * ds[((int64_t)b * heads + h) * D + d] +
-                     dscore[(int64_t)h * M + o + j] * r[((int64_t)b * heads + h) * D + d];
-            GL[((int64_t)p * M + o + j) * 16 + c] = v;
-        }
-    }
-}
-
-int launch_attn_g(const PackedView &pk, const MbView &mb, int D, int heads, const float *alpha, const float *dscore, const float *ds,
-                  const float *r, const float *dhbarV, int ld_dhbarV, float *GL, hipStream_t st) {
-    hipLaunchKernelGGL(attn_g_kernel, dim3(mb.B), dim3(256), 0, st, pk, mb, D / 16, heads, alpha, dscore, ds, r, dhbarV, ld_dhbarV, GL);
-    UPAMD_HIP(hipGetLastError());
-    return 0;
-}
-
-bool attn_bwd_single_pass_ok(const MbView &mb, int D, int heads) {
-    const int np = D / 16;
-    if (D % 16 || !(np == 1 || np == 2 || np == 4 || np == 8 || np == 16)) return false;
-    return sizeof(float) * (size_t)(16 * D + 16 + 2 * heads * D + 2 * heads * mb.max_n) <= 64 * 1024;
-}
-
 int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     const float *alpha, const float *s, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL,
-                    float *dr, hipStream_t st, float *dscore_out) {
+                    float *dr, hipStream_t st) {
     if (mb.rows && s) {
         int rc = -1;
         switch (D / 16) {
-            case 1: rc = launch_attn_bwd16<1>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st, dscore_out); break;
-            case 2: rc = launch_attn_bwd16<2>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st, dscore_out); break;
-            case 4: rc = launch_attn_bwd16<4>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st, dscore_out); break;
-            case 8: rc = launch_attn_bwd16<8>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st, dscore_out); break;
-            case 16: rc = launch_attn_bwd16<16>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st, dscore_out); break;
+            case 1: rc = launch_attn_bwd16<1>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
+            case 2: rc = launch_attn_bwd16<2>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
+            case 4: rc = launch_attn_bwd16<4>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
+            case 8: rc = launch_attn_bwd16<8>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
+            case 16: rc = launch_attn_bwd16<16>(pk, mb, heads, HL, r, alpha, s, ds, dhbarV, ld_dhbarV, GL, dr, st); break;
             default: break;
         }
         if (rc >= 0) return rc;      // -1: shape not covered, fall through to the two-pass kernel
     }
-    if (!GL) return fail(UPAMD_E_INVALID, "attn_bwd: the single-pass kernel does not cover this shape and G^L was not requested");
     const size_t lds = sizeof(float) * (size_t)(2 * heads * D + 2 * heads * mb.max_n + 256 + 8);
     if (lds > (size_t)LDS_LIMIT) return fail(UPAMD_E_LIMIT, "attn_bwd: LDS need %zu too large", lds);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&attn_bwd_kernel), (int64_t)lds)) return rc;

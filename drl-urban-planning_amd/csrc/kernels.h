@@ -103,7 +103,6 @@ int64_t gemm_exp_flag_bytes(int64_t M, int N);
 bool gemm_nt_exp_store_ok(const GemmNT &g);      // a launch of g with exp_flags set WILL write them (same choice as the launcher)
 bool gemm_nt_mfma_ok(const GemmNT &g);
 void set_gemm_nt_dma_variant(int v);
-void set_gemm_tn_dma(int on);               // tune knob "gemm_tn_dma" (default off): LDS-DMA staged weight-gradient GEMM tiles
 void set_gemm_nt_min_wgs(int v);            // tune knob "nt_min_wgs": workgroups a launch must have before the 128-wide N tile is used
 void set_gemm_stagger(int mode, int cycles);
 void set_gemm_lds_pad(int bytes);   // first-residency-round stagger of the GEMM workgroups (-1 = keep)       // kernel-lab knob: LDS-DMA configuration of the plain panel-major launches
@@ -133,7 +132,6 @@ int launch_reduce_slabs(const float *slabs, int S, int I, int J, int mode, int j
 
 // ---- graph.hip -------------------------------------------------------------------------
 __host__ __device__ int64_t edge_lds_bytes(int max_n, int max_inc, bool bwd, bool last, bool stage, bool hlds = true, bool nblds = true);
-void set_edge_min_lds(int bytes);          // tune knob "edge_min_lds": minimum dynamic LDS of the message-passing launches (co-scheduling lab)
 void set_bwd_nb_global(int on);            // tune knob "bwd_nb_global" (default on): large size class of the backward walks the neighbour ids from global memory
 // First GCN layer folded into the message-passing stage-in (edge.hip: fold_fill): the workgroup computes its P/Q (and
 // H_0) slice from the raw node features.  Xp: panel-major [2][M][16]; W1c = Wcat_1 We [2D][32] (rows in P/Q pair
@@ -141,39 +139,26 @@ void set_bwd_nb_global(int on);            // tune knob "bwd_nb_global" (default
 struct FoldArgs {
     const float *Xp, *W1c, *b1c, *We, *be;
 };
-// "virtual G" of the last layer's backward (one attention head): G^L_j = live_j dhbarV / n + alpha_j ds + dscore_j r is rebuilt in
-// the kernel's stage-in from the attention backward's per-node scalars (alpha, dscore: [M]) and per-graph vectors (ds, r: [B][D];
-// dhbarV is read in front of dhbarE) instead of being written to and read from HBM (4 D bytes per node each way)
-struct VirtualG {
-    const float *alpha, *dscore, *ds, *r;
-};
-bool edge_bwd_all_staged(const MbView &mb, bool last);
 bool edge_fold_ok(const MbView &mb);        // every graph of the minibatch fits the staged (LDS-resident) size classes
 bool edge_fold_pays(const MbView &mb);      // ... and fits half the LDS (two workgroups per CU), where the fold beats the K = 32 GEMMs
 void set_fwd_h_hbm(int on);                // tune knob: large-graph size class of the forward with H left in HBM (default on)
-void set_side_wgrad(int on);               // tune knob "side_wgrad" (default off): GCN weight-gradient GEMMs on the side stream
+void set_side_wgrad(int on);               // tune knob "side_wgrad" (default 1 = adaptive: on for minibatches of <= 98304 nodes; 0 never, 2 behind the dgrad, 3 always): GCN weight-gradient GEMMs on a side stream
 void set_side_priority(int v);             // tune knob "side_priority": priority level of the side streams created from now on (1 high, 0 normal, 2 low)
 void set_side_heads(int on);               // tune knob "side_heads" (default on): the land-use pointer-head chain on the side stream
 void set_side_stream(int on);              // tune knob "side_stream" (default on): per-sample chains + grouped weight gradients on an engine-owned side stream
 void set_pq_exp(int on);                   // tune knob "pq_exp" (default on): exp-form P/Q from the GEMM epilogue + LDS-DMA stage-in
-void set_fold_layer1(int on);              // tune knob: compute the first GCN layer inside the message-passing kernels       // every graph of the minibatch fits the staged (LDS-resident) size classes
+void set_fold_layer1(int on);              // tune knob: compute the first GCN layer inside the message-passing kernels
 int launch_edge_fwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *Hin, float *Hout, float *hbarV, float *hbarE, const float *Ccur, float *FE,
                     hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, int fe_full = 1, const uint8_t *pqflag = nullptr);
 int launch_edge_bwd(const PackedView &pk, const MbView &mb, int D, bool last, const float *PQ, const float *bias,
                     const float *G, const float *dhbarE, int ld_dhbarE, const float *dMhe, float *dPQ,
-                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, const uint8_t *pqflag = nullptr,
-                    const VirtualG *virt = nullptr);
+                    float *dbias_part, hipStream_t st, Profiler *prof, const FoldArgs *fold = nullptr, const uint8_t *pqflag = nullptr);
 int launch_attn_fwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     float *alpha, float *s, hipStream_t st);
 int launch_attn_bwd(const PackedView &pk, const MbView &mb, int D, int heads, const float *HL, const float *r,
                     const float *alpha, const float *s, const float *ds, const float *dhbarV, int ld_dhbarV, float *GL, float *dr,
-                    hipStream_t st, float *dscore_out = nullptr);
-// the single-pass attention backward covers this shape (then GL may be null and dscore_out given: "virtual G", see edge.hip)
-bool attn_bwd_single_pass_ok(const MbView &mb, int D, int heads);
-int launch_attn_g(const PackedView &pk, const MbView &mb, int D, int heads, const float *alpha, const float *dscore, const float *ds,
-                  const float *r, const float *dhbarV, int ld_dhbarV, float *GL, hipStream_t st);
-void set_virtual_g(int on);                // tune knob "virtual_g" (default off, needs side_heads): see VirtualG
+                    hipStream_t st);
 int launch_he_feat_bwd(const PackedView &pk, const MbView &mb, int D, const float *FE, const float *C,
                        const float *dFE, float *dMhe, float *dC_head, hipStream_t st, int keep_dead = 0);
 // the same with dFE = dpre W1f (h0 == 32) computed inside the kernel on the matrix cores: no dFE tensor in HBM

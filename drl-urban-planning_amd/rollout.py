@@ -55,6 +55,7 @@ class ActionClient:
         self._shm_name, self.index, self.slot_bytes, self.conn = shm_name, index, slot_bytes, conn
         self.timeout_s = timeout_s            # a dead server must not hang the sampling phase for ever
         self._shm = None
+        self._dead = None                     # set after a timeout: the request is still in flight on the shared slot
         self.type = 'discrete'
 
     def _slot(self):
@@ -64,6 +65,8 @@ class ActionClient:
         return np.ndarray((self.slot_bytes,), dtype=np.uint8, buffer=self._shm.buf, offset=base)
 
     def select_action(self, x, mean_action=False):
+        if self._dead is not None:
+            raise RuntimeError('action client %d is closed: %s' % (self.index, self._dead))
         if len(x) > self.MAX_ROWS:
             raise ValueError('at most %d states per request' % self.MAX_ROWS)
         slot = self._slot()
@@ -78,6 +81,13 @@ class ActionClient:
             cursor = _align(cursor + rec.size)
         self.conn.send((sizes, bool(mean_action)))
         if not self.conn.poll(self.timeout_s):
+            # the request stays in flight: the server may still read or answer it on the shared slot, and its late 'ok'
+            # would be taken for the answer to the NEXT request -- this client is finished
+            self._dead = 'a request timed out after %.0f s and may still be in flight' % self.timeout_s
+            try:
+                self.conn.close()
+            except OSError:
+                pass
             raise TimeoutError('action server did not answer within %.0f s (is its serving thread alive?)' % self.timeout_s)
         status = self.conn.recv()
         if status != 'ok':

@@ -288,10 +288,12 @@ int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev
  *   "pq_exp"      [1]   P/Q GEMMs of layers 2..L store 2^(C2 x) block by block (flag bytes), the message-passing kernels stage
  *                       their slices by LDS-DMA; 0 = plain P/Q, register-staged slices
  *   "bwd_nb_global" [1] backward of graphs too big for two workgroups per CU walks the neighbour ids from global memory
- *   "gemm_tn_dma" [0]   LDS-DMA staged 128 x 128 weight-gradient tiles (measured 2 % slower than the register-staged kernel)
  *   "fold_layer1" = 2   fold only where every graph of the minibatch fits half the LDS
  *   "nt_min_wgs"  [128] workgroups a gemm_nt launch must have before the 128-wide N tile is used (tests: 1)
- *   "edge_min_lds" [0]  minimum dynamic LDS of the message-passing launches (co-scheduling lab)
+ *   "side_heads"  [1]   land-use pointer-head chain (forward: first Linear; backward: softmax / feature / weight-gradient kernels) on the side stream
+ *   "side_wgrad"  [1]   GCN weight-gradient GEMMs on a second side stream: 1 = for minibatches of <= 98304 nodes, 0 never, 2 behind the
+ *                       layer's dgrad GEMM, 3 always
+ *   "side_priority" [1] priority level of the side streams created from now on: 1 high, 0 normal, 2 low
  *   "gemm_lds_pad", "gemm_stagger_mode", "gemm_stagger_cycles": residency / first-round stagger of the LDS-DMA gemm_nt */
 int upamd_tune(const char *name, int32_t value);
 /* Lab hook: one wave writes `samples` pairs (shader-clock counter, 100 MHz wall-clock counter) into out_dev (int64[2 * samples]),

@@ -70,30 +70,6 @@ def test_gemm_tn(M, I, J, rm):
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
 
 
-@pytest.mark.parametrize('M,I,J', [(5000, 512, 256), (70001, 128, 128), (2048, 256, 256), (17, 128, 128)])
-def test_gemm_tn_lds_dma_kernel(M, I, J):
-    """The opt-in LDS-DMA staged weight-gradient kernel (tune knob gemm_tn_dma, default off: measured 2 % slower inside the
-    step): panel chunks by global_load_lds, one 16-byte LDS read feeding four MFMAs through a row permutation of the tile;
-    M not a multiple of 16 exercises the clamped source rows + masked fragments of the last chunk."""
-    lib = native.lib()
-    g = torch.Generator(device='cpu').manual_seed(M + I + J)
-    A = torch.randn(M, I, generator=g).to(DEV)
-    B = torch.randn(M, J, generator=g).to(DEV)
-    ref = (A.double().t() @ B.double()).float()
-    scratch = torch.empty(int(lib.upamd_gemm_tn_scratch_floats(I, J, M)), device=DEV)
-    out = torch.empty(I, J, device=DEV)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    A_in, B_in = to_pm(A), to_pm(B)       # (named: a temporary would be freed -- and its block reused -- before the launch)
-    native.check(lib.upamd_tune(b'gemm_tn_dma', 1))
-    try:
-        native.check(lib.upamd_gemm_tn(P(A_in), I, I, P(B_in), J, J, M, 0, P(scratch), P(out), st))
-        torch.cuda.synchronize()
-    finally:
-        native.check(lib.upamd_tune(b'gemm_tn_dma', 0))
-    scale = float(ref.abs().max())
-    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
-
-
 @pytest.mark.parametrize('M,K,N', [(4099, 256, 512), (777, 512, 256), (130, 16, 128), (1500, 48, 128)])
 @pytest.mark.parametrize('nprod', [6, 9])
 def test_gemm_nt_split_has_fp32_accuracy(M, K, N, nprod):
