@@ -278,7 +278,7 @@ def main():
     if not args.no_kernel_events:
         for name in ('gemm_nt_128', 'gemm_nt_128_k32', 'gemm_nt_64', 'gemm_nt_32', 'gemm_nt_128_rm', 'gemm_nt_64_rm',
                      'gemm_nt_32_rm', 'gemm_nt_generic', 'gemm_tn_128', 'gemm_tn_64', 'gemm_tn_32', 'gemm_tn_generic', 'gemm_tn_small',
-                     'edge_fwd', 'edge_bwd'):
+                     'edge_fwd', 'edge_bwd', 'tiny_fwd', 'tiny_bwd', 'tiny_step'):
             st = engine.profile_read(name)
             if st['launches']:
                 kern[name] = st

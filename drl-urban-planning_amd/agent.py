@@ -100,6 +100,7 @@ class PPOUpdater:
         self.group_steps = [0, 0, 0]          # Adam step counts: encoder+value / land head / road head
         self.flat = self.m = self.v = self.grads = None
         self.engine = None
+        self.fused_small = True               # small models: forward + loss + backward as one launch (csrc/tiny.hip)
         self.last_losses = None               # np [steps, 4] of the last update_params call
         self.last_timing = {}
 
@@ -298,12 +299,24 @@ class PPOUpdater:
         inv_ind = 1.0 / ep.ind_glob[k] if ep.ind_glob[k] > 0 else float('nan')
         mb, _ = ep.sched.minibatch(k)
         idx = ep.order_dev[k * B:(k + 1) * B]
+        if self.fused_small and engine.step_fused_ok(mb):
+            # small models (gcn_node_dim <= 32, the shipped YAML dims): gathers + forward + loss + backward of the whole
+            # minibatch in ONE launch, the per-workgroup gradient slabs added by a second one (csrc/tiny.hip)
+            engine.step_fused(it.packed, mb, self.flat, idx, it.adv, it.ret, it.old_logp, it.exps, self.clip_epsilon,
+                              self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind, value_b, logp_b, ent_b,
+                              self.grads[:nflt], self.grads[nflt:])
+            return self._finish_step(ep, k, loss_out)
         engine.forward(it.packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
         # gathers of the minibatch rows, the loss and zero_grad in one launch
         engine.ppo_loss_rows(B, value_b, logp_b, ent_b, idx, it.adv, it.ret, it.old_logp, it.exps,
                              self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
                              dvalue, dlogp, dent, self.grads[nflt:], zero=self.grads[:nflt])
         engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
+        self._finish_step(ep, k, loss_out)
+
+    def _finish_step(self, ep, k, loss_out):
+        """all-reduce, first-step clip, Adam -- everything behind the backward of a step"""
+        engine, nflt = self.engine, self.engine.n_floats
         self.dist.all_reduce_sum(self.grads)              # ONE collective per optimizer step (no-op for one rank)
         if self.clip_pending:
             engine.clip_first_step(self.grads, self.max_grad_norm, self.scratch)

@@ -148,6 +148,8 @@ extern "C" int upamd_tune(const char *name, int32_t value) {
     if (!strcmp(name, "side_stream")) { set_side_stream(value); return UPAMD_OK; }
     if (!strcmp(name, "fwd_h_hbm")) { set_fwd_h_hbm(value); return UPAMD_OK; }
     if (!strcmp(name, "fe_half")) { set_fe_half(value); return UPAMD_OK; }
+    if (!strcmp(name, "tiny_fused")) { set_tiny_fused(value); return UPAMD_OK; }
+    if (!strcmp(name, "tiny_threads")) { set_tiny_threads(value); return UPAMD_OK; }
     return fail(UPAMD_E_INVALID, "upamd_tune: unknown knob '%s'", name);
 }
 

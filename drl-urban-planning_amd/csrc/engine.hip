@@ -85,7 +85,9 @@ enum Slot : int {
     S_EBP = S_EWT + MAXL * (MAXK + 1),    // + lk, k = 1 .. K-1: per-graph column sums of dpre_k+1 [B, D] (bias gradient of linear_k)
     S_ESLAB = S_EBP + MAXL * (MAXK + 1),  // + lk, k = 1 .. K-1: split-K slabs of dW_k
     S_PQF = S_ESLAB + MAXL * (MAXK + 1),  // + l (1 .. L): bytes, exp-form flags of the layer's P/Q GEMM output (kernels.h: PQ_EXP_LIMIT)
-    S_COUNT = S_PQF + MAXL + 1
+    // fused small-model path (tiny.hip): per-workgroup gradient slabs, per-workgroup global scratch, per-row loss terms
+    S_TINY_SLAB = S_PQF + MAXL + 1, S_TINY_SCR, S_TINY_LOSS,
+    S_COUNT
 };
 
 struct Plan {
@@ -230,6 +232,12 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     // per-row sums of the pointer heads' backward (pointer_bwd2): [B][h0] each, reduced over the rows afterwards;
     // 0: land dz*hid, 1: (free), 2: road dz*hid, 3: road dpre  (the land dpre sums are S_DCONST)
     for (int k = 0; k < 4; ++k) add(S_CSP0 + k, B * std::max(std::max(x.h0l, x.h0r), 16));
+    if (tiny_supported(d, mb.max_n, mb.max_inc)) {
+        const int G = tiny_groups((int)B);
+        add(S_TINY_SLAB, (int64_t)G * tiny_slab_stride(P));
+        add(S_TINY_SCR, (int64_t)G * tiny_scratch_stride(d, mb.max_inc));
+        add(S_TINY_LOSS, B * 4);
+    }
     // second dP|dQ buffer (layer l's weight gradient on the side stream may still read its own).  LAST slot of the plan on
     // purpose: whether it exists depends on a process-wide knob, and a knob change between a forward and its backward must not
     // move any other slot (it only changes the size the backward asks for, which check_args verifies)
@@ -640,6 +648,18 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     auto W = [&](int slot) { return ws + pl.off[slot]; };
     auto PR = [&](int idx) { return prm + P.off(idx); };
     Profiler *prof = &eng->prof;
+    // fused small-model path (tiny.hip): the whole forward of a graph in one workgroup, one launch for the minibatch
+    if (tiny_supported(d, mbp->max_n, mbp->max_inc)) {
+        TinyIO io;
+        memset(&io, 0, sizeof(io));
+        io.mode = 0;
+        io.value = value_dev; io.logp = logp_dev; io.ent = ent_dev;
+        io.z_he = W(S_Z_HE); io.z_rn = W(S_Z_RN);           // candidate logits for the action heads (upamd_ws_tensor)
+        const int began = prof_begin(prof, "tiny_fwd", st, 0.0, 0.0);
+        const int rc = launch_tiny(d, P, pk, mb, prm, io, st);
+        prof_end(prof, "tiny_fwd", st, began);
+        return rc;
+    }
     const float *Win = x.mlp ? prm : PR(P.inproj_w), *bin = x.mlp ? prm : PR(P.inproj_b);      // (unused by the rl-mlp encoder)
     const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
     const float *biq = bin, *biv = bin + 2 * D;
@@ -905,6 +925,19 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     auto PR = [&](int idx) { return prm + P.off(idx); };
     auto GR = [&](int idx) { return grads + P.off(idx); };
     Profiler *prof = &eng->prof;
+    if (tiny_supported(d, mbp->max_n, mbp->max_inc)) {
+        // fused small-model path: forward recomputed inside the kernel, backward from the given seeds, slabs -> grads (added)
+        TinyIO io;
+        memset(&io, 0, sizeof(io));
+        io.mode = 1;
+        io.dvalue = dvalue_dev; io.dlogp = dlogp_dev; io.dent = dent_dev;
+        io.slab = W(S_TINY_SLAB); io.scratch = W(S_TINY_SCR); io.loss_rows = W(S_TINY_LOSS);
+        io.grads = grads; io.accumulate = 1;
+        const int began = prof_begin(prof, "tiny_bwd", st, 0.0, 0.0);
+        const int rc = launch_tiny(d, P, pk, mb, prm, io, st);
+        prof_end(prof, "tiny_bwd", st, began);
+        return rc;
+    }
     const float *Win = x.mlp ? prm : PR(P.inproj_w);                                           // (unused by the rl-mlp encoder)
     const float *Wiq = Win, *Wik = Win + (int64_t)D * D, *Wiv = Win + 2LL * D * D;
     float *gWin = x.mlp ? grads : GR(P.inproj_w), *gbin = x.mlp ? grads : GR(P.inproj_b);
@@ -1344,4 +1377,43 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     CK(red2.add(W(S_DBVV), 1, 0, 1, D, 0, D, gbin + 2 * D, D));
     CK(red2.flush());
     return UPAMD_OK;
+}
+
+// =============================================================================================
+// fused optimizer-step front end of small models (tiny.hip)
+// =============================================================================================
+extern "C" int upamd_step_fused_ok(upamd_engine *eng, const upamd_minibatch *mb) {
+    if (!eng || !mb) return 0;
+    return tiny_supported(eng->d, mb->max_n, mb->max_inc) ? 1 : 0;
+}
+
+extern "C" int upamd_step_fused(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout, const upamd_minibatch *mbp,
+                                const float *prm, void *ws_dev, int64_t ws_bytes, const int64_t *rows_dev, const float *adv_dev,
+                                const float *ret_dev, const float *old_logp_dev, const float *exps_dev, float clip_eps, float cv,
+                                float ce, float inv_rows, float inv_ind, float *value_dev, float *logp_dev, float *ent_dev,
+                                float *grads_dev, float *losses_dev, void *stream) {
+    Plan pl;
+    CK(check_args(eng, packed_dev, layout, mbp, prm, ws_dev, ws_bytes, &pl));
+    if (!adv_dev || !ret_dev || !old_logp_dev || !exps_dev || !value_dev || !logp_dev || !ent_dev || !grads_dev || !losses_dev)
+        return fail(UPAMD_E_INVALID, "upamd_step_fused: null argument");
+    if (!tiny_supported(eng->d, mbp->max_n, mbp->max_inc))
+        return fail(UPAMD_E_INVALID, "upamd_step_fused: this model / minibatch is not covered by the fused small-model path "
+                                     "(ask upamd_step_fused_ok first and use upamd_forward / upamd_ppo_loss_rows / upamd_backward)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *ws = static_cast<float *>(ws_dev);
+    const PackedView pk = make_view(packed_dev, *layout);
+    const MbView mb = make_mb(*mbp);
+    TinyIO io;
+    memset(&io, 0, sizeof(io));
+    io.mode = 2;
+    io.value = value_dev; io.logp = logp_dev; io.ent = ent_dev;
+    io.rows = rows_dev; io.adv = adv_dev; io.ret = ret_dev; io.old_logp = old_logp_dev; io.exps = exps_dev;
+    io.clip_eps = clip_eps; io.cv = cv; io.ce = ce; io.inv_rows = inv_rows; io.inv_ind = inv_ind;
+    io.slab = ws + pl.off[S_TINY_SLAB]; io.scratch = ws + pl.off[S_TINY_SCR]; io.loss_rows = ws + pl.off[S_TINY_LOSS];
+    io.grads = grads_dev; io.accumulate = 0; io.losses = losses_dev;
+    Profiler *prof = &eng->prof;
+    const int began = prof_begin(prof, "tiny_step", st, 0.0, 0.0);
+    const int rc = launch_tiny(eng->d, eng->P, pk, mb, prm, io, st);
+    prof_end(prof, "tiny_step", st, began);
+    return rc;
 }

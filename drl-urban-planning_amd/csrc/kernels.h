@@ -300,4 +300,26 @@ int launch_adam_groups(int n_groups, const int64_t *begin, const int64_t *end, c
 int launch_sumsq(const float *x, int64_t n, float *scratch, float *out_accum, hipStream_t st);
 int launch_clip_scale(float *g, int64_t n, const float *sumsq, float max_norm, hipStream_t st);
 
+// ---- tiny.hip: fused small-model path (D <= 32; one workgroup per graph, the whole network out of LDS) --------------------
+struct TinyIO {
+    int mode;                                   // 0 forward, 1 backward from seeds (forward recomputed), 2 forward + PPO loss + backward
+    float *value, *logp, *ent, *z_he, *z_rn;
+    const float *dvalue, *dlogp, *dent;
+    const int64_t *rows;
+    const float *adv, *ret, *old_logp, *exps;
+    float clip_eps, cv, ce, inv_rows, inv_ind;
+    float *loss_rows, *slab, *scratch;          // workspace: [B][4], [groups][slab_stride], [groups][scratch_stride]
+    float *grads;                               // flat gradient buffer (accumulate != 0: added to, else overwritten)
+    int accumulate;
+    float *losses;                              // mode 2: the four loss scalars
+};
+void set_tiny_fused(int on);                    // tune knob "tiny_fused" (default on)
+void set_tiny_threads(int n);                   // tune knob "tiny_threads": 1024 (default) | 512 threads per workgroup
+bool tiny_supported(const upamd_model_desc &d, int max_n, int max_inc);
+int tiny_groups(int B);
+int64_t tiny_scratch_stride(const upamd_model_desc &d, int max_inc);
+int64_t tiny_slab_stride(const ParamLayout &P);
+int launch_tiny(const upamd_model_desc &d, const ParamLayout &P, const PackedView &pk, const MbView &mb, const float *prm,
+                const TinyIO &io, hipStream_t st);
+
 }  // namespace upamd

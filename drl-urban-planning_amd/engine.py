@@ -37,7 +37,9 @@ class NativeEngine:
         self.ws_slots = {}        # scratch workspaces; slot > 0 = concurrent sub-batches on side streams
         # The native entry points are not re-entrant (per-stream side contexts, profiler tables, the slot workspaces):
         # host threads that share one engine -- a rollout.ActionServer thread next to the learner -- are serialised
-        # here.  Only the ENQUEUE is under the lock; the kernels of two callers still overlap on their streams.
+        # here.  EVERY method that calls into the library takes the lock (forward / backward, the PPO-math launches,
+        # workspace read-backs, the profiler).  Only the ENQUEUE is under it; the kernels of two callers still overlap
+        # on their streams.
         self.lock = threading.RLock()
 
     def _st(self):
@@ -135,19 +137,40 @@ class NativeEngine:
             self.ws_slots.pop(slot, None)
 
     def backward(self, packed, mb, flat_params, dvalue, dlogp, dent, grads, slot=0, ws=None):
-        wsp, wsb, _ = self._ws_args(slot, ws)
         with self.lock, self._on_device():
+            wsp, wsb, _ = self._ws_args(slot, ws)
             native.check(self.lib.upamd_backward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
                                                  _ptr(flat_params), wsp, wsb, _ptr(dvalue), _ptr(dlogp), _ptr(dent),
                                                  _ptr(grads), self._st()), 'upamd_backward')
 
+    # ---- fused optimizer-step front end of small models (csrc/tiny.hip)
+    def step_fused_ok(self, mb):
+        """True when forward + PPO loss + backward of this minibatch run as ONE launch (gcn_node_dim <= 32, graphs that fit
+        a workgroup's LDS): `step_fused` then replaces forward / ppo_loss_rows / backward."""
+        return bool(self.lib.upamd_step_fused_ok(self.handle, C.byref(mb)))
+
+    def step_fused(self, packed, mb, flat_params, rows, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind, value,
+                   logp, ent, grads, losses, slot=0):
+        """forward + loss seeds + backward; `grads` (flat, n_floats) is overwritten, `losses` (4) gets the loss scalars"""
+        assert rows is None or (rows.dtype == torch.int64 and rows.is_contiguous())
+        with self.lock:
+            self.ensure_workspace(mb, slot)
+            wsp, wsb, _ = self._ws_args(slot, None)
+            with self._on_device():
+                native.check(self.lib.upamd_step_fused(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
+                                                       _ptr(flat_params), wsp, wsb, _ptr(rows), _ptr(adv), _ptr(ret),
+                                                       _ptr(old_logp), _ptr(exps), clip_eps, cv, ce, inv_rows, inv_ind,
+                                                       _ptr(value), _ptr(logp), _ptr(ent), _ptr(grads), _ptr(losses),
+                                                       self._st()), 'upamd_step_fused')
+
     def ws_tensor(self, mb, name, slot=0, ws=None):
         """Row-major copy of a named intermediate of the last forward on that workspace (parity tests, action heads)."""
         off, rows, cols, kind = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
-        native.check(self.lib.upamd_ws_tensor(self.handle, C.byref(mb), name.encode(), C.byref(off), C.byref(rows),
-                                              C.byref(cols), C.byref(kind)), 'upamd_ws_tensor')
-        _, _, shift = self._ws_args(slot, ws)
-        buf = self.ws_slots[slot] if ws is None else ws
+        with self.lock:
+            native.check(self.lib.upamd_ws_tensor(self.handle, C.byref(mb), name.encode(), C.byref(off), C.byref(rows),
+                                                  C.byref(cols), C.byref(kind)), 'upamd_ws_tensor')
+            _, _, shift = self._ws_args(slot, ws)
+            buf = self.ws_slots[slot] if ws is None else ws
         n = rows.value * cols.value
         raw = buf[shift + off.value: shift + off.value + 4 * n].view(torch.float32)
         if kind.value == 1:
@@ -157,7 +180,7 @@ class NativeEngine:
     # ---- PPO math
     def ppo_loss(self, B, value, logp, ent, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind, dvalue,
                  dlogp, dent, losses):
-        with self._on_device():
+        with self.lock, self._on_device():
             native.check(self.lib.upamd_ppo_loss(B, _ptr(value), _ptr(logp), _ptr(ent), _ptr(adv), _ptr(ret),
                                                  _ptr(old_logp), _ptr(exps), clip_eps, cv, ce, inv_rows, inv_ind,
                                                  _ptr(dvalue), _ptr(dlogp), _ptr(dent), _ptr(losses), self._st()),
@@ -167,7 +190,7 @@ class NativeEngine:
                       dvalue, dlogp, dent, losses, zero=None):
         """loss of the minibatch whose replay rows are `rows` (int64, device) + zeroing of `zero` in the same launch"""
         assert rows.dtype == torch.int64 and rows.is_contiguous()
-        with self._on_device():
+        with self.lock, self._on_device():
             native.check(self.lib.upamd_ppo_loss_rows(B, _ptr(value), _ptr(logp), _ptr(ent), _ptr(rows), _ptr(adv),
                                                       _ptr(ret), _ptr(old_logp), _ptr(exps), clip_eps, cv, ce, inv_rows,
                                                       inv_ind, _ptr(dvalue), _ptr(dlogp), _ptr(dent), _ptr(losses),
@@ -176,18 +199,18 @@ class NativeEngine:
                          'upamd_ppo_loss_rows')
 
     def gae(self, rewards, masks, values, gamma, tau, adv, ret):
-        with self._on_device():
+        with self.lock, self._on_device():
             native.check(self.lib.upamd_gae(rewards.numel(), _ptr(rewards), _ptr(masks), _ptr(values), float(gamma),
                                             float(tau), _ptr(adv), _ptr(ret), self._st()), 'upamd_gae')
 
     def clip_first_step(self, grads, max_norm, scratch):
-        with self._on_device():
+        with self.lock, self._on_device():
             native.check(self.lib.upamd_clip_first_step(C.byref(self.desc), _ptr(grads), float(max_norm), _ptr(scratch),
                                                         self._st()), 'upamd_clip_first_step')
 
     def adam_step(self, group, params, grads, m, v, step, lr, beta1, beta2, eps, weight_decay):
         b, e = self.groups[group]
-        with self._on_device():
+        with self.lock, self._on_device():
             native.check(self.lib.upamd_adam_step(b, e, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), int(step),
                                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                                   self._st()), 'upamd_adam_step')
@@ -198,7 +221,7 @@ class NativeEngine:
         b = (C.c_int64 * n)(*[g[0] for g in self.groups])
         e = (C.c_int64 * n)(*[g[1] for g in self.groups])
         st = (C.c_int32 * n)(*[int(x) for x in steps])
-        with self._on_device():
+        with self.lock, self._on_device():
             native.check(self.lib.upamd_adam_groups(n, b, e, st, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), float(lr),
                                                     float(beta1), float(beta2), float(eps), float(weight_decay),
                                                     _ptr(loss_src) if loss_src is not None else None,
@@ -207,13 +230,16 @@ class NativeEngine:
 
     # ---- profiling
     def profile(self, on):
-        native.check(self.lib.upamd_profile_enable(self.handle, 1 if on else 0), 'upamd_profile_enable')
+        with self.lock:
+            native.check(self.lib.upamd_profile_enable(self.handle, 1 if on else 0), 'upamd_profile_enable')
 
     def profile_reset(self):
-        native.check(self.lib.upamd_profile_reset(self.handle), 'upamd_profile_reset')
+        with self.lock:
+            native.check(self.lib.upamd_profile_reset(self.handle), 'upamd_profile_reset')
 
     def profile_read(self, name):
         n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-        native.check(self.lib.upamd_profile_read(self.handle, name.encode(), C.byref(n), C.byref(ms), C.byref(fl),
-                                                 C.byref(by)), 'upamd_profile_read')
+        with self.lock:
+            native.check(self.lib.upamd_profile_read(self.handle, name.encode(), C.byref(n), C.byref(ms), C.byref(fl),
+                                                     C.byref(by)), 'upamd_profile_read')
         return dict(launches=n.value, total_ms=ms.value, flops=fl.value, bytes=by.value)

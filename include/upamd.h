@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define UPAMD_ABI_VERSION 4
+#define UPAMD_ABI_VERSION 5
 
 #define UPAMD_OK 0
 #define UPAMD_E_INVALID (-1)   /* bad argument / unsupported configuration            */
@@ -191,6 +191,20 @@ int upamd_backward(upamd_engine *eng, const void *packed_dev, const upamd_pack_l
                    const float *dvalue_dev, const float *dlogp_dev, const float *dent_dev,
                    float *grads_dev, void *stream);
 
+/* Small models (gcn_node_dim <= 32 -- the dims of every shipped YAML, hlg.yaml:21-33 -- single-Linear edge MLPs, graphs that fit one
+ * workgroup's LDS): ONE launch runs forward + PPO loss seeds + backward of the whole minibatch, one workgroup per graph, and a second
+ * one adds the per-workgroup gradient slabs in a fixed order.  Replaces the upamd_forward / upamd_ppo_loss_rows / upamd_backward
+ * sequence of one optimizer step (urban_planning_agent.py:326-337) for such models -- same arguments, same results (same tolerances
+ * against the reference), `grads_dev` is OVERWRITTEN (no zero_grad needed), `losses_dev` gets the four loss scalars.
+ * upamd_step_fused_ok returns 1 when the engine's model and this minibatch are covered (upamd_forward / upamd_backward then take the
+ * fused kernels too, and upamd_ws_tensor only serves "z_he" / "z_rn"), else 0. */
+int upamd_step_fused_ok(upamd_engine *eng, const upamd_minibatch *mb);
+int upamd_step_fused(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout, const upamd_minibatch *mb,
+                     const float *params_dev, void *ws_dev, int64_t ws_bytes, const int64_t *rows_dev, const float *adv_dev,
+                     const float *ret_dev, const float *old_logp_dev, const float *exps_dev, float clip_eps, float cv, float ce,
+                     float inv_rows, float inv_ind, float *value_dev, float *logp_dev, float *ent_dev, float *grads_dev,
+                     float *losses_dev, void *stream);
+
 /* byte offset / shape of a named intermediate inside ws after upamd_forward(keep=1) -- for the
  * stage-by-stage parity tests.  kind: 0 = row-major [rows][cols], 1 = panel-major [cols/16][rows][16]. */
 int upamd_ws_tensor(upamd_engine *eng, const upamd_minibatch *mb, const char *name, int64_t *byte_offset,
@@ -290,6 +304,8 @@ int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev
  *   "bwd_nb_global" [1] backward of graphs too big for two workgroups per CU walks the neighbour ids from global memory
  *   "fold_layer1" = 2   fold only where every graph of the minibatch fits half the LDS
  *   "nt_min_wgs"  [128] workgroups a gemm_nt launch must have before the 128-wide N tile is used (tests: 1)
+ *   "tiny_fused"  [1]   models with D <= 32 run the fused one-workgroup-per-graph kernels (tiny.hip); 0 = the general path
+ *   "tiny_threads" [1024] threads per workgroup of the fused small-model kernels (1024 | 512)
  *   "side_heads"  [1]   land-use pointer-head chain (forward: first Linear; backward: softmax / feature / weight-gradient kernels) on the side stream
  *   "side_wgrad"  [1]   GCN weight-gradient GEMMs on a second side stream: 1 = for minibatches of <= 98304 nodes, 0 never, 2 behind the
  *                       layer's dgrad GEMM, 3 always

@@ -68,7 +68,7 @@ def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
 def tune():
     """set native tune knobs for one test; every knob is put back to its default afterwards"""
     from drl_urban_planning_amd import native
-    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1, 'pq_exp': 1, 'nt_min_wgs': 128, 'bwd_nb_global': 1, 'side_heads': 1, 'side_wgrad': 1}
+    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1, 'pq_exp': 1, 'nt_min_wgs': 128, 'bwd_nb_global': 1, 'side_heads': 1, 'side_wgrad': 1, 'tiny_fused': 1, 'tiny_threads': 1024}
     touched = []
 
     def _set(name, value):
@@ -80,9 +80,19 @@ def tune():
         native.check(native.lib().upamd_tune(name.encode(), defaults[name]), 'upamd_tune')
 
 
+@pytest.fixture(params=['fused', 'general'])
+def small_path(request, tune):
+    """Models with gcn_node_dim <= 32 run the fused one-workgroup-per-graph kernels (csrc/tiny.hip) by default; the general
+    kernels remain the path of larger graphs / one-layer models / deep edge MLPs at those dims: tests of small models
+    run on both."""
+    tune('tiny_fused', 1 if request.param == 'fused' else 0)
+    return request.param
+
+
 @pytest.mark.parametrize('fold', [1, 0])
 @pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c'])
 def test_forward_stages_match_oracle(name, fold, tune):
+    tune('tiny_fused', 0)          # (the stage tensors of the GENERAL path; the fused kernels keep theirs in LDS)
     # fold = 1 (default): the first GCN layer is computed inside the message-passing kernels, H0 / PQ1 never exist in
     # HBM (asking for them fails); fold = 0: two K = 32 GEMMs materialise them
     tune('fold_layer1', fold)
@@ -126,7 +136,9 @@ def test_forward_stages_match_oracle(name, fold, tune):
 
 @pytest.mark.parametrize('fold', [1, 0])
 @pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c'])
-def test_loss_and_gradients_match_reference(name, fold, tune):
+def test_loss_and_gradients_match_reference(name, fold, tune, small_path):
+    if small_path == 'fused' and fold == 0:
+        pytest.skip('fold_layer1 is a knob of the general path')
     tune('fold_layer1', fold)
     from test_oracle_golden import CASE_HYPER
     z, sd, states = helpers.load_case(name)
@@ -159,7 +171,7 @@ def test_loss_and_gradients_match_reference(name, fold, tune):
 
 
 @pytest.mark.parametrize('name', ['case_a', 'case_c'])
-def test_module_surface_autograd(name):
+def test_module_surface_autograd(name, small_path):
     """The reference's own call pattern: value_net(x), policy_net.get_log_prob_entropy(x, a), loss.backward()."""
     from test_oracle_golden import CASE_HYPER
     z, sd, states = helpers.load_case(name)
@@ -218,7 +230,7 @@ def test_gae_bit_exact(name):
 
 
 @pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c'])
-def test_update_params_matches_reference(name):
+def test_update_params_matches_reference(name, small_path):
     """The whole update_params (two calls): loss curve within 1e-4 rel per step, parameters rel-L2 <= 1e-4,
     loss_iter bookkeeping, TB scalar tags; clipping active on the very first step only."""
     from drl_urban_planning_amd import PPOUpdater, synth
@@ -485,7 +497,7 @@ def _check_against_oracle(cfg, sd, replay, heads, T, tol=1e-4):
                  rtol_l2=tol)
 
 
-def test_degenerate_rows_match_reference_semantics():
+def test_degenerate_rows_match_reference_semantics(small_path):
     """A row without any valid candidate (all logits = the pad constant: in fp32 the reference's normalised
     logits are all 0, policy.py:50-52), a row whose stored action points at a masked slot, a stage-2 row."""
     from drl_urban_planning_amd import synth
@@ -655,7 +667,7 @@ def test_native_failure_modes():
 
 
 @pytest.mark.parametrize('seed', list(range(10)))
-def test_random_small_configurations(seed):
+def test_random_small_configurations(seed, small_path):
     """Fuzz over model shapes and graph sizes (tiny graphs below one 8-node chunk, one-layer models, several heads,
     road-only and land-only minibatches): forward values, losses and every gradient against the oracle."""
     rng = np.random.default_rng(1000 + seed)

@@ -1,0 +1,202 @@
+"""The fused small-model program (csrc/tiny_body.h) on the CPU, against the reference-generated goldens and the oracle.
+
+``tests/emul/tiny_emul.cpp`` compiles the SAME per-graph program the HIP kernel is built from (g++, ``TINY_HOST``) and runs
+one "workgroup" per graph with its parallel ranges executed sequentially.  What that pins without a GPU: the forward math,
+the loss seeds and the complete hand-derived backward (every parameter gradient), the LDS plan (every graph runs on a
+NaN-poisoned image, so a read of something it did not write shows up), the slab accumulation over several graphs per
+workgroup.  What it cannot see -- a missing barrier, a cross-iteration race -- is what the GPU parity tests are for.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import sgnn_oracle as orc
+from test_oracle_golden import CASE_HYPER
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MAXMLP, MAXL = 4, 16
+
+
+class Dims(C.Structure):
+    _fields_ = [('D', C.c_int), ('L', C.c_int), ('heads', C.c_int), ('F', C.c_int), ('Fn', C.c_int), ('n_num', C.c_int),
+                ('num_hidden', C.c_int * MAXMLP), ('n_value', C.c_int), ('value_hidden', C.c_int * MAXMLP), ('h0l', C.c_int),
+                ('h0r', C.c_int), ('S_last', C.c_int), ('W', C.c_int)]
+
+
+class Offs(C.Structure):
+    _fields_ = [('num_w', C.c_int * MAXMLP), ('num_b', C.c_int * MAXMLP), ('node_w', C.c_int), ('node_b', C.c_int),
+                ('edge_w', C.c_int * MAXL), ('edge_b', C.c_int * MAXL), ('inproj_w', C.c_int), ('inproj_b', C.c_int),
+                ('outproj_w', C.c_int), ('outproj_b', C.c_int), ('q_w', C.c_int), ('q_b', C.c_int), ('k_w', C.c_int),
+                ('k_b', C.c_int), ('v_w', C.c_int), ('v_b', C.c_int), ('value_w', C.c_int * MAXMLP),
+                ('value_b', C.c_int * MAXMLP), ('land_w0', C.c_int), ('land_b0', C.c_int), ('land_w1', C.c_int),
+                ('road_w0', C.c_int), ('road_b0', C.c_int), ('road_w1', C.c_int), ('n_floats', C.c_int)]
+
+
+@pytest.fixture(scope='module')
+def emul(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp('emul') / 'tiny_emul.so')
+    res = subprocess.run(['g++', '-O1', '-std=c++17', '-shared', '-fPIC', '-Wno-unknown-pragmas',
+                          os.path.join(ROOT, 'tests', 'emul', 'tiny_emul.cpp'), '-o', out], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    lib = C.CDLL(out)
+    assert lib.tiny_emul_sizeof_dims() == C.sizeof(Dims) and lib.tiny_emul_sizeof_offs() == C.sizeof(Offs)
+    return lib
+
+
+def _setup(cfg, sd):
+    """flat parameters + the (Dims, Offs) the engine derives from the model description, built from the C ABI's table"""
+    from drl_urban_planning_amd import native
+    from drl_urban_planning_amd.models import backend_of
+    policy_net, value_net, ac = helpers.build_product(cfg)
+    ac.load_state_dict(sd)
+    backend = backend_of(policy_net)
+    desc = backend.desc()
+    table, n_floats, _ = native.param_table(desc)
+    named = backend.named_params()
+    flat = np.zeros(n_floats, dtype=np.float32)
+    off_of = {}
+    for name, off, rows, cols, _ in table:
+        flat[off:off + rows * cols] = named[name].detach().numpy().reshape(-1)
+        off_of[name] = off
+    se, ps, vs = cfg.state_encoder_specs, cfg.policy_specs, cfg.value_specs
+    d = Dims()
+    d.D, d.L, d.heads, d.F, d.Fn = se['gcn_node_dim'], se['num_gcn_layers'], se['num_attention_heads'], 23, 52
+    S = se['state_encoder_hidden_size']
+    d.n_num = len(S)
+    for i, h in enumerate(S):
+        d.num_hidden[i] = h
+    vh = vs['value_head_hidden_size']
+    d.n_value = len(vh)
+    for i, h in enumerate(vh):
+        d.value_hidden[i] = h
+    d.h0l, d.h0r = ps['policy_land_use_head_hidden_size'][0], ps['policy_road_head_hidden_size'][0]
+    d.S_last, d.W = S[-1], 3 * d.D + S[-1] + 3
+    o = Offs()
+    e = 'shared_net.'
+    for i in range(d.n_num):
+        o.num_w[i] = off_of[e + 'numerical_feature_encoder.linear_%d.weight' % i]
+        o.num_b[i] = off_of[e + 'numerical_feature_encoder.linear_%d.bias' % i]
+    o.node_w, o.node_b = off_of[e + 'node_encoder.weight'], off_of[e + 'node_encoder.bias']
+    for l in range(d.L):
+        o.edge_w[l] = off_of[e + 'edge_fc_layers.%d.linear_0.weight' % l]
+        o.edge_b[l] = off_of[e + 'edge_fc_layers.%d.linear_0.bias' % l]
+    o.inproj_w, o.inproj_b = off_of[e + 'attention_layer.in_proj_weight'], off_of[e + 'attention_layer.in_proj_bias']
+    o.outproj_w, o.outproj_b = off_of[e + 'attention_layer.out_proj.weight'], off_of[e + 'attention_layer.out_proj.bias']
+    for nm in 'qkv':
+        full = dict(q='query', k='key', v='value')[nm]
+        setattr(o, nm + '_w', off_of[e + 'attention_%s_layer.weight' % full])
+        setattr(o, nm + '_b', off_of[e + 'attention_%s_layer.bias' % full])
+    for i in range(d.n_value):
+        o.value_w[i], o.value_b[i] = off_of['value_head.linear_%d.weight' % i], off_of['value_head.linear_%d.bias' % i]
+    o.land_w0 = off_of['policy_land_use_head.land_use_linear_0.weight']
+    o.land_b0 = off_of['policy_land_use_head.land_use_linear_0.bias']
+    o.land_w1 = off_of['policy_land_use_head.land_use_linear_1.weight']
+    o.road_w0 = off_of['policy_road_head.road_linear_0.weight']
+    o.road_b0 = off_of['policy_road_head.road_linear_0.bias']
+    o.road_w1 = off_of['policy_road_head.road_linear_1.weight']
+    o.n_floats = n_floats
+    return flat, d, o, table
+
+
+def run_emul(lib, cfg, sd, states, actions, mode, groups=None, seeds=None, step=None):
+    from drl_urban_planning_amd import packer
+    flat, d, o, table = _setup(cfg, sd)
+    pk = packer.pack_replay(states, np.asarray(actions), 23, 52, pin=False)
+    B = len(states)
+    meta = pk.meta
+    idx = np.arange(B, dtype=np.int32)
+    he_off = np.concatenate([[0], np.cumsum(meta[:, 2])]).astype(np.int32)
+    rn_off = np.concatenate([[0], np.cumsum(meta[:, 3])]).astype(np.int32)
+    max_n, max_inc = int(meta[:, 0].max()), int(2 * meta[:, 1].max())
+    f32 = lambda n: np.zeros(max(int(n), 1), dtype=np.float32)
+    value, logp, ent, z_he, z_rn = f32(B), f32(B), f32(B), f32(he_off[-1]), f32(rn_off[-1])
+    grads, losses = f32(o.n_floats), f32(4)
+    P = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    dv = dl = de = adv = ret = old = exps = None
+    hy = dict(clip=0.0, cv=0.0, ce=0.0, inv_rows=0.0, inv_ind=0.0)
+    if seeds is not None:
+        dv, dl, de = (np.ascontiguousarray(s, dtype=np.float32) for s in seeds)
+    if step is not None:
+        adv, ret, old, exps = (np.ascontiguousarray(step[k], dtype=np.float32) for k in ('adv', 'ret', 'old_logp', 'exps'))
+        hy = step
+    lds = C.c_int64()
+    buf = pk.host_buf.numpy()
+    rc = lib.tiny_emul_run(P(buf), C.byref(pk.layout), B, P(idx), P(he_off), P(rn_off), max_n, max_inc, C.byref(d), C.byref(o),
+                           P(flat), mode, groups or B, P(value), P(logp), P(ent), P(z_he), P(z_rn), P(dv), P(dl), P(de), None,
+                           P(adv), P(ret), P(old), P(exps), C.c_float(hy['clip']), C.c_float(hy['cv']), C.c_float(hy['ce']),
+                           C.c_float(hy['inv_rows']), C.c_float(hy['inv_ind']), P(grads), P(losses), C.byref(lds))
+    assert rc == 0
+    return dict(value=value, logp=logp, ent=ent, grads=grads, losses=losses, table=table, lds_bytes=lds.value, z_he=z_he,
+                z_rn=z_rn, meta=meta)
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def check_grads(out, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
+    refs = {name: ref_of(name) for name, *_ in out['table']}
+    scale = max(max(float(np.abs(r).max()) for r in refs.values()), 1e-12)
+    bad, report = [], []
+    for name, off, rows, cols, _ in out['table']:
+        mine = out['grads'][off:off + rows * cols].reshape(refs[name].shape)
+        err, rl2 = float(np.abs(mine - refs[name]).max()), _rel_l2(mine, refs[name])
+        report.append('%-62s max|d|=%.3e relL2=%.3e |ref|max=%.3e' % (name, err, rl2, float(np.abs(refs[name]).max())))
+        if (err > atol_scale * scale and rl2 > rtol_l2) or err > 50 * atol_scale * scale or not np.isfinite(mine).all():
+            bad.append(name)
+    assert not bad, 'gradient mismatch in %s\n%s' % (bad, '\n'.join(report))
+
+
+@pytest.mark.parametrize('name', ['case_a', 'case_b', 'case_c', 'case_s'])
+def test_emulated_program_matches_the_reference_goldens(emul, name):
+    """forward rows, the four loss terms and every parameter gradient of the golden minibatch (generated by the REAL reference),
+    through the STEP mode (loss seeds computed inside the program), one graph per workgroup and several per workgroup"""
+    z, sd, states = helpers.load_case(name)
+    cfg = helpers.make_cfg(**helpers.CASE_MODEL[name])
+    hy = CASE_HYPER[name]
+    B = z['fwd/value'].shape[0]
+    nind = int((z['exps'][:B] != 0).sum())
+    step = dict(adv=z['mb/adv'][:, 0], ret=z['mb/ret'][:, 0], old_logp=z['mb/old_logp'][:, 0], exps=z['exps'][:B],
+                clip=hy['clip_epsilon'], cv=hy['value_pred_coef'], ce=hy['entropy_coef'], inv_rows=1.0 / B, inv_ind=1.0 / nind)
+    for groups in (B, 3):
+        out = run_emul(emul, cfg, sd, states[:B], z['actions'][:B], 2, groups=groups, step=step)
+        np.testing.assert_allclose(out['value'], z['fwd/value'][:, 0], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out['logp'], z['fwd/logp'][:, 0], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out['ent'], z['fwd/entropy'][:, 0], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out['losses'], z['mb/losses'], rtol=2e-5, atol=2e-6)
+        check_grads(out, lambda nm: z[helpers.golden_key('grad/', nm)])
+
+
+def test_backward_from_given_seeds_and_reference_dims(emul):
+    """BWD mode (seeds handed in, as the module surface's autograd does) on HLG-sized graphs at the reference YAML dims,
+    against the oracle's autograd; the LDS plan of that size fits one workgroup per CU."""
+    from drl_urban_planning_amd import synth
+    cfg = helpers.make_cfg(D=16, L=2, max_nodes=360, max_edges=2000)
+    policy_net, value_net, ac = helpers.build_product(cfg, seed=3)
+    sd = helpers.perturbed_state_dict(ac, seed=5)
+    rep = synth.make_replay(6, 'hlg', max_nodes=360, max_edges=2000, seed=21, road_fraction=0.34)
+    B = len(rep.states)
+    g = np.random.default_rng(2)
+    seeds = [g.standard_normal(B).astype(np.float32) for _ in range(3)]
+    fwd = run_emul(emul, cfg, sd, rep.states, rep.actions, 0)
+    out = run_emul(emul, cfg, sd, rep.states, rep.actions, 1, groups=4, seeds=seeds)
+    assert out['lds_bytes'] <= 160 * 1024 - 512, out['lds_bytes']
+    P = helpers.oracle_params(sd)
+    xs = orc.tensorfy(rep.states)
+    value = orc.value_forward(P, xs, 1)
+    logp, ent = orc.get_log_prob_entropy(P, xs, torch.from_numpy(np.asarray(rep.actions, dtype=np.float32)), 1)
+    np.testing.assert_allclose(fwd['value'], value.detach().numpy().reshape(-1), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(fwd['logp'], logp.detach().numpy().reshape(-1), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(fwd['ent'], ent.detach().numpy().reshape(-1), rtol=1e-4, atol=1e-5)
+    loss = (value.reshape(-1) * torch.from_numpy(seeds[0])).sum() + (logp.reshape(-1) * torch.from_numpy(seeds[1])).sum() + \
+        (ent.reshape(-1) * torch.from_numpy(seeds[2])).sum()
+    loss.backward()
+    ref = {k: (p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)) for k, p in P.items()}
+    check_grads(out, lambda nm: ref[nm], atol_scale=2e-5, rtol_l2=2e-4)
+    # candidate logits in minibatch order (what the action heads read back)
+    assert np.isfinite(fwd['z_he']).all() and np.isfinite(fwd['z_rn']).all()
