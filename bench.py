@@ -44,6 +44,8 @@ WORKLOADS = {
     # BASELINE.json configs[0]: "synthetic grid community, PPO batch 256, policy hidden 64 -- reference CPU path": the
     # reference YAML dims (grid.yaml:21-33), grid-sized graphs, land-use / road rows mixed (grid.yaml:16-18), pads 1000/3000
     'grid_ref': dict(community='grid', D=16, L=2, B=256, T=2560, unique=1024, max_nodes=1000, max_edges=3000, road_fraction=0.5),
+    # BASELINE.json configs[3], per-GPU share: HLG graphs with the concept pads 1500 / 4000 (hlg_concept.yaml:27-28), 2048 rows per GPU
+    'hlg_concept_d256': dict(community='hlg', D=256, L=3, B=2048, T=16384, unique=1024, max_nodes=1500, max_edges=4000),
     # BASELINE.json configs[2]
     'dhm_d256': dict(community='dhm', D=256, L=3, B=4096, T=32768, unique=1024, max_nodes=1000, max_edges=3000),
     # BASELINE.json configs[4], per-GPU share: heterogeneous HLG + DHM graphs in one minibatch (2048 rows per GPU)
@@ -152,6 +154,28 @@ def cpu_baseline(w, mode='quick'):
                           [(r['threads'], r['rows_per_step']) for r in padded]),
                 ms_per_step=best['ms_per_step'], host_cpus=ncpu, one_thread=rows[0]['samples_per_s'],
                 tight_pad=tight['samples_per_s'], rows=rows)
+
+
+def pmc_figure(fname, args, pick):
+    """(value, reason): a figure of a committed PMC summary (profiles/<fname>; the counters need their own rocprofv3 passes,
+    --pmc with --kernel-trace only, so bench.py cannot measure them in its own run).  The summaries are stamped with the hash
+    of the native sources they were collected on: a figure is only reported for the default workload AND when that hash is
+    the one of the sources this run was built from -- otherwise null with the reason."""
+    if args.workload != 'hlg_d256' or args.minibatch:
+        return None, 'PMC passes are only collected for the default workload (hlg_d256, full minibatch)'
+    root = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(root, 'profiles', fname)
+    if not os.path.exists(path):
+        return None, 'profiles/%s is absent' % fname
+    with open(path) as fh:
+        doc = json.load(fh)
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    from csrc_hash import csrc_hash
+    have, want = doc.get('csrc_hash'), csrc_hash(root)
+    if have != want:
+        return None, 'profiles/%s was collected on csrc %s, this build is %s: re-run the PMC passes (tools/pmc_*.py)' % (fname, have, want)
+    v = pick(doc)
+    return v, (None if v is not None else 'kernel not in profiles/%s' % fname)
 
 
 def main():
@@ -309,6 +333,7 @@ def main():
         'metric': 'PPO-update samples/sec', 'value': value, 'unit': 'samples/s', 'n_gpus': ctx.world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
         'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'node_steps_per_s': value * nodes_per_sample,      # graph-nodes x steps / s: what makes HLG / DHM / mixed lines comparable
         'config': {'workload': '%s: %s-shaped graphs (n~%.0f nodes, e~%.0f edges live; pads %d/%d), SGNN %d layers x %d, '
                                'PPO minibatch %d per GPU, replay %d states resident in HBM'
                                % (args.workload, w['community'].upper(), nodes_per_sample, edges_per_sample, w['max_nodes'],
@@ -350,15 +375,11 @@ def main():
         # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (FETCH_SIZE / WRITE_SIZE,
         # --kernel-trace only), so the figure is read from the committed summary of those passes over this same
         # command (tools/pmc_traffic.py -> profiles/pmc_traffic.json); null when that file is absent
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
-        if args.workload == 'hlg_d256' and not args.minibatch and os.path.exists(pmc):
-            with open(pmc) as fh:
-                k = json.load(fh).get('kernels', {}).get(dom)
-            if k:
-                out['roofline']['traffic'] = k['hbm_bytes_per_launch']
-                out['roofline']['traffic_source'] = ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + '
-                                                     'WRITE_SIZE, separate passes over bench.py, averaged over %d launches'
-                                                     % k['launches'])
+        out['roofline']['traffic'], out['roofline']['traffic_reason'] = pmc_figure(
+            'pmc_traffic.json', args, lambda doc: (doc.get('kernels', {}).get(dom) or {}).get('hbm_bytes_per_launch'))
+        if out['roofline']['traffic'] is not None:
+            out['roofline']['traffic_source'] = ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, '
+                                                 'separate passes over bench.py, stamped with the hash of csrc/ it was taken on')
         out['kernel_ms_per_step'] = {k: v['total_ms'] / args.steps for k, v in kern.items()}
     if 'edge_fwd' in kern and 'edge_bwd' in kern:
         # the message-passing group (6 launches per step at L = 3): second-largest share of the step, no MFMA work to speak of.
@@ -375,11 +396,10 @@ def main():
         mp = {'kernels': 'edge_fwd + edge_bwd', 'ms_per_step': ms, 'share_of_step': ms / out['ms_per_step'],
               'algorithmic_bytes_per_step': fwd + bwd, 'achieved': (fwd + bwd) / (ms * 1e-3) / 1e9, 'unit': 'GB/s',
               'peak': 8000.0, 'frac_of_hbm_peak': (fwd + bwd) / (ms * 1e-3) / 8e12, 'bound': 'valu', 'valu_busy': None}
-        util = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_util.json')
-        if args.workload == 'hlg_d256' and not args.minibatch and os.path.exists(util):
-            with open(util) as fh:
-                u = json.load(fh).get('kernels', {})
-            mp['valu_busy'] = {k: u[k]['valu_busy'] for k in u if k.startswith('edge_')}
+        mp['valu_busy'], mp['valu_busy_reason'] = pmc_figure(
+            'pmc_util.json', args,
+            lambda doc: {k: u['valu_busy'] for k, u in doc.get('kernels', {}).items() if k.startswith('edge_')} or None)
+        if mp['valu_busy'] is not None:
             mp['valu_busy_source'] = 'profiles/pmc_util.json: rocprofv3 --pmc SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE, one pass over bench.py'
         out['message_passing'] = mp
     if ctx.world == 1 and not args.no_cpu_baseline and args.cpu_baseline != 'off':

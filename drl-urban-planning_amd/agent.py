@@ -281,11 +281,8 @@ class PPOUpdater:
         rows_glob, ind_glob, land_glob, road_glob = counts
         sched = packer.Schedule(it.packed, row_lists, dev) if nb else None
         flat_rows = (np.concatenate(row_lists) if nb else np.zeros(0)).astype(np.int64)
-        host_rows = torch.from_numpy(np.ascontiguousarray(flat_rows)).pin_memory()
-        order_dev = host_rows.to(dev, non_blocking=True)
-        ep = Epoch(sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob)
-        ep._host_rows = host_rows            # (kept until the asynchronous upload has certainly run)
-        return ep
+        order_dev, _ = packer.upload_pinned(flat_rows, dev)      # (recycled page-locked staging buffer, asynchronous copy)
+        return Epoch(sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob)
 
     # ------------------------------------------------------------------ one optimizer step
     def step(self, it, ep, k, loss_out=None):

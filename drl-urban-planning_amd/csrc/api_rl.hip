@@ -130,6 +130,11 @@ extern "C" int upamd_clock_probe(void *out_dev, int32_t samples, int32_t gap_tic
     return UPAMD_OK;
 }
 
+extern "C" int upamd_tiny_profile(void *buf_dev) {
+    set_tiny_prof(buf_dev);
+    return UPAMD_OK;
+}
+
 extern "C" int upamd_tune(const char *name, int32_t value) {
     if (!name) return fail(UPAMD_E_INVALID, "upamd_tune: name is null");
     if (!strcmp(name, "gemm_nt_dma")) { set_gemm_nt_dma_variant(value); return UPAMD_OK; }

@@ -232,10 +232,10 @@ void make_plan(const upamd_model_desc &d, const ParamLayout &P, const upamd_mini
     // per-row sums of the pointer heads' backward (pointer_bwd2): [B][h0] each, reduced over the rows afterwards;
     // 0: land dz*hid, 1: (free), 2: road dz*hid, 3: road dpre  (the land dpre sums are S_DCONST)
     for (int k = 0; k < 4; ++k) add(S_CSP0 + k, B * std::max(std::max(x.h0l, x.h0r), 16));
-    if (tiny_supported(d, mb.max_n, mb.max_inc)) {
+    if (tiny_supported(d, mb.max_n, mb.max_inc, mb.max_cand)) {
         const int G = tiny_groups((int)B);
         add(S_TINY_SLAB, (int64_t)G * tiny_slab_stride(P));
-        add(S_TINY_SCR, (int64_t)G * tiny_scratch_stride(d, mb.max_inc));
+        add(S_TINY_SCR, (int64_t)G * tiny_scratch_stride(d, mb.max_cand));
         add(S_TINY_LOSS, B * 4);
     }
     // second dP|dQ buffer (layer l's weight gradient on the side stream may still read its own).  LAST slot of the plan on
@@ -271,7 +271,7 @@ PackedView make_view(const void *packed_dev, const upamd_pack_layout &L) {
 
 MbView make_mb(const upamd_minibatch &mb) {
     MbView v;
-    v.B = mb.B; v.M = mb.n_nodes; v.Nhe = mb.n_he; v.Nrn = mb.n_rn; v.max_n = mb.max_n; v.max_inc = mb.max_inc;
+    v.B = mb.B; v.M = mb.n_nodes; v.Nhe = mb.n_he; v.Nrn = mb.n_rn; v.max_n = mb.max_n; v.max_inc = mb.max_inc; v.max_cand = mb.max_cand;
     v.idx = mb.idx_dev; v.node_off = mb.node_off_dev; v.he_off = mb.he_off_dev; v.rn_off = mb.rn_off_dev;
     v.NI = mb.n_inc; v.inc_off = mb.inc_off_dev;
     v.rows = nullptr;
@@ -649,7 +649,7 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     auto PR = [&](int idx) { return prm + P.off(idx); };
     Profiler *prof = &eng->prof;
     // fused small-model path (tiny.hip): the whole forward of a graph in one workgroup, one launch for the minibatch
-    if (tiny_supported(d, mbp->max_n, mbp->max_inc)) {
+    if (tiny_supported(d, mbp->max_n, mbp->max_inc, mbp->max_cand)) {
         TinyIO io;
         memset(&io, 0, sizeof(io));
         io.mode = 0;
@@ -925,7 +925,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     auto PR = [&](int idx) { return prm + P.off(idx); };
     auto GR = [&](int idx) { return grads + P.off(idx); };
     Profiler *prof = &eng->prof;
-    if (tiny_supported(d, mbp->max_n, mbp->max_inc)) {
+    if (tiny_supported(d, mbp->max_n, mbp->max_inc, mbp->max_cand)) {
         // fused small-model path: forward recomputed inside the kernel, backward from the given seeds, slabs -> grads (added)
         TinyIO io;
         memset(&io, 0, sizeof(io));
@@ -1384,7 +1384,7 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
 // =============================================================================================
 extern "C" int upamd_step_fused_ok(upamd_engine *eng, const upamd_minibatch *mb) {
     if (!eng || !mb) return 0;
-    return tiny_supported(eng->d, mb->max_n, mb->max_inc) ? 1 : 0;
+    return tiny_supported(eng->d, mb->max_n, mb->max_inc, mb->max_cand) ? 1 : 0;
 }
 
 extern "C" int upamd_step_fused(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout, const upamd_minibatch *mbp,
@@ -1396,7 +1396,7 @@ extern "C" int upamd_step_fused(upamd_engine *eng, const void *packed_dev, const
     CK(check_args(eng, packed_dev, layout, mbp, prm, ws_dev, ws_bytes, &pl));
     if (!adv_dev || !ret_dev || !old_logp_dev || !exps_dev || !value_dev || !logp_dev || !ent_dev || !grads_dev || !losses_dev)
         return fail(UPAMD_E_INVALID, "upamd_step_fused: null argument");
-    if (!tiny_supported(eng->d, mbp->max_n, mbp->max_inc))
+    if (!tiny_supported(eng->d, mbp->max_n, mbp->max_inc, mbp->max_cand))
         return fail(UPAMD_E_INVALID, "upamd_step_fused: this model / minibatch is not covered by the fused small-model path "
                                      "(ask upamd_step_fused_ok first and use upamd_forward / upamd_ppo_loss_rows / upamd_backward)");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -56,7 +56,7 @@ struct PackedView {   // device pointers into the packed replay (upamd_pack_layo
 struct MbView {       // one minibatch (device schedule arrays)
     int B;
     int64_t M, Nhe, Nrn;
-    int max_n, max_inc;
+    int max_n, max_inc, max_cand;
     const int32_t *idx, *node_off, *he_off, *rn_off;
     int64_t NI;                 // incidences (edge directions) of the minibatch; only used when num_edge_fc_layers > 1
     const int32_t *inc_off;     // [B+1] prefix sums of 2e (may be null when K = 1)
@@ -314,10 +314,11 @@ struct TinyIO {
     float *losses;                              // mode 2: the four loss scalars
 };
 void set_tiny_fused(int on);                    // tune knob "tiny_fused" (default on)
+void set_tiny_prof(void *dev_buf);              // lab hook: int64[32] section time stamps (100 MHz) of workgroup 0's first graph
 void set_tiny_threads(int n);                   // tune knob "tiny_threads": 1024 (default) | 512 threads per workgroup
-bool tiny_supported(const upamd_model_desc &d, int max_n, int max_inc);
+bool tiny_supported(const upamd_model_desc &d, int max_n, int max_inc, int max_cand);
 int tiny_groups(int B);
-int64_t tiny_scratch_stride(const upamd_model_desc &d, int max_inc);
+int64_t tiny_scratch_stride(const upamd_model_desc &d, int max_cand);
 int64_t tiny_slab_stride(const ParamLayout &P);
 int launch_tiny(const upamd_model_desc &d, const ParamLayout &P, const PackedView &pk, const MbView &mb, const float *prm,
                 const TinyIO &io, hipStream_t st);

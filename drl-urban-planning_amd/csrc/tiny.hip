@@ -18,6 +18,8 @@ static int g_tiny_threads = 1024;
 void set_tiny_threads(int n) { g_tiny_threads = n == 512 ? 512 : 1024; }
 constexpr int64_t TINY_LDS_LIMIT = 160 * 1024 - 512;
 
+static long long *g_tiny_prof = nullptr;      // lab hook (upamd_tiny_profile): section time stamps of one graph
+void set_tiny_prof(void *buf) { g_tiny_prof = static_cast<long long *>(buf); }
 static int g_tiny_fused = 1;       // tune knob "tiny_fused" (default on)
 void set_tiny_fused(int on) { g_tiny_fused = on ? 1 : 0; }
 
@@ -100,8 +102,8 @@ static void tiny_fill(const upamd_model_desc &d, const ParamLayout &P, Dims *x, 
 // The fused path covers: the SGNN encoder with single-Linear edge MLPs, D = 16 | 32, at least two GCN layers (the backward
 // recomputes H^0 in H^1's place), two-layer pointer heads, hidden widths <= 64, and minibatches whose LARGEST graph fits one
 // workgroup's LDS next to everything else (D = 16: up to ~400 nodes / ~2300 edges, the DHM community included).
-bool tiny_supported(const upamd_model_desc &d, int max_n, int max_inc) {
-    if (!g_tiny_fused) return false;
+bool tiny_supported(const upamd_model_desc &d, int max_n, int max_inc, int max_cand) {
+    if (!g_tiny_fused || max_cand <= 0) return false;
     if (d.encoder != UPAMD_ENCODER_SGNN || edge_fc_layers(d) != 1) return false;
     if (!(d.D == 16 || d.D == 32) || d.L < 2 || d.L > MAXL || d.node_dim > XPAD) return false;
     if (d.n_land != 2 || d.n_road != 2 || d.land_hidden[0] > 64 || d.road_hidden[0] > 64) return false;
@@ -113,11 +115,11 @@ bool tiny_supported(const upamd_model_desc &d, int max_n, int max_inc) {
     ParamLayout P;
     if (build_param_layout(&d, &P)) return false;
     tiny_fill(d, P, &x, &o);
-    return make_plan(x, max_n > 0 ? max_n : 1, max_inc).total * 4 <= TINY_LDS_LIMIT;
+    return make_plan(x, max_n > 0 ? max_n : 1, max_inc, max_cand).total * 4 <= TINY_LDS_LIMIT;
 }
 
 int tiny_groups(int B) { return B < 256 ? B : 256; }
-int64_t tiny_scratch_stride(const upamd_model_desc &d, int max_inc) { return align_up(((int64_t)max_inc / 2 + 1) * d.D, 64); }
+int64_t tiny_scratch_stride(const upamd_model_desc &d, int max_cand) { return align_up(((int64_t)max_cand + 1) * d.D, 64); }
 int64_t tiny_slab_stride(const ParamLayout &P) { return align_up(P.n_floats, 64); }
 
 int launch_tiny(const upamd_model_desc &d, const ParamLayout &P, const PackedView &pk, const MbView &mb, const float *prm,
@@ -136,9 +138,10 @@ int launch_tiny(const upamd_model_desc &d, const ParamLayout &P, const PackedVie
     A.clip_eps = io.clip_eps; A.cv = io.cv; A.ce = io.ce; A.inv_rows = io.inv_rows; A.inv_ind = io.inv_ind;
     A.loss_rows = io.loss_rows;
     A.slab = io.slab; A.slab_stride = tiny_slab_stride(P);
-    A.scratch = io.scratch; A.scratch_stride = tiny_scratch_stride(d, mb.max_inc);
-    A.max_n = mb.max_n; A.max_inc = mb.max_inc;
-    const Plan pl = make_plan(A.d, mb.max_n > 0 ? mb.max_n : 1, mb.max_inc);
+    A.scratch = io.scratch; A.scratch_stride = tiny_scratch_stride(d, mb.max_cand);
+    A.max_n = mb.max_n; A.max_inc = mb.max_inc; A.max_cand = mb.max_cand;
+    A.prof = g_tiny_prof;
+    const Plan pl = make_plan(A.d, mb.max_n > 0 ? mb.max_n : 1, mb.max_inc, mb.max_cand);
     const int64_t lds = pl.total * 4;
     if (lds > TINY_LDS_LIMIT) return fail(UPAMD_E_LIMIT, "fused small-model path: a graph of %d nodes / %d incidences needs %lld bytes of LDS", mb.max_n, mb.max_inc, (long long)lds);
     if (io.mode != FWD && (!io.slab || !io.scratch)) return fail(UPAMD_E_INVALID, "fused small-model path: no slab / scratch workspace");

@@ -8,15 +8,20 @@
 // (loss); the hand-derived backward is the one of tests/csr_model.py, stage by stage.
 //
 // This header holds the PER-GRAPH program and nothing target specific: tiny.hip instantiates it as a HIP kernel; the test
-// infrastructure (tests/tiny_emul.cpp, TINY_HOST) compiles the very same text with g++ and runs it on the CPU against the
+// infrastructure (tests/emul/tiny_emul.cpp, TINY_HOST) compiles the very same text with g++ and runs it on the CPU against the
 // oracle before any GPU time is spent.  The contract that makes that possible:
-//   * all parallelism is "for every index i of a range, independent iterations", written T_FOR(i, N) and closed by T_SYNC()
-//     (a workgroup barrier on the GPU, nothing on the host where the range runs sequentially) -- no wave intrinsics, no
-//     atomics, no thread-private state that survives a T_SYNC();
+//   * all parallelism is "for every index of a range, independent iterations" -- T_FOR(i, N), or T_FOR_J(j, NJ) { .. T_FOR_V(v,
+//     NV, NJ) { .. } } where a thread keeps ONE j (its weight row in registers) and strides over v -- closed by T_SYNC() (a
+//     workgroup barrier on the GPU, nothing on the host where the ranges run sequentially); no wave intrinsics, no atomics,
+//     no thread-private state that survives a T_SYNC();
 //   * an iteration writes only elements it owns; every sum is a serial loop in a fixed order inside one iteration (two-level
-//     sums: fixed partial groups, then a fixed combine) => bit-reproducible run to run, like the large-model kernels;
+//     sums: fixed partial groups, then a fixed combine) => bit-reproducible run to run and for any block size;
 //   * gradients of the parameters go to the workgroup's own slab in global memory (`+=` by the owning iteration); the slabs
 //     are added in a fixed order by the reduction launch.
+//
+// What bounds the kernel is the LATENCY of its ~70 dependent phases, not arithmetic (1 MFLOP per graph): weight rows are
+// hoisted into registers, the raw node features and the candidate lists are staged in LDS once per use, long node sums are
+// split over fixed partial groups, and the small per-sample layers read their weights with many loads in flight.
 #pragma once
 #include <stdint.h>
 
@@ -26,10 +31,15 @@
 #define TMEM inline
 #define THD static inline
 #define T_FOR(i, N) for (int i = 0; i < (N); ++i)
+#define T_FOR_J(j, NJ) for (int j = 0; j < (NJ); ++j)
+#define T_FOR_V(v, NV, NJ) for (int v = 0; v < (NV); ++v)
 #define T_SYNC() \
     do {         \
     } while (0)
-#define T_TID0 1
+#define T_MARK(k) \
+    do {          \
+    } while (0)
+#define T_FLAG(p) (*(p) |= 1)
 static inline float t_exp2(float x) { return exp2f(x); }
 static inline float t_rcp(float x) { return 1.0f / x; }
 static inline float t_log(float x) { return logf(x); }
@@ -38,8 +48,18 @@ static inline float t_log(float x) { return logf(x); }
 #define TMEM __device__ __forceinline__
 #define THD __host__ __device__ inline
 #define T_FOR(i, N) for (int i = (int)threadIdx.x; i < (N); i += (int)blockDim.x)
+// thread -> (j = tid % NJP, first v = tid / NJP), NJP = NJ rounded up to a power of two (it divides the block size)
+#define T_FOR_J(j, NJ) for (int j = (int)threadIdx.x & (upamd_tiny::np2(NJ) - 1), _once = 1; _once && j < (NJ); _once = 0)
+#define T_FOR_V(v, NV, NJ) \
+    for (int v = (int)threadIdx.x / upamd_tiny::np2(NJ), _vs = (int)blockDim.x / upamd_tiny::np2(NJ); v < (NV); v += _vs)
 #define T_SYNC() __syncthreads()
-#define T_TID0 (threadIdx.x == 0)
+// section time stamps (100 MHz wall clock) of the FIRST graph of workgroup 0 into A.prof (lab hook, null in production)
+#define T_MARK(k)                                                                                \
+    do {                                                                                         \
+        if (A.prof && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) A.prof[k] = wall_clock64(); \
+    } while (0)
+// raise a per-graph flag word in LDS (an OR: order independent, so the result does not depend on who gets there first)
+#define T_FLAG(p) atomicOr((p), 1)
 TDEV float t_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 TDEV float t_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 TDEV float t_log(float x) { return __logf(x); }
@@ -52,10 +72,14 @@ constexpr int XPAD = 24;          // UPAMD_NODE_PAD
 constexpr int MAXMLP = 4;
 constexpr int MAXL = 16;
 constexpr int NG = 32;            // partial groups of the two-level sums
-constexpr int CH = 32;            // pointer-head candidates per chunk
+constexpr int CHMIN = 32;         // pointer-head candidates per chunk the LDS plan guarantees (more when the graph leaves room)
 constexpr float C2 = 2.8853900817779268f;     // 2 log2(e)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float PAD_LOGIT = -4294967296.0f;   // -2^32 + 1 in fp32 (policy.py:50,59)
+// Exp form of a layer's P | Q (as in edge.hip): with E = 2^(C2 (P_v + Q_u + b)) = eP_v * eb * eQ_u, tanh(x) = 1 - 2 / (1 + E) needs no
+// exponential per incidence -- valid while no factor over / underflows: every |C2 P|, |C2 Q| <= EF_LIMIT and |C2 b| <= EF_BIAS keep
+// all products inside [2^-86, 2^86].  A graph whose layer leaves that range raises the layer's flag and walks in the linear form.
+constexpr float EF_LIMIT = 40.0f, EF_BIAS = 6.0f;
 
 struct Dims {
     int D, L, heads, F, Fn;
@@ -100,37 +124,51 @@ struct Args {
     int64_t slab_stride;
     float *scratch;                               // [G][scratch_stride] per-workgroup global scratch (dM of the candidates)
     int64_t scratch_stride;
-    int max_n, max_inc;
+    int max_n, max_inc, max_cand;
+    long long *prof;                              // lab hook: section time stamps (see T_MARK), normally null
 };
 
 TDEV float t_tanh(float x) { return 1.0f - 2.0f * t_rcp(t_exp2(C2 * x) + 1.0f); }
 TDEV float t_exp(float x) { return t_exp2(x * LOG2E); }
 THD int imax(int a, int b) { return a > b ? a : b; }
+THD int imin(int a, int b) { return a < b ? a : b; }
 THD int64_t a4(int64_t x) { return (x + 3) / 4 * 4; }
+THD int np2(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
 
-// ---- LDS plan (floats).  n / inc = the LARGEST graph of the launch: one plan per launch, every graph uses its prefix.
+// ---- LDS plan (floats).  n / inc / cand = the LARGEST graph of the launch: one plan per launch, every graph uses its prefix.
 struct Plan {
     int64_t H, X, PQ, rp, nb, alpha, sc, vec, total;      // offsets
     int64_t xsize, vsize;
 };
+// head scratch inside the X region: z [nc] | candidate lists (2 u16 + 1 u8 per candidate -> 1.25 floats, kept at 1.5) | chunk buffers
+THD int64_t head_fixed(int nc) { return a4(nc) + a4((3 * (int64_t)nc + 1) / 2); }
+THD int part_floats(const Dims &d) {
+    const int Hd = d.heads * d.D;
+    return imax(NG * 2 * imax(Hd, 32), 4 * d.D * d.D + NG * d.D);
+}
 THD int64_t vec_floats(const Dims &d) {
     int64_t u = d.Fn, v = 0;
     for (int i = 0; i < d.n_num; ++i) u += d.num_hidden[i];
     for (int i = 0; i < d.n_value; ++i) v += d.value_hidden[i];
     const int64_t D = d.D, Hd = (int64_t)d.heads * d.D, h0 = imax(d.h0l, d.h0r);
-    //     U        cur   C..dC (16 D-vectors)   head vectors (10)   SV, dSV     V, dV      A, M (h0 x D)  const, s, w2..   partials        scalars
-    return u + XPAD + 16 * D + 10 * Hd + 2 * a4(d.W) + 2 * a4(v) + 2 * h0 * D + 8 * h0 + (int64_t)NG * imax((int)Hd, 64) + 64 + 256;
+    //     U        cur   16 D-vectors   10 head vectors   SV, dSV     V, dV      A, M (h0 x D)  const, s, w2..   partials   scalars + slack
+    return u + XPAD + 16 * D + 10 * Hd + 2 * a4(d.W) + 2 * a4(v) + 2 * h0 * D + 8 * h0 + part_floats(d) + 64 + 256;
 }
-THD Plan make_plan(const Dims &d, int n, int inc) {
+THD Plan make_plan(const Dims &d, int n, int inc, int cand) {
     Plan p;
     const int64_t nD = (int64_t)n * d.D;
     int64_t o = 0;
     p.H = o; o += a4((int64_t)d.L * nD);                                           // H^1 .. H^L ([n][D] each; slot L becomes G)
-    p.xsize = imax((int)nD, inc / 2 + imax(n, 1) + CH * (d.D + 2 * imax(d.h0l, d.h0r)));
-    p.X = o; o += a4(p.xsize);                                                     // S / dS | head scratch (z, chunk buffers)
-    p.PQ = o; o += a4(2 * nD);                                                     // P | Q of a layer; backward: half | d(half)
+    const int64_t hs = head_fixed(imax(cand, 1)) + (int64_t)CHMIN * (d.D + 2 * imax(d.h0l, d.h0r));
+    p.xsize = nD > hs ? nD : hs;
+    p.X = o; o += a4(p.xsize);                                                     // S / dS | head scratch
+    p.PQ = o; o += a4(imax((int)(2 * nD), n * XPAD));                              // P | Q of a layer / staged raw features; backward: half | d(half)
     p.rp = o; o += a4(n + 1);
-    p.nb = o; o += a4((inc + 1) / 2);                                              // u16 neighbour ids
+    p.nb = o; o += a4((inc + 1) / 2 + 1);                                          // u16 neighbour ids
     p.alpha = o; o += a4((int64_t)d.heads * n);
     p.sc = o; o += a4((int64_t)d.heads * n);
     p.vsize = vec_floats(d);
@@ -150,53 +188,99 @@ struct Bump {
     }
 };
 
-// out[j] = act(bias[j] + sum_k W[j * K + k] * in[k]);  weights from global memory, vectors in LDS (tiny per-sample layers)
+// sum_k w[k] x[k]: the (global-memory) weights in batches of 16 loads in flight (the layers are latency-bound: an L2 round trip per
+// batch is what a phase costs)
+TDEV float dot_g(const float *w, const float *x, int K, float acc = 0.0f) {
+    int k = 0;
+    for (; k + 16 <= K; k += 16) {
+        float a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = w[k + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = fmaf(a[q], x[k + q], acc);
+    }
+    if (k + 8 <= K) {
+        float a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = w[k + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fmaf(a[q], x[k + q], acc);
+        k += 8;
+    }
+    if (k < K) {                               // tail: clamped loads, masked adds (all in flight together)
+        float a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = w[k + q < K ? k + q : K - 1];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = k + q < K ? fmaf(a[q], x[k + q], acc) : acc;
+    }
+    return acc;
+}
+// sum_j W[j * ld + k] in[j], j in [j0, j1): strided weights, 16 loads in flight
+TDEV float dot_t(const float *W, int ld, int k, const float *in, int j0, int j1) {
+    float acc = 0.0f;
+    int j = j0;
+    for (; j + 16 <= j1; j += 16) {
+        float a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = W[(int64_t)(j + q) * ld + k];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = fmaf(a[q], in[j + q], acc);
+    }
+    if (j + 8 <= j1) {
+        float a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = W[(int64_t)(j + q) * ld + k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fmaf(a[q], in[j + q], acc);
+        j += 8;
+    }
+    if (j < j1) {
+        float a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = W[(int64_t)(j + q < j1 ? j + q : j1 - 1) * ld + k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = j + q < j1 ? fmaf(a[q], in[j + q], acc) : acc;
+    }
+    return acc;
+}
+
+// out[j] = act((bias[j] + sum_k W[j * K + k] * in[k]) * scale);  weights from global memory, vectors in LDS
 TDEV void lin(float *out, const float *in, const float *W, const float *bias, int N, int K, int act, float scale = 1.0f) {
     T_FOR(j, N) {
-        float acc = bias ? bias[j] : 0.0f;
-        const float *w = W + (int64_t)j * K;
-        for (int k = 0; k < K; ++k) acc = fmaf(w[k], in[k], acc);
-        acc *= scale;
+        const float acc = dot_g(W + (int64_t)j * K, in, K, bias ? bias[j] : 0.0f) * scale;
         out[j] = act ? t_tanh(acc) : acc;
     }
     T_SYNC();
 }
-// out[k] = sum_j W[j * K + k] * in[j]   (W^T in)
-TDEV void lin_t(float *out, const float *in, const float *W, int N, int K, int j0 = 0, int j1 = -1) {
-    if (j1 < 0) j1 = N;
-    T_FOR(k, K) {
-        float acc = 0.0f;
-        for (int j = j0; j < j1; ++j) acc = fmaf(W[(int64_t)j * K + k], in[j], acc);
-        out[k] = acc;
+// One layer of a small MLP backwards, ONE phase: weight gradient gw[j][k] += dz[j] x[k], bias gradient gb[j] += dz[j], and the
+// gradient of the layer's input dx[k] = (sum_j W[j][k] dz[j]) * (1 - y[k]^2) (y = that input if it is a tanh output, else null)
+TDEV void mlp_layer_bwd(float *gw, float *gb, float *dx, const float *dz, const float *x, const float *W, const float *y, int N,
+                        int K) {
+    T_FOR(i, N * K + N + (dx ? K : 0)) {
+        if (i < N * K) {
+            const int j = i / K, k = i - j * K;
+            gw[i] += dz[j] * x[k];
+        } else if (i < N * K + N) {
+            gb[i - N * K] += dz[i - N * K];
+        } else {
+            const int k = i - N * K - N;
+            float g = dot_t(W, K, k, dz, 0, N);
+            if (y) g *= 1.0f - y[k] * y[k];
+            dx[k] = g;
+        }
     }
     T_SYNC();
 }
 // slab[(j, k)] += a[j] * x[k]  (rank-1 weight gradient of a per-sample layer), and slab_b[j] += a[j]
 TDEV void outer_acc(float *gw, float *gb, const float *a, const float *x, int N, int K) {
-    T_FOR(i, N * K) {
-        const int j = i / K, k = i - j * K;
-        gw[i] += a[j] * x[k];
-    }
-    if (gb) {
-        T_FOR(j, N) gb[j] += a[j];
-    }
-    T_SYNC();
-}
-
-// dst[c] = scale * sum_{v < N} f(v, c), c < C: NG fixed partial groups, then a fixed combine
-template <class F>
-TDEV void colsum(float *dst, float *part, int N, int C, float scale, F f) {
-    T_FOR(i, NG * C) {
-        const int g = i / C, c = i - g * C;
-        float acc = 0.0f;
-        for (int v = g; v < N; v += NG) acc += f(v, c);
-        part[i] = acc;
-    }
-    T_SYNC();
-    T_FOR(c, C) {
-        float acc = 0.0f;
-        for (int g = 0; g < NG; ++g) acc += part[g * C + c];
-        dst[c] = acc * scale;
+    T_FOR(i, N * K + (gb ? N : 0)) {
+        if (i < N * K) {
+            const int j = i / K, k = i - j * K;
+            gw[i] += a[j] * x[k];
+        } else {
+            gb[i - N * K] += a[i - N * K];
+        }
     }
     T_SYNC();
 }
@@ -221,7 +305,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     const uint16_t *rnn = A.rn_node + m[12];
     const int32_t *hpg = A.hinc_ptr + m[13];
     const uint16_t *hnb = A.hinc_nbr + 2 * (int64_t)m[11], *hhe = A.hinc_he + 2 * (int64_t)m[11];
-    const int L = d.L, Hn = d.heads, dh = D / Hn, inc = 2 * e;
+    const int L = d.L, Hn = d.heads, dh = D / Hn, inc = 2 * e, F = d.F;
     const int nD = n * D;
     const bool land = stage == 0 && nc > 0, road = stage == 1 && nc > 0;
     const bool bwd = A.mode != FWD;
@@ -229,6 +313,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     float *Hs = lds + pl.H;                      // slot l (1..L) at Hs + (l - 1) * nD
     float *Xr = lds + pl.X;
     float *PQ = lds + pl.PQ;                     // [n][2D]: P columns 0..D-1, Q columns D..2D-1
+    float *Xs = PQ;                              // ... or the graph's raw node features [n][XPAD], while P | Q is not needed
     int *rp = reinterpret_cast<int *>(lds + pl.rp);
     uint16_t *nb = reinterpret_cast<uint16_t *>(lds + pl.nb);
     float *alpha = lds + pl.alpha, *sc = lds + pl.sc;
@@ -246,25 +331,29 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     float *V[MAXMLP + 1];
     V[0] = SV;
     for (int i = 0; i < d.n_value; ++i) V[i + 1] = vb.get(d.value_hidden[i]);
-    const int h0 = land ? d.h0l : d.h0r;
-    float *Aeff = vb.get((int64_t)imax(d.h0l, d.h0r) * D);       // land: (Wa + Wd) + Wc diag(C);  road: R1
-    float *cst = vb.get(imax(d.h0l, d.h0r));                    // land: b1 + (Wb - Wd) C;        road: rb1
-    float *w2v = vb.get(imax(d.h0l, d.h0r));
-    float *part = vb.get((int64_t)NG * imax(Hn * D, 64));
-    float *scal = vb.get(64);      // 0 mx, 1 lse, 2 ent, 3 logp, 4.. softmax scratch per head (mx, sum), 16 dvalue 17 dlogp 18 dent
+    const int h0 = land ? d.h0l : d.h0r, h0m = imax(d.h0l, d.h0r);
+    float *Aeff = vb.get((int64_t)h0m * D);      // land: (Wa + Wd) + Wc diag(C);  road: R1
+    float *cst = vb.get(h0m);                    // land: b1 + (Wb - Wd) C;        road: rb1
+    float *w2v = vb.get(h0m);
+    float *part = vb.get(part_floats(d));
+    float *scal = vb.get(64);      // 0 max logit, 1 lse, 2 entropy, 3 log-prob, 8 + h: 1 / softmax sum of head h
+    int *bad = reinterpret_cast<int *>(vb.get(MAXL + 4));      // bad[l] != 0: layer l's P | Q left the exp-form range (linear walk)
     // backward-only vectors
-    float *dSV = vb.get(d.W), *dC = vb.get(D), *dq0 = vb.get(D), *dq1 = vb.get(D), *dov = vb.get(D), *datt_unused = vb.get(D);
-    (void)datt_unused;
+    float *dSV = vb.get(d.W), *dC = vb.get(D), *dq0 = vb.get(D), *dq1 = vb.get(D), *dov = vb.get(D);
     float *du = vb.get(Hn * D), *ds = vb.get(Hn * D), *dr = vb.get(Hn * D), *dtk = vb.get(Hn * D);
-    float *dVa = vb.get(64), *dVb = vb.get(64);      // ping-pong of the small MLP backward (hidden <= 64)
-    float *Mj = vb.get((int64_t)imax(d.h0l, d.h0r) * D), *sj = vb.get(imax(d.h0l, d.h0r)), *dw2 = vb.get(imax(d.h0l, d.h0r));
+    float *dVa = vb.get(64), *dVb = vb.get(64);  // ping-pong of the small MLPs' backward (hidden <= 64)
+    float *Mj = vb.get((int64_t)h0m * D), *sj = vb.get(h0m), *dw2 = vb.get(h0m);
 
     // =============================================================================== forward
-    // lists + per-sample inputs
+    T_MARK(0);
+    // lists, per-sample inputs, the raw node features
     T_FOR(i, n + 1) rp[i] = rpg[i];
     T_FOR(i, inc) nb[i] = nbg[i];
     T_FOR(i, d.Fn) U[0][i] = A.numerical[(int64_t)t * d.Fn + i];
     T_FOR(i, XPAD) cur[i] = A.cur[(int64_t)t * XPAD + i];
+    T_FOR(i, MAXL + 1) bad[i] = 0;
+    auto stage_x = [&]() { T_FOR(i, n * XPAD) Xs[i] = Xg[i]; };
+    stage_x();
     T_SYNC();
     // numerical encoder (state_encoder.py:35-57,187)
     {
@@ -274,67 +363,125 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             K = d.num_hidden[i];
         }
     }
+    T_MARK(1);
     // current node through the node encoder (:191), attention query path (:150-156 + MultiheadAttention's q projection)
-    lin(C, cur, prm + o.node_w, prm + o.node_b, D, d.F, 0);
+    lin(C, cur, prm + o.node_w, prm + o.node_b, D, F, 0);
     lin(q0, C, prm + o.q_w, prm + o.q_b, D, D, 0);
     const float scale = 1.0f / sqrtf((float)dh);
     lin(q1, q0, prm + o.inproj_w, prm + o.inproj_b, D, D, 0, scale);
     // r_h = Wk^T (Wik[head rows]^T q1[head rows]):  score_j = r_h . h_j   (key-side biases are softmax-shift invariant)
-    for (int h = 0; h < Hn; ++h) lin_t(tk + h * D, q1, prm + o.inproj_w + (int64_t)D * D, D, D, h * dh, (h + 1) * dh);
-    for (int h = 0; h < Hn; ++h) lin_t(rr + h * D, tk + h * D, prm + o.k_w, D, D);
+    T_FOR(i, Hn * D) {
+        const int h = i / D, k = i - h * D;
+        tk[i] = dot_t(prm + o.inproj_w + (int64_t)D * D, D, k, q1, h * dh, (h + 1) * dh);
+    }
+    T_SYNC();
+    T_FOR(i, Hn * D) {
+        const int h = i / D, k = i - h * D;
+        rr[i] = dot_t(prm + o.k_w, D, k, tk + h * D, 0, D);
+    }
+    T_SYNC();
+    T_MARK(2);
 
-    // node encoder on every node (:189-190): H^0 into slot 1 (layer 1 updates it in place)
+    // node encoder on every node (:189-190): H^0 from the staged raw features; thread = one output column, its weight row in registers
     const float *We = prm + o.node_w, *be = prm + o.node_b;
     auto encode_nodes = [&](float *dst) {
-        T_FOR(i, nD) {
-            const int v = i / D, c = i - v * D;
-            const float *x = Xg + (int64_t)v * XPAD, *w = We + (int64_t)c * d.F;
-            float acc = be[c];
-            for (int f = 0; f < d.F; ++f) acc = fmaf(w[f], x[f], acc);
-            dst[i] = acc;
-        }
-        T_SYNC();
-    };
-    // P | Q of layer l from Hin: PQ[v][j] = sum_k Wl[j % D][(j / D) * D + k] Hin[v][k]   (linear_0.weight is [D][2D] = [Wa | Wb])
-    auto pq_full = [&](int l, const float *Hin) {
-        const float *Wl = prm + o.edge_w[l - 1];
-        T_FOR(i, n * 2 * D) {
-            const int v = i / (2 * D), j = i - v * 2 * D;
-            const float *w = Wl + (int64_t)(j % D) * (2 * D) + (j / D) * D, *h = Hin + (int64_t)v * D;
-            float acc = 0.0f;
+        T_FOR_J(c, D) {
+            float w[XPAD];
 #pragma unroll
-            for (int k = 0; k < D; ++k) acc = fmaf(w[k], h[k], acc);
-            PQ[i] = acc;
+            for (int f = 0; f < XPAD; ++f) w[f] = f < F ? We[(int64_t)c * F + f] : 0.0f;
+            const float bc = be[c];
+            T_FOR_V(v, n, D) {
+                const float *x = Xs + (int64_t)v * XPAD;
+                float acc = bc;
+#pragma unroll
+                for (int f = 0; f < XPAD; ++f) acc = fmaf(w[f], x[f], acc);
+                dst[v * D + c] = acc;
+            }
         }
         T_SYNC();
     };
-    encode_nodes(slotH(1));
+    encode_nodes(slotH(1));                      // layer 1 updates it in place
+    T_MARK(3);
     for (int l = 1; l <= L; ++l) {
         const float *Hin = l == 1 ? slotH(1) : slotH(l - 1);
         float *Hout = slotH(l);
-        const float *bl = prm + o.edge_b[l - 1];
+        const float *Wl = prm + o.edge_w[l - 1], *bl = prm + o.edge_b[l - 1];
         const bool last = l == L;
-        pq_full(l, Hin);
-        // node-centric segment sum (:110-148): S_v = sum over incidences 1/2 [tanh(P_v + Q_u + b) + tanh(P_u + Q_v + b)]
-        T_FOR(i, nD) {
-            const int v = i / D, c = i - v * D;
-            const float pv = PQ[v * 2 * D + c] + bl[c], qv = PQ[v * 2 * D + D + c] + bl[c];
-            const int k0 = rp[v], k1 = rp[v + 1];
-            float S = 0.0f;
-            for (int k = k0; k < k1; ++k) {
-                const int u = nb[k];
-                S += 0.5f * (t_tanh(pv + PQ[u * 2 * D + D + c]) + t_tanh(PQ[u * 2 * D + c] + qv));
+        // P | Q of the layer: PQ[v][j] = sum_k Wl[j % D][(j / D) * D + k] Hin[v][k]   (linear_0.weight is [D][2D] = [Wa | Wb])
+        T_FOR_J(j, 2 * D) {
+            float w[D];
+            const float *wr = Wl + (int64_t)(j % D) * (2 * D) + (j / D) * D;
+#pragma unroll
+            for (int k = 0; k < D; ++k) w[k] = wr[k];
+            float mx = fabsf(bl[j % D]) * (EF_LIMIT / EF_BIAS);          // (the bias limit folded into the same test)
+            T_FOR_V(v, n, 2 * D) {
+                const float *h = Hin + (int64_t)v * D;
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc = fmaf(w[k], h[k], acc);
+                PQ[v * 2 * D + j] = acc;
+                mx = fmaxf(mx, fabsf(acc));
             }
-            Hout[i] = Hin[i] + S / ((float)(k1 - k0) + 1e-6f);
-            if (last) Xr[i] = S;
+            if (!(C2 * mx <= EF_LIMIT)) T_FLAG(bad + l);
+        }
+        T_SYNC();
+        const bool ef = bad[l] == 0;
+        if (ef) {                                // exp form in place: the walks below then need no exponential per incidence
+            T_FOR(i, n * 2 * D) PQ[i] = t_exp2(C2 * PQ[i]);
+            T_SYNC();
+        }
+        // node-centric segment sum (:110-148): S_v = sum over incidences 1/2 [tanh(P_v + Q_u + b) + tanh(P_u + Q_v + b)]
+        //   exp form: 1/2 (t1 + t2) = 1 - (r1 + r2),  r = 1 / (1 + E)
+        T_FOR_J(c, D) {
+            const float bc = bl[c], eb = t_exp2(C2 * bc);
+            T_FOR_V(v, n, D) {
+                const int k0 = rp[v], k1 = rp[v + 1];
+                float S = 0.0f;
+                if (ef) {
+                    const float pv = PQ[v * 2 * D + c] * eb, qv = PQ[v * 2 * D + D + c] * eb;
+                    float acc = 0.0f;
+                    for (int k = k0; k < k1; ++k) {
+                        const int u = nb[k];
+                        acc += t_rcp(fmaf(pv, PQ[u * 2 * D + D + c], 1.0f)) + t_rcp(fmaf(PQ[u * 2 * D + c], qv, 1.0f));
+                    }
+                    S = (float)(k1 - k0) - acc;
+                } else {
+                    const float pv = PQ[v * 2 * D + c] + bc, qv = PQ[v * 2 * D + D + c] + bc;
+                    for (int k = k0; k < k1; ++k) {
+                        const int u = nb[k];
+                        S += 0.5f * (t_tanh(pv + PQ[u * 2 * D + D + c]) + t_tanh(PQ[u * 2 * D + c] + qv));
+                    }
+                }
+                Hout[v * D + c] = fmaf(S, t_rcp((float)(k1 - k0) + 1e-6f), Hin[v * D + c]);
+                if (last) Xr[v * D + c] = S;
+            }
         }
         T_SYNC();
     }
+    T_MARK(4);
     float *HL = slotH(L);
-    // masked node mean, edge mean (:179-182,199-200; every message is summed at both endpoints)
-    colsum(hbarV, part, n, D, 1.0f / (float)m[6], [&](int v, int c) { return nmg[v] ? HL[v * D + c] : 0.0f; });
-    colsum(hbarE, part, n, D, 0.5f / (float)e, [&](int v, int c) { return Xr[v * D + c]; });
-    // single-query attention over the node_mask nodes (:150-161)
+    // masked node mean, edge mean (:179-182,199-200; every message is summed at both endpoints): one two-level pass for both
+    T_FOR(i, NG * 2 * D) {
+        const int g = i / (2 * D), c = i - g * 2 * D;
+        float acc = 0.0f;
+        if (c < D) {
+            for (int v = g; v < n; v += NG) acc += nmg[v] ? HL[v * D + c] : 0.0f;
+        } else {
+            for (int v = g; v < n; v += NG) acc += Xr[v * D + c - D];
+        }
+        part[i] = acc;
+    }
+    T_SYNC();
+    T_FOR(c, 2 * D) {
+        float acc = 0.0f;
+        for (int g = 0; g < NG; ++g) acc += part[g * 2 * D + c];
+        if (c < D) hbarV[c] = acc * (1.0f / (float)m[6]);
+        else hbarE[c - D] = acc * (0.5f / (float)e);
+    }
+    T_SYNC();
+    T_MARK(5);
+    // single-query attention over the node_mask nodes (:150-161).  alpha is kept UNNORMALISED (exp(score - max)) until the
+    // backward, its normaliser as scal[8 + h]
     for (int h = 0; h < Hn; ++h) {
         float *sch = sc + (int64_t)h * n, *al = alpha + (int64_t)h * n;
         const float *r = rr + h * D;
@@ -351,38 +498,40 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             part[g] = mx;
         }
         T_SYNC();
-        if (T_TID0) {
+        T_FOR(v, n) {                            // (every iteration combines the NG partial maxima itself: no extra phase)
             float mx = -INFINITY;
             for (int g = 0; g < NG; ++g) mx = fmaxf(mx, part[g]);
-            scal[4] = mx;
+            al[v] = nmg[v] ? t_exp(sch[v] - mx) : 0.0f;
         }
         T_SYNC();
-        T_FOR(v, n) al[v] = nmg[v] ? t_exp(sch[v] - scal[4]) : 0.0f;
-        T_SYNC();
-        T_FOR(g, NG) {
-            float sum = 0.0f;
-            for (int v = g; v < n; v += NG) sum += al[v];
-            part[g] = sum;
+        // partial sums of alpha (column D) and of alpha * H^L (columns 0..D-1)
+        T_FOR(i, NG * (D + 1)) {
+            const int g = i / (D + 1), c = i - g * (D + 1);
+            float acc = 0.0f;
+            if (c < D) {
+                for (int v = g; v < n; v += NG) acc = fmaf(al[v], HL[v * D + c], acc);
+            } else {
+                for (int v = g; v < n; v += NG) acc += al[v];
+            }
+            part[i] = acc;
         }
         T_SYNC();
-        if (T_TID0) {
-            float sum = 0.0f;
-            for (int g = 0; g < NG; ++g) sum += part[g];
-            scal[5] = 1.0f / sum;
+        T_FOR(c, D + 1) {
+            float sum = 0.0f, acc = 0.0f;
+            for (int g = 0; g < NG; ++g) {
+                sum += part[g * (D + 1) + D];
+                acc += part[g * (D + 1) + (c < D ? c : 0)];
+            }
+            const float inv = 1.0f / sum;
+            if (c < D) ss[h * D + c] = acc * inv;
+            else scal[8 + h] = inv;
         }
         T_SYNC();
-        T_FOR(v, n) al[v] *= scal[5];
-        T_SYNC();
-        colsum(ss + h * D, part, n, D, 1.0f, [&](int v, int c) { return al[v] * HL[v * D + c]; });
         // u_h = Wv s_h + bv;   o[head rows] = Wiv[head rows] u_h + biv[head rows]
         lin(uu + h * D, ss + h * D, prm + o.v_w, prm + o.v_b, D, D, 0);
     }
-    T_FOR(i, D) {
-        const float *w = prm + o.inproj_w + (int64_t)(2 * D + i) * D, *u = uu + (i / dh) * D;
-        float acc = prm[o.inproj_b + 2 * D + i];
-        for (int k = 0; k < D; ++k) acc = fmaf(w[k], u[k], acc);
-        ov[i] = acc;
-    }
+    T_MARK(6);
+    T_FOR(i, D) ov[i] = dot_g(prm + o.inproj_w + (int64_t)(2 * D + i) * D, uu + (i / dh) * D, D, prm[o.inproj_b + 2 * D + i]);
     T_SYNC();
     lin(att, ov, prm + o.outproj_w, prm + o.outproj_b, D, D, 0);
     // state_value = [h_num | mean nodes | mean edges | attended current node | stage] (:204-205), value head (value.py:15-39)
@@ -403,42 +552,73 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             K = d.value_hidden[i];
         }
     }
+    T_MARK(7);
     // ---- pointer head of the row's stage (policy.py:45-104); candidates only (a masked slot has probability exactly 0)
-    float *z = Xr;                               // [nc] logits
-    float *chunk = Xr + a4(imax(nc, 1));         // [CH][D] m (or XR), [CH][h0] hid, [CH][h0] dpre
+    // head scratch in the X region: z [nc] | the candidate lists | chunk buffers ([CH][D] inputs, [CH][h0] hidden, [CH][h0] dpre)
+    const int ncl = imax(nc, 1);
+    float *z = Xr;
+    uint16_t *cl_a = reinterpret_cast<uint16_t *>(Xr + a4(ncl));                   // land: src | road: node
+    uint16_t *cl_b = cl_a + ncl;                                                   // land: dst
+    uint8_t *cl_live = reinterpret_cast<uint8_t *>(cl_b + ncl);
+    float *chunk = Xr + head_fixed(ncl);
+    const int per = D + 2 * h0m;
+    int CH = (int)((pl.xsize - head_fixed(ncl)) / per);
+    CH = imin(imax(CH, 1), ncl);
     const float *PQl = PQ;                       // last layer's P | Q is still in place (the forward wrote it last)
     const float *blL = prm + o.edge_b[L - 1];
     // candidate inputs of a chunk: land = the candidate edge's last-layer message m (0 if not a live edge), road = its node's H^L row
     auto cand_inputs = [&](int q0c, int cn, float *mq) {
-        T_FOR(i, cn * D) {
-            const int q = q0c + i / D, c = i % D;
-            float val;
-            if (land) {
-                val = 0.0f;
-                if (hlive[q]) {
-                    const int vi = hsrc[q], vj = hdst[q];
-                    val = 0.5f * (t_tanh(PQl[vi * 2 * D + c] + PQl[vj * 2 * D + D + c] + blL[c]) +
-                                  t_tanh(PQl[vj * 2 * D + c] + PQl[vi * 2 * D + D + c] + blL[c]));
+        const bool efL = bad[L] == 0;           // (the last layer's P | Q is in exp form)
+        T_FOR_J(c, D) {
+            const float bc = blL[c], eb = t_exp2(C2 * bc);
+            T_FOR_V(qq, cn, D) {
+                const int q = q0c + qq;
+                float val;
+                if (land) {
+                    val = 0.0f;
+                    if (cl_live[q]) {
+                        const int vi = cl_a[q], vj = cl_b[q];
+                        if (efL)
+                            val = 1.0f - (t_rcp(fmaf(PQl[vi * 2 * D + c] * eb, PQl[vj * 2 * D + D + c], 1.0f)) +
+                                          t_rcp(fmaf(PQl[vj * 2 * D + c] * eb, PQl[vi * 2 * D + D + c], 1.0f)));
+                        else
+                            val = 0.5f * (t_tanh(PQl[vi * 2 * D + c] + PQl[vj * 2 * D + D + c] + bc) +
+                                          t_tanh(PQl[vj * 2 * D + c] + PQl[vi * 2 * D + D + c] + bc));
+                    }
+                } else {
+                    val = HL[cl_a[q] * D + c];
                 }
-            } else {
-                val = HL[rnn[q] * D + c];
+                mq[qq * D + c] = val;
             }
-            mq[i] = val;
         }
         T_SYNC();
     };
     auto cand_hidden = [&](int cn, const float *mq, float *hid) {
-        T_FOR(i, cn * h0) {
-            const int q = i / h0, j = i - q * h0;
-            const float *a = Aeff + (int64_t)j * D, *x = mq + (int64_t)q * D;
-            float acc = cst[j];
+        T_FOR_J(j, h0) {
+            float a[D];
 #pragma unroll
-            for (int c = 0; c < D; ++c) acc = fmaf(a[c], x[c], acc);
-            hid[i] = t_tanh(acc);
+            for (int c = 0; c < D; ++c) a[c] = Aeff[j * D + c];
+            const float cj = cst[j];
+            T_FOR_V(q, cn, h0) {
+                const float *x = mq + (int64_t)q * D;
+                float acc = cj;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc = fmaf(a[c], x[c], acc);
+                hid[q * h0 + j] = t_tanh(acc);
+            }
         }
         T_SYNC();
     };
     if (land || road) {
+        T_FOR(q, nc) {
+            if (land) {
+                cl_a[q] = hsrc[q];
+                cl_b[q] = hdst[q];
+                cl_live[q] = hlive[q];
+            } else {
+                cl_a[q] = rnn[q];
+            }
+        }
         if (land) {
             // W1 [m; c; m*c; m-c] = ((Wa + Wd) + Wc diag(c)) m + (Wb - Wd) c: per-graph effective weight + per-graph bias
             const float *W1 = prm + o.land_w0;
@@ -450,6 +630,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             T_FOR(j, h0) {
                 const float *w = W1 + (int64_t)j * 4 * D;
                 float acc = prm[o.land_b0 + j];
+#pragma unroll
                 for (int c = 0; c < D; ++c) acc = fmaf(w[D + c] - w[3 * D + c], C[c], acc);
                 cst[j] = acc;
                 w2v[j] = prm[o.land_w1 + j];
@@ -463,8 +644,8 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         }
         T_SYNC();
         for (int c0 = 0; c0 < nc; c0 += CH) {
-            const int cn = nc - c0 < CH ? nc - c0 : CH;
-            float *mq = chunk, *hid = chunk + CH * D;
+            const int cn = imin(nc - c0, CH);
+            float *mq = chunk, *hid = chunk + (int64_t)CH * D;
             cand_inputs(c0, cn, mq);
             cand_hidden(cn, mq, hid);
             T_FOR(q, cn) {
@@ -481,60 +662,58 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             part[g] = mx;
         }
         T_SYNC();
-        if (T_TID0) {
+        T_FOR(g, NG) {
             float mx = -INFINITY;
-            for (int g = 0; g < NG; ++g) mx = fmaxf(mx, part[g]);
-            scal[0] = mx;
+            for (int gg = 0; gg < NG; ++gg) mx = fmaxf(mx, part[gg]);
+            float sum = 0.0f;
+            for (int q = g; q < nc; q += NG) sum += t_exp(z[q] - mx);
+            part[NG + g] = sum;
+            if (g == 0) scal[0] = mx;
         }
         T_SYNC();
         T_FOR(g, NG) {
             float sum = 0.0f;
-            for (int q = g; q < nc; q += NG) sum += t_exp(z[q] - scal[0]);
-            part[g] = sum;
-        }
-        T_SYNC();
-        if (T_TID0) {
-            float sum = 0.0f;
-            for (int g = 0; g < NG; ++g) sum += part[g];
-            scal[1] = scal[0] + t_log(sum);
-        }
-        T_SYNC();
-        T_FOR(g, NG) {
+            for (int gg = 0; gg < NG; ++gg) sum += part[NG + gg];
+            const float lse = scal[0] + t_log(sum);
             float pz = 0.0f;
             for (int q = g; q < nc; q += NG) {
-                const float lp = z[q] - scal[1];
+                const float lp = z[q] - lse;
                 pz += t_exp(lp) * lp;
             }
-            part[g] = pz;
+            part[2 * NG + g] = pz;
+            if (g == 0) scal[1] = lse;
         }
         T_SYNC();
-        if (T_TID0) {
+        T_FOR(g, 1) {
             float pz = 0.0f;
-            for (int g = 0; g < NG; ++g) pz += part[g];
+            for (int gg = 0; gg < NG; ++gg) pz += part[2 * NG + gg];
             scal[2] = -pz;
             scal[3] = (act >= 0 ? z[act] : PAD_LOGIT) - scal[1];
         }
-        T_SYNC();
         float *zout = land ? A.z_he : A.z_rn;
         if (zout) {
             const int64_t zo = land ? A.he_off[b] : A.rn_off[b];
             T_FOR(q, nc) zout[zo + q] = z[q];
         }
+        T_SYNC();
     } else {
         // a row of another stage, or without any valid candidate (every logit is the pad constant, whose logsumexp is
         // absorbed in fp32): log-prob = entropy = 0 (policy.py:90-91)
-        if (T_TID0) {
+        T_FOR(g, 1) {
             scal[1] = 0.0f;
             scal[2] = 0.0f;
             scal[3] = 0.0f;
         }
         T_SYNC();
     }
+    T_MARK(8);
     const float value = V[d.n_value][0], logp = scal[3], entr = scal[2];
-    if (A.mode != BWD && T_TID0) {
-        A.value[b] = value;
-        A.logp[b] = logp;
-        A.ent[b] = entr;
+    if (A.mode != BWD) {
+        T_FOR(g, 1) {
+            A.value[b] = value;
+            A.logp[b] = logp;
+            A.ent[b] = entr;
+        }
     }
     if (!bwd) {
         T_SYNC();
@@ -563,7 +742,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             gl = -dsdr * ratio * A.inv_ind;
             ge = -A.ce * A.inv_ind;
         }
-        if (T_TID0) {
+        T_FOR(g, 1) {
             A.loss_rows[(int64_t)b * 4 + 0] = diff * diff;
             A.loss_rows[(int64_t)b * 4 + 1] = smin;
             A.loss_rows[(int64_t)b * 4 + 2] = sent;
@@ -576,81 +755,85 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     }
 
     // =============================================================================== backward
+    T_MARK(9);
     float *G = slab;                             // gradient slab of this workgroup (parameter layout)
-    // ---- value head (value.py:15-39)
+    // ---- value head (value.py:15-39): one phase per layer
     {
         float *dz = dVa, *dn = dVb;
-        if (T_TID0) dz[0] = gv;
+        T_FOR(g, 1) dz[0] = gv;
         T_SYNC();
         for (int i = d.n_value - 1; i >= 0; --i) {
             const int N = d.value_hidden[i], K = i == 0 ? d.W : d.value_hidden[i - 1];
-            if (i < d.n_value - 1) {
-                T_FOR(j, N) dz[j] *= 1.0f - V[i + 1][j] * V[i + 1][j];
-                T_SYNC();
-            }
-            outer_acc(G + o.value_w[i], G + o.value_b[i], dz, V[i], N, K);
-            float *dst = i == 0 ? dSV : dn;
-            lin_t(dst, dz, prm + o.value_w[i], N, K);
-            if (i > 0) {
-                float *tmp = dz;
-                dz = dn;
-                dn = tmp;
-            }
+            mlp_layer_bwd(G + o.value_w[i], G + o.value_b[i], i == 0 ? dSV : dn, dz, V[i], prm + o.value_w[i], i == 0 ? nullptr : V[i],
+                          N, K);
+            float *tmp = dz;
+            dz = dn;
+            dn = tmp;
         }
     }
     const float *dhbarV = dSV + d.S_last, *dhbarE = dSV + d.S_last + D, *datt = dSV + d.S_last + 2 * D;
+    T_MARK(10);
     // ---- numerical encoder
     {
         float *dz = dVa, *dn = dVb;
-        T_FOR(j, d.S_last) dz[j] = dSV[j];
+        T_FOR(j, d.S_last) dz[j] = dSV[j] * (1.0f - U[d.n_num][j] * U[d.n_num][j]);
         T_SYNC();
         for (int i = d.n_num - 1; i >= 0; --i) {
             const int N = d.num_hidden[i], K = i == 0 ? d.Fn : d.num_hidden[i - 1];
-            T_FOR(j, N) dz[j] *= 1.0f - U[i + 1][j] * U[i + 1][j];
-            T_SYNC();
-            outer_acc(G + o.num_w[i], G + o.num_b[i], dz, U[i], N, K);
-            if (i > 0) {
-                lin_t(dn, dz, prm + o.num_w[i], N, K);
-                float *tmp = dz;
-                dz = dn;
-                dn = tmp;
-            }
+            mlp_layer_bwd(G + o.num_w[i], G + o.num_b[i], i == 0 ? nullptr : dn, dz, U[i], prm + o.num_w[i], i == 0 ? nullptr : U[i], N,
+                          K);
+            float *tmp = dz;
+            dz = dn;
+            dn = tmp;
         }
     }
-    // ---- attention, the part behind the softmax: out-projection, value projections
-    outer_acc(G + o.outproj_w, G + o.outproj_b, datt, ov, D, D);
-    lin_t(dov, datt, prm + o.outproj_w, D, D);
+    T_MARK(11);
+    // ---- attention, the part behind the softmax: out-projection (weight gradient + do in one phase), value projections
+    mlp_layer_bwd(G + o.outproj_w, G + o.outproj_b, dov, datt, ov, prm + o.outproj_w, nullptr, D, D);
     // o[i] = Wiv[i] . u_h(i) + biv[i]:  dbiv += do;  dWiv[i][k] += do[i] u_h(i)[k];  du_h[k] = sum_{i in h} Wiv[i][k] do[i]
-    T_FOR(i, D * D) {
-        const int r = i / D, k = i - r * D;
-        G[o.inproj_w + (int64_t)(2 * D + r) * D + k] += dov[r] * uu[(r / dh) * D + k];
+    T_FOR(i, D * D + D + Hn * D) {
+        if (i < D * D) {
+            const int r = i / D, k = i - r * D;
+            G[o.inproj_w + (int64_t)(2 * D + r) * D + k] += dov[r] * uu[(r / dh) * D + k];
+        } else if (i < D * D + D) {
+            G[o.inproj_b + 2 * D + i - D * D] += dov[i - D * D];
+        } else {
+            const int ii = i - D * D - D, h = ii / D, k = ii - h * D;
+            du[ii] = dot_t(prm + o.inproj_w + (int64_t)2 * D * D, D, k, dov, h * dh, (h + 1) * dh);
+        }
     }
-    T_FOR(i, D) G[o.inproj_b + 2 * D + i] += dov[i];
     T_SYNC();
-    for (int h = 0; h < Hn; ++h) lin_t(du + h * D, dov, prm + o.inproj_w + (int64_t)2 * D * D, D, D, h * dh, (h + 1) * dh);
     // u_h = Wv s_h + bv:  dbv += sum_h du_h;  dWv[j][k] += sum_h du_h[j] s_h[k];  ds_h = Wv^T du_h
-    T_FOR(i, D * D) {
-        const int j = i / D, k = i - j * D;
-        float acc = 0.0f;
-        for (int h = 0; h < Hn; ++h) acc += du[h * D + j] * ss[h * D + k];
-        G[o.v_w + i] += acc;
-    }
-    T_FOR(j, D) {
-        float acc = 0.0f;
-        for (int h = 0; h < Hn; ++h) acc += du[h * D + j];
-        G[o.v_b + j] += acc;
+    T_FOR(i, D * D + D + Hn * D) {
+        if (i < D * D) {
+            const int j = i / D, k = i - j * D;
+            float acc = 0.0f;
+            for (int h = 0; h < Hn; ++h) acc += du[h * D + j] * ss[h * D + k];
+            G[o.v_w + i] += acc;
+        } else if (i < D * D + D) {
+            const int j = i - D * D;
+            float acc = 0.0f;
+            for (int h = 0; h < Hn; ++h) acc += du[h * D + j];
+            G[o.v_b + j] += acc;
+        } else {
+            const int ii = i - D * D - D, h = ii / D, k = ii - h * D;
+            ds[ii] = dot_t(prm + o.v_w, D, k, du + h * D, 0, D);
+        }
     }
     T_SYNC();
-    for (int h = 0; h < Hn; ++h) lin_t(ds + h * D, du + h * D, prm + o.v_w, D, D);
+    T_MARK(12);
     // ---- attention core per head: t_j = ds . h_j, T = sum alpha t, dscore_j = alpha_j (t_j - T), dr = sum_j dscore_j h_j
+    //      (alpha is normalised here: alpha[] held exp(score - max), scal[8 + h] its normaliser)
     for (int h = 0; h < Hn; ++h) {
-        float *tj = sc + (int64_t)h * n;
-        const float *al = alpha + (int64_t)h * n, *dsv = ds + h * D;
+        float *tj = sc + (int64_t)h * n, *al = alpha + (int64_t)h * n;
+        const float *dsv = ds + h * D;
+        const float inv = scal[8 + h];
         T_FOR(v, n) {
             float acc = 0.0f;
 #pragma unroll
             for (int k = 0; k < D; ++k) acc = fmaf(dsv[k], HL[v * D + k], acc);
             tj[v] = acc;
+            al[v] *= inv;
         }
         T_SYNC();
         T_FOR(g, NG) {
@@ -659,31 +842,42 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             part[g] = sum;
         }
         T_SYNC();
-        if (T_TID0) {
-            float sum = 0.0f;
-            for (int g = 0; g < NG; ++g) sum += part[g];
-            scal[6] = sum;
+        T_FOR(v, n) {
+            float T = 0.0f;
+            for (int g = 0; g < NG; ++g) T += part[g];
+            tj[v] = al[v] * (tj[v] - T);         // dscore_j (0 on nodes outside the mask: alpha = 0)
         }
         T_SYNC();
-        T_FOR(v, n) tj[v] = al[v] * (tj[v] - scal[6]);       // dscore_j (0 on nodes outside the mask: alpha = 0)
+        T_FOR(i, NG * D) {
+            const int g = i / D, c = i - g * D;
+            float acc = 0.0f;
+            for (int v = g; v < n; v += NG) acc = fmaf(tj[v], HL[v * D + c], acc);
+            part[i] = acc;
+        }
         T_SYNC();
-        colsum(dr + h * D, part, n, D, 1.0f, [&](int v, int c) { return tj[v] * HL[v * D + c]; });
+        T_FOR(c, D) {
+            float acc = 0.0f;
+            for (int g = 0; g < NG; ++g) acc += part[g * D + c];
+            dr[h * D + c] = acc;
+        }
+        T_SYNC();
     }
+    T_MARK(13);
     // ---- pointer head (before H^L is overwritten by G^L): dz, second + first Linear, candidate inputs
-    T_FOR(i, imax(d.h0l, d.h0r) * D) Mj[i] = 0.0f;
-    T_FOR(i, imax(d.h0l, d.h0r)) {
+    T_FOR(i, h0m * D) Mj[i] = 0.0f;
+    T_FOR(i, h0m) {
         sj[i] = 0.0f;
         dw2[i] = 0.0f;
     }
     T_FOR(i, D) dC[i] = 0.0f;
     T_SYNC();
-    float *dXR = PQ;                             // road rows only: [nc][D] gradient of the candidates' H^L rows (P | Q is free)
     float *dMg = gscr;                           // land rows: [nc][D] gradient of the candidates' messages (global scratch)
+    float *dXR = PQ;                             // road rows only: [nc][D] gradient of the candidates' H^L rows (P | Q is free)
     if (land || road) {
         const float lse = scal[1], Hent = scal[2];
         for (int c0 = 0; c0 < nc; c0 += CH) {
-            const int cn = nc - c0 < CH ? nc - c0 : CH;
-            float *mq = chunk, *hid = chunk + CH * D, *dpre = chunk + CH * D + CH * h0;
+            const int cn = imin(nc - c0, CH);
+            float *mq = chunk, *hid = chunk + (int64_t)CH * D, *dpre = chunk + (int64_t)CH * (D + h0);
             cand_inputs(c0, cn, mq);
             cand_hidden(cn, mq, hid);
             // dz_k = dlogp (delta_ka - p_k) - dent p_k (log p_k + H);  dpre[k][j] = dz_k w2[j] (1 - hid^2)
@@ -697,30 +891,32 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 hid[i] = dz * hv;                 // (dz hid: the summand of dw2)
             }
             T_SYNC();
-            // running sums over the candidates: dw2, db1 (= s), M[j][c] = sum dpre[k][j] m[k][c]
-            T_FOR(j, h0) {
-                float a1 = dw2[j], a2 = sj[j];
-                for (int q = 0; q < cn; ++q) {
-                    a1 += hid[q * h0 + j];
-                    a2 += dpre[q * h0 + j];
+            // running sums over the candidates: dw2, db1 (= s), M[j][c] = sum dpre[k][j] m[k][c];  and the gradient of the
+            // candidate inputs dm[k][c] = sum_j A[j][c] dpre[k][j]  (land: only live candidates carry it on)
+            T_FOR(i, h0 + h0 * D) {
+                if (i < h0) {
+                    float a1 = dw2[i], a2 = sj[i];
+                    for (int q = 0; q < cn; ++q) {
+                        a1 += hid[q * h0 + i];
+                        a2 += dpre[q * h0 + i];
+                    }
+                    dw2[i] = a1;
+                    sj[i] = a2;
+                } else {
+                    const int ii = i - h0, j = ii / D, c = ii - j * D;
+                    float acc = Mj[ii];
+                    for (int q = 0; q < cn; ++q) acc = fmaf(dpre[q * h0 + j], mq[q * D + c], acc);
+                    Mj[ii] = acc;
                 }
-                dw2[j] = a1;
-                sj[j] = a2;
             }
-            T_FOR(i, h0 * D) {
-                const int j = i / D, c = i - j * D;
-                float acc = Mj[i];
-                for (int q = 0; q < cn; ++q) acc = fmaf(dpre[q * h0 + j], mq[q * D + c], acc);
-                Mj[i] = acc;
-            }
-            // gradient of the candidate inputs: dm[k][c] = sum_j A[j][c] dpre[k][j]  (land: only live candidates carry it on)
             float *dst = land ? dMg : dXR;
-            T_FOR(i, cn * D) {
-                const int q = i / D, c = i - q * D;
-                float acc = 0.0f;
-                for (int j = 0; j < h0; ++j) acc = fmaf(Aeff[j * D + c], dpre[q * h0 + j], acc);
-                if (land && !hlive[c0 + q]) acc = 0.0f;
-                dst[(int64_t)(c0 + q) * D + c] = acc;
+            T_FOR_J(c, D) {
+                T_FOR_V(q, cn, D) {
+                    float acc = 0.0f;
+                    for (int j = 0; j < h0; ++j) acc = fmaf(Aeff[j * D + c], dpre[q * h0 + j], acc);
+                    if (land && !cl_live[c0 + q]) acc = 0.0f;
+                    dst[(int64_t)(c0 + q) * D + c] = acc;
+                }
             }
             T_SYNC();
         }
@@ -728,26 +924,28 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             // feat = [m; c; m*c; m-c]:  dWa += M,  dWb += s (x) c,  dWc += M * c,  dWd += M - s (x) c;  db1 += s;  dw2
             // dC[c] += sum_j (Wb - Wd)[j][c] s[j] + Wc[j][c] M[j][c]
             const float *W1 = prm + o.land_w0;
-            T_FOR(i, h0 * D) {
-                const int j = i / D, c = i - j * D;
-                float *g = G + o.land_w0 + (int64_t)j * 4 * D;
-                const float Mv = Mj[i], sc_ = sj[j] * C[c];
-                g[c] += Mv;
-                g[D + c] += sc_;
-                g[2 * D + c] += Mv * C[c];
-                g[3 * D + c] += Mv - sc_;
-            }
-            T_FOR(j, h0) {
-                G[o.land_b0 + j] += sj[j];
-                G[o.land_w1 + j] += dw2[j];
-            }
-            T_FOR(c, D) {
-                float acc = 0.0f;
-                for (int j = 0; j < h0; ++j) {
-                    const float *w = W1 + (int64_t)j * 4 * D;
-                    acc += (w[D + c] - w[3 * D + c]) * sj[j] + w[2 * D + c] * Mj[j * D + c];
+            T_FOR(i, h0 * D + h0 + D) {
+                if (i < h0 * D) {
+                    const int j = i / D, c = i - j * D;
+                    float *g = G + o.land_w0 + (int64_t)j * 4 * D;
+                    const float Mv = Mj[i], sc_ = sj[j] * C[c];
+                    g[c] += Mv;
+                    g[D + c] += sc_;
+                    g[2 * D + c] += Mv * C[c];
+                    g[3 * D + c] += Mv - sc_;
+                } else if (i < h0 * D + h0) {
+                    const int j = i - h0 * D;
+                    G[o.land_b0 + j] += sj[j];
+                    G[o.land_w1 + j] += dw2[j];
+                } else {
+                    const int c = i - h0 * D - h0;
+                    float acc = 0.0f;
+                    for (int j = 0; j < h0; ++j) {
+                        const float *w = W1 + (int64_t)j * 4 * D;
+                        acc += (w[D + c] - w[3 * D + c]) * sj[j] + w[2 * D + c] * Mj[j * D + c];
+                    }
+                    dC[c] = acc;
                 }
-                dC[c] = acc;
             }
         } else {
             T_FOR(i, h0 * D) G[o.road_w0 + i] += Mj[i];
@@ -758,70 +956,78 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         }
         T_SYNC();
     }
+    T_MARK(14);
     // ---- G^L in place of H^L: masked-mean share + attention terms (+ the road candidates' rows)
-    T_FOR(i, nD) {
-        const int v = i / D, c = i - v * D;
-        float g = nmg[v] ? dhbarV[c] / (float)m[6] : 0.0f;
-        for (int h = 0; h < Hn; ++h) g += alpha[(int64_t)h * n + v] * ds[h * D + c] + sc[(int64_t)h * n + v] * rr[h * D + c];
-        HL[i] = g;
+    T_FOR_J(c, D) {
+        const float gm = dhbarV[c] / (float)m[6];
+        T_FOR_V(v, n, D) {
+            float g = nmg[v] ? gm : 0.0f;
+            for (int h = 0; h < Hn; ++h) g += alpha[(int64_t)h * n + v] * ds[h * D + c] + sc[(int64_t)h * n + v] * rr[h * D + c];
+            HL[v * D + c] = g;
+        }
     }
     T_SYNC();
     if (road) {
         T_FOR(i, nc * D) {                       // road_mask slots are distinct nodes: one writer per element
             const int q = i / D, c = i - q * D;
-            HL[rnn[q] * D + c] += dXR[i];
+            HL[cl_a[q] * D + c] += dXR[i];
         }
         T_SYNC();
     }
     float *Gn = HL;
+    T_MARK(15);
     // ---- attention, the query chain:  r_h = Wk^T tk_h,  tk_h = Wik[head rows]^T q1[head rows]
-    for (int h = 0; h < Hn; ++h) {
-        // dtk_h[j] = sum_d Wk[j][d] dr_h[d]
-        T_FOR(j, D) {
-            float acc = 0.0f;
-            for (int k = 0; k < D; ++k) acc = fmaf(prm[o.k_w + j * D + k], dr[h * D + k], acc);
-            dtk[h * D + j] = acc;
-        }
-        T_SYNC();
-    }
-    T_FOR(i, D * D) {                            // dWk[j][d] += sum_h tk_h[j] dr_h[d]
-        const int j = i / D, k = i - j * D;
-        float acc = 0.0f;
-        for (int h = 0; h < Hn; ++h) acc += tk[h * D + j] * dr[h * D + k];
-        G[o.k_w + i] += acc;
-    }
-    T_FOR(i, D * D) {                            // dWik[r][j] += q1[r] dtk_h(r)[j]
-        const int r = i / D, j = i - r * D;
-        G[o.inproj_w + (int64_t)(D + r) * D + j] += q1[r] * dtk[(r / dh) * D + j];
-    }
-    T_FOR(r, D) {                                // dq1[r] = sum_j Wik[r][j] dtk_h(r)[j]
-        const float *w = prm + o.inproj_w + (int64_t)(D + r) * D, *dt = dtk + (r / dh) * D;
-        float acc = 0.0f;
-        for (int j = 0; j < D; ++j) acc = fmaf(w[j], dt[j], acc);
-        dq1[r] = acc * scale;                    // through q1 = (Wiq q0 + biq) * scale
+    T_FOR(i, Hn * D) {                           // dtk_h[j] = sum_d Wk[j][d] dr_h[d]
+        const int h = i / D, j = i - h * D;
+        dtk[i] = dot_g(prm + o.k_w + (int64_t)j * D, dr + h * D, D);
     }
     T_SYNC();
-    outer_acc(G + o.inproj_w, G + o.inproj_b, dq1, q0, D, D);
-    lin_t(dq0, dq1, prm + o.inproj_w, D, D);
-    outer_acc(G + o.q_w, G + o.q_b, dq0, C, D, D);
-    T_FOR(c, D) {
-        float acc = dC[c];
-        for (int j = 0; j < D; ++j) acc = fmaf(prm[o.q_w + j * D + c], dq0[j], acc);
-        dC[c] = acc;
+    T_FOR(i, 2 * D * D + D) {
+        if (i < D * D) {                         // dWk[j][d] += sum_h tk_h[j] dr_h[d]
+            const int j = i / D, k = i - j * D;
+            float acc = 0.0f;
+            for (int h = 0; h < Hn; ++h) acc += tk[h * D + j] * dr[h * D + k];
+            G[o.k_w + i] += acc;
+        } else if (i < 2 * D * D) {              // dWik[r][j] += q1[r] dtk_h(r)[j]
+            const int ii = i - D * D, r = ii / D, j = ii - r * D;
+            G[o.inproj_w + (int64_t)(D + r) * D + j] += q1[r] * dtk[(r / dh) * D + j];
+        } else {                                 // dq1[r] = sum_j Wik[r][j] dtk_h(r)[j], through q1 = (Wiq q0 + biq) * scale
+            const int r = i - 2 * D * D;
+            dq1[r] = dot_g(prm + o.inproj_w + (int64_t)(D + r) * D, dtk + (r / dh) * D, D) * scale;
+        }
+    }
+    T_SYNC();
+    mlp_layer_bwd(G + o.inproj_w, G + o.inproj_b, dq0, dq1, q0, prm + o.inproj_w, nullptr, D, D);
+    // q0 = Wq C + bq:  dWq, dbq;  dC += Wq^T dq0 (on top of the land-use head's share)
+    T_FOR(i, D * D + 2 * D) {
+        if (i < D * D) {
+            const int j = i / D, k = i - j * D;
+            G[o.q_w + i] += dq0[j] * C[k];
+        } else if (i < D * D + D) {
+            G[o.q_b + i - D * D] += dq0[i - D * D];
+        } else {
+            const int c = i - D * D - D;
+            dC[c] += dot_t(prm + o.q_w, D, c, dq0, 0, D);
+        }
     }
     T_SYNC();
     // current node's pass through the node encoder
-    outer_acc(G + o.node_w, G + o.node_b, dC, cur, D, d.F);
+    outer_acc(G + o.node_w, G + o.node_b, dC, cur, D, F);
+    T_MARK(16);
 
     // ---- GCN layers, last to first (:110-148,194-197).  Per layer in two column halves: P | Q of the half in PQ[0 .. nD),
     // dP | dQ of the half in PQ[nD .. 2 nD).  Row layout of a half: [v][0 .. D/2) = P columns, [v][D/2 .. D) = Q columns.
     constexpr int HC = D / 2;
+    constexpr int NGW = D == 16 ? 4 : 1;         // node groups of the weight-gradient partial sums (NGW * D * D partials)
     float *PQh = PQ, *dPQh = PQ + nD, *dS = Xr;
     for (int l = L; l >= 1; --l) {
         const bool last = l == L;
         float *Hprev;
+        if (l == L - 1) T_MARK(17);
         if (l == 1) {
             Hprev = slotH(1);                    // H^1 is dead (layer 2 is done): recompute H^0 in its place
+            stage_x();
+            T_SYNC();
             encode_nodes(Hprev);
         } else {
             Hprev = slotH(l - 1);
@@ -829,93 +1035,127 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         const float *Wl = prm + o.edge_w[l - 1], *bl = prm + o.edge_b[l - 1];
         float *gW = G + o.edge_w[l - 1], *gB = G + o.edge_b[l - 1];
         // dS_v = G_v / (deg_v + 1e-6) (+ 1/2 dhbarE / e on the last layer)
-        T_FOR(i, nD) {
-            const int v = i / D, c = i - v * D;
-            float x = Gn[i] / ((float)(rp[v + 1] - rp[v]) + 1e-6f);
-            if (last) x += 0.5f * dhbarE[c] / (float)e;
-            dS[i] = x;
+        T_FOR_J(c, D) {
+            const float ex = last ? 0.5f * dhbarE[c] / (float)e : 0.0f;
+            T_FOR_V(v, n, D) dS[v * D + c] = fmaf(Gn[v * D + c], t_rcp((float)(rp[v + 1] - rp[v]) + 1e-6f), ex);
         }
         T_SYNC();
+        const bool ef = bad[l] == 0;             // the forward's verdict on this layer's P | Q (same values: same form)
         for (int half = 0; half < 2; ++half) {
             const int cb = half * HC;
-            // P | Q of the half
-            T_FOR(i, nD) {
-                const int v = i / D, jj = i - v * D;
-                const int side = jj / HC, c = cb + jj % HC;
-                const float *w = Wl + (int64_t)c * (2 * D) + side * D, *h = Hprev + (int64_t)v * D;
-                float acc = 0.0f;
+            // P | Q of the half (thread = one of its D columns, weight row in registers), in exp form where the layer allows it
+            T_FOR_J(jj, D) {
+                float w[D];
+                const float *wr = Wl + (int64_t)(cb + jj % HC) * (2 * D) + (jj / HC) * D;
 #pragma unroll
-                for (int k = 0; k < D; ++k) acc = fmaf(w[k], h[k], acc);
-                PQh[i] = acc;
+                for (int k = 0; k < D; ++k) w[k] = wr[k];
+                T_FOR_V(v, n, D) {
+                    const float *h = Hprev + (int64_t)v * D;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc = fmaf(w[k], h[k], acc);
+                    PQh[v * D + jj] = ef ? t_exp2(C2 * acc) : acc;
+                }
             }
             T_SYNC();
             // dP_v = sum_u 1/2 dm (1 - tanh^2(P_v + Q_u + b)),  dQ_v = sum_u 1/2 dm (1 - tanh^2(P_u + Q_v + b)),
             // dm = dS_v + dS_u; the row's candidate edges add their head gradient on the last layer (packer's
-            // candidate-incidence lists: neighbour + candidate index per incident live candidate)
-            T_FOR(i, n * HC) {
-                const int v = i / HC, cc = i - v * HC, c = cb + cc;
-                const float bc = bl[c];
-                const float pv = PQh[v * D + cc] + bc, qv = PQh[v * D + HC + cc] + bc, sv = dS[v * D + c];
-                float aP = 0.0f, aQ = 0.0f;
-                for (int k = rp[v]; k < rp[v + 1]; ++k) {
-                    const int u = nb[k];
-                    const float dm = sv + dS[u * D + c];
-                    const float t1 = t_tanh(pv + PQh[u * D + HC + cc]), t2 = t_tanh(PQh[u * D + cc] + qv);
-                    aP = fmaf(0.5f * dm, 1.0f - t1 * t1, aP);
-                    aQ = fmaf(0.5f * dm, 1.0f - t2 * t2, aQ);
-                }
-                if (last && land) {
-                    for (int k = hpg[v]; k < hpg[v + 1]; ++k) {
-                        const int u = hnb[k];
-                        const float dm = dMg[(int64_t)hhe[k] * D + c];
-                        const float t1 = t_tanh(pv + PQh[u * D + HC + cc]), t2 = t_tanh(PQh[u * D + cc] + qv);
-                        aP = fmaf(0.5f * dm, 1.0f - t1 * t1, aP);
-                        aQ = fmaf(0.5f * dm, 1.0f - t2 * t2, aQ);
+            // candidate-incidence lists: neighbour + candidate index per incident live candidate).
+            // exp form: 1 - tanh^2 = 4 (r - r^2) with r = 1 / (1 + E)
+            T_FOR_J(cc, HC) {
+                const int c = cb + cc;
+                const float bc = bl[c], eb = t_exp2(C2 * bc);
+                T_FOR_V(v, n, HC) {
+                    const float sv = dS[v * D + c];
+                    const float pv = ef ? PQh[v * D + cc] * eb : PQh[v * D + cc] + bc;
+                    const float qv = ef ? PQh[v * D + HC + cc] * eb : PQh[v * D + HC + cc] + bc;
+                    float aP = 0.0f, aQ = 0.0f;
+                    // one edge term: neighbour u, edge gradient dm
+                    auto term = [&](int u, float dm) {
+                        if (ef) {
+                            const float r1 = t_rcp(fmaf(pv, PQh[u * D + HC + cc], 1.0f)), r2 = t_rcp(fmaf(PQh[u * D + cc], qv, 1.0f));
+                            aP = fmaf(2.0f * dm, fmaf(-r1, r1, r1), aP);
+                            aQ = fmaf(2.0f * dm, fmaf(-r2, r2, r2), aQ);
+                        } else {
+                            const float t1 = t_tanh(pv + PQh[u * D + HC + cc]), t2 = t_tanh(PQh[u * D + cc] + qv);
+                            aP = fmaf(0.5f * dm, 1.0f - t1 * t1, aP);
+                            aQ = fmaf(0.5f * dm, 1.0f - t2 * t2, aQ);
+                        }
+                    };
+                    for (int k = rp[v]; k < rp[v + 1]; ++k) {
+                        const int u = nb[k];
+                        term(u, sv + dS[u * D + c]);
                     }
+                    if (last && land) {
+                        for (int k = hpg[v]; k < hpg[v + 1]; ++k) term(hnb[k], dMg[(int64_t)hhe[k] * D + c]);
+                    }
+                    dPQh[v * D + cc] = aP;
+                    dPQh[v * D + HC + cc] = aQ;
                 }
-                dPQh[v * D + cc] = aP;
-                dPQh[v * D + HC + cc] = aQ;
             }
             T_SYNC();
-            // weight / bias gradient of the half's rows:  dW[c][side * D + k] += sum_v d(side)_v[c] H_v[k];  db[c] += sum_v dP_v[c]
-            T_FOR(i, D * D) {
-                const int jj = i / D, k = i - jj * D;
-                const int side = jj / HC, c = cb + jj % HC;
-                float acc = 0.0f;
-                for (int v = 0; v < n; ++v) acc = fmaf(dPQh[v * D + jj], Hprev[v * D + k], acc);
-                gW[(int64_t)c * (2 * D) + side * D + k] += acc;
-            }
-            T_FOR(cc, HC) {
-                float acc = 0.0f;
-                for (int v = 0; v < n; ++v) acc += dPQh[v * D + cc];
-                gB[cb + cc] += acc;
-            }
+            // partial sums over fixed node groups of the half's weight gradient (rows c of [Wa | Wb]) and bias gradient, and the
             // dgrad in place: G_v[k] += sum_c dP_v[c] Wa[c][k] + dQ_v[c] Wb[c][k]   (the walks read dS, not G)
-            T_FOR(i, nD) {
-                const int v = i / D, k = i - v * D;
-                float acc = Gn[i];
-                for (int jj = 0; jj < D; ++jj) {
-                    const int side = jj / HC, c = cb + jj % HC;
-                    acc = fmaf(dPQh[v * D + jj], Wl[(int64_t)c * (2 * D) + side * D + k], acc);
+            T_FOR(i, NGW * D * D + NG * HC) {
+                if (i < NGW * D * D) {
+                    const int g = i / (D * D), r = i - g * D * D, jj = r / D, k = r - jj * D;
+                    float acc = 0.0f;
+                    for (int v = g; v < n; v += NGW) acc = fmaf(dPQh[v * D + jj], Hprev[v * D + k], acc);
+                    part[i] = acc;
+                } else {
+                    const int ii = i - NGW * D * D, g = ii / HC, cc = ii - g * HC;
+                    float acc = 0.0f;
+                    for (int v = g; v < n; v += NG) acc += dPQh[v * D + cc];
+                    part[i] = acc;
                 }
-                Gn[i] = acc;
+            }
+            T_FOR_J(k, D) {
+                float w[D];
+#pragma unroll
+                for (int jj = 0; jj < D; ++jj) w[jj] = Wl[(int64_t)(cb + jj % HC) * (2 * D) + (jj / HC) * D + k];
+                T_FOR_V(v, n, D) {
+                    const float *dp = dPQh + (int64_t)v * D;
+                    float acc = Gn[v * D + k];
+#pragma unroll
+                    for (int jj = 0; jj < D; ++jj) acc = fmaf(dp[jj], w[jj], acc);
+                    Gn[v * D + k] = acc;
+                }
+            }
+            T_SYNC();
+            // fixed-order combine into the slab:  dW[c][side * D + k],  db[c] += sum_v dP_v[c]
+            T_FOR(i, D * D + HC) {
+                if (i < D * D) {
+                    const int jj = i / D, k = i - jj * D;
+                    float acc = 0.0f;
+                    for (int g = 0; g < NGW; ++g) acc += part[g * D * D + i];
+                    gW[(int64_t)(cb + jj % HC) * (2 * D) + (jj / HC) * D + k] += acc;
+                } else {
+                    const int cc = i - D * D;
+                    float acc = 0.0f;
+                    for (int g = 0; g < NG; ++g) acc += part[NGW * D * D + g * HC + cc];
+                    gB[cb + cc] += acc;
+                }
             }
             T_SYNC();
         }
     }
-    // ---- node encoder on every node: dWe += G^0^T X, dbe += colsum(G^0)
-    T_FOR(i, D * d.F) {
-        const int c = i / d.F, f = i - c * d.F;
+    T_MARK(19);
+    // ---- node encoder on every node: dWe += G^0^T X, dbe += colsum(G^0)   (X staged once more: P | Q is dead)
+    stage_x();
+    T_SYNC();
+    T_FOR(i, D * (F + 1)) {
+        const int c = i / (F + 1), f = i - c * (F + 1);
         float acc = 0.0f;
-        for (int v = 0; v < n; ++v) acc = fmaf(Gn[v * D + c], Xg[(int64_t)v * XPAD + f], acc);
-        G[o.node_w + i] += acc;
-    }
-    T_FOR(c, D) {
-        float acc = 0.0f;
-        for (int v = 0; v < n; ++v) acc += Gn[v * D + c];
-        G[o.node_b + c] += acc;
+        if (f < F) {
+            for (int v = 0; v < n; ++v) acc = fmaf(Gn[v * D + c], Xs[v * XPAD + f], acc);
+            G[o.node_w + (int64_t)c * F + f] += acc;
+        } else {
+            for (int v = 0; v < n; ++v) acc += Gn[v * D + c];
+            G[o.node_b + c] += acc;
+        }
     }
     T_SYNC();
+    T_MARK(20);
 }
 
 }  // namespace upamd_tiny

@@ -43,7 +43,7 @@ class Minibatch(C.Structure):
     _fields_ = [('B', C.c_int32), ('n_nodes', C.c_int64), ('n_he', C.c_int64), ('n_rn', C.c_int64),
                 ('max_n', C.c_int32), ('max_inc', C.c_int32), ('idx_dev', C.c_void_p), ('node_off_dev', C.c_void_p),
                 ('he_off_dev', C.c_void_p), ('rn_off_dev', C.c_void_p),
-                ('n_inc', C.c_int64), ('inc_off_dev', C.c_void_p)]
+                ('n_inc', C.c_int64), ('inc_off_dev', C.c_void_p), ('max_cand', C.c_int32)]
 
 
 # every symbol include/upamd.h declares: (restype, argtypes)
@@ -88,6 +88,7 @@ SYMBOLS = {
     'upamd_gemm_tn': (C.c_int, [_P, C.c_int32, C.c_int64, _P, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P]),
     'upamd_tune': (C.c_int, [C.c_char_p, C.c_int32]),
     'upamd_clock_probe': (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    'upamd_tiny_profile': (C.c_int, [_P]),
     'upamd_profile_enable': (C.c_int, [_P, C.c_int32]),
     'upamd_profile_read': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -311,6 +311,46 @@ def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     return PackedReplay(meta, layout, host)
 
 
+class _PinnedRing:
+    """Per (device, dtype) ring of page-locked staging buffers for small asynchronous uploads.  A buffer is reused only after
+    the copy that read it has certainly finished (an event recorded behind the copy; by the time the ring comes round it is
+    long past), and grows when a bigger upload comes along."""
+
+    def __init__(self, slots=4):
+        self.slots, self.bufs, self.events, self.next = slots, {}, {}, {}
+
+    def upload(self, array, device):
+        device = torch.device(device)
+        t = torch.from_numpy(np.ascontiguousarray(array))
+        if device.type != 'cuda':
+            return t.to(device), t
+        key = (device.index, t.dtype)
+        k = self.next.get(key, 0)
+        self.next[key] = (k + 1) % self.slots
+        slot = key + (k,)
+        buf = self.bufs.get(slot)
+        if buf is None or buf.numel() < t.numel():
+            buf = torch.empty(max(int(t.numel() * 1.25), 1024), dtype=t.dtype).pin_memory()
+            self.bufs[slot] = buf
+        elif slot in self.events:
+            self.events[slot].synchronize()
+        host = buf[:t.numel()]
+        host.copy_(t)
+        dev = host.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self.events[slot] = ev
+        return dev, host
+
+
+_ring = _PinnedRing()
+
+
+def upload_pinned(array, device):
+    """(device tensor, host staging view) of a numpy array, uploaded asynchronously from a recycled page-locked buffer."""
+    return _ring.upload(array, device)
+
+
 class Schedule:
     """Device-side index arrays of a sequence of minibatches (uploaded once per epoch).
 
@@ -339,16 +379,15 @@ class Schedule:
             chunks.append(np.concatenate([arr, np.zeros(pad, dtype=np.int32)]))
             self.items.append(dict(B=int(B), n_nodes=int(n.sum()), n_he=int(nh.sum()), n_rn=int(nr.sum()),
                                    max_n=int(n.max()), max_inc=int(ninc.max()), n_inc=int(ninc.sum()), base=cursor,
+                                   max_cand=max(1, int(np.where(meta[rows, M_STAGE] == 0, nh, np.where(meta[rows, M_STAGE] == 1, nr, 0)).max())),
                                    n_land=int((meta[rows, M_STAGE] == 0).sum()),
                                    n_road=int((meta[rows, M_STAGE] == 1).sum())))
             cursor += arr.size + pad
         flat = np.concatenate(chunks)
         # pinned + asynchronous: a pageable, blocking upload made the host wait for every kernel queued before it -- one
-        # pipeline drain per epoch (the staging tensor lives as long as the schedule, i.e. beyond the copy)
-        self._host = torch.from_numpy(flat)
-        if torch.device(device).type == 'cuda':
-            self._host = self._host.pin_memory()
-        self.dev = self._host.to(device, non_blocking=True)
+        # pipeline drain per epoch.  The page-locked staging buffers are RECYCLED (upload_pinned): allocating one per epoch
+        # costs 1-2 ms of host time (and now and then tens of ms), which is a whole epoch of small-model optimizer steps.
+        self.dev, self._host = upload_pinned(flat, device)
 
     def minibatch(self, k):
         it = self.items[k]
@@ -362,4 +401,5 @@ class Schedule:
         mb.he_off_dev = base + 4 * (2 * B + 1)
         mb.rn_off_dev = base + 4 * (3 * B + 2)
         mb.n_inc, mb.inc_off_dev = it['n_inc'], base + 4 * (4 * B + 3)
+        mb.max_cand = it['max_cand']
         return mb, it

@@ -171,6 +171,9 @@ typedef struct upamd_minibatch {
     /* only read when the model has edge_fc_layers > 1 (may be 0 / NULL otherwise): */
     int64_t n_inc;                /* sum of 2*e over the rows (incidences = edge directions)           */
     const int32_t *inc_off_dev;   /* [B+1] prefix sums of 2*e in minibatch order                       */
+    /* read by the fused small-model path (upamd_step_fused_ok): max over the rows of the row's pointer-head candidates
+     * (n_head_edges for a land-use row, n_road_nodes for a road row); 0 = not provided -> the general path is taken */
+    int32_t max_cand;
 } upamd_minibatch;
 
 int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out);
@@ -312,6 +315,9 @@ int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev
  *   "side_priority" [1] priority level of the side streams created from now on: 1 high, 0 normal, 2 low
  *   "gemm_lds_pad", "gemm_stagger_mode", "gemm_stagger_cycles": residency / first-round stagger of the LDS-DMA gemm_nt */
 int upamd_tune(const char *name, int32_t value);
+/* Lab hook: buf_dev = int64[32] (or NULL to switch off): the fused small-model kernel's workgroup 0 writes 100 MHz wall-clock stamps
+ * at the section boundaries of its first graph (tools/r04_diag_tiny.py prints the section times). */
+int upamd_tiny_profile(void *buf_dev);
 /* Lab hook: one wave writes `samples` pairs (shader-clock counter, 100 MHz wall-clock counter) into out_dev (int64[2 * samples]),
  * `gap_ticks` wall-clock ticks apart; launched on a side stream it measures the effective shader clock under load. */
 int upamd_clock_probe(void *out_dev, int32_t samples, int32_t gap_ticks, void *stream);

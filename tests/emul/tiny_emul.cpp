@@ -20,7 +20,7 @@ int tiny_emul_sizeof_offs() { return (int)sizeof(Offs); }
 
 // grads (out, [n_floats]): sum of the per-workgroup slabs in workgroup order;  losses (out, [4]): STEP mode only
 int tiny_emul_run(const void *packed, const upamd_pack_layout *L, int B, const int32_t *idx, const int32_t *he_off,
-                  const int32_t *rn_off, int max_n, int max_inc, const Dims *dims, const Offs *offs, const float *prm, int mode,
+                  const int32_t *rn_off, int max_n, int max_inc, int max_cand, const Dims *dims, const Offs *offs, const float *prm, int mode,
                   int groups, float *value, float *logp, float *ent, float *z_he, float *z_rn, const float *dvalue,
                   const float *dlogp, const float *dent, const int64_t *rows, const float *adv, const float *ret,
                   const float *old_logp, const float *exps, float clip_eps, float cv, float ce, float inv_rows, float inv_ind,
@@ -48,15 +48,15 @@ int tiny_emul_run(const void *packed, const upamd_pack_layout *L, int B, const i
     A.dvalue = dvalue; A.dlogp = dlogp; A.dent = dent;
     A.rows = rows; A.adv = adv; A.ret = ret; A.old_logp = old_logp; A.exps = exps;
     A.clip_eps = clip_eps; A.cv = cv; A.ce = ce; A.inv_rows = inv_rows; A.inv_ind = inv_ind;
-    A.max_n = max_n; A.max_inc = max_inc;
-    const Plan pl = make_plan(A.d, max_n, max_inc);
+    A.max_n = max_n; A.max_inc = max_inc; A.max_cand = max_cand;
+    const Plan pl = make_plan(A.d, max_n, max_inc, max_cand);
     if (lds_bytes_out) *lds_bytes_out = pl.total * 4;
     const int G = groups < B ? groups : B;
     const int64_t P = offs->n_floats;
-    std::vector<float> slabs((size_t)G * P, 0.f), scratch((size_t)G * ((size_t)max_inc / 2 + 1) * dims->D, 0.f), loss_rows((size_t)B * 4, 0.f);
+    std::vector<float> slabs((size_t)G * P, 0.f), scratch((size_t)G * ((size_t)max_cand + 1) * dims->D, 0.f), loss_rows((size_t)B * 4, 0.f);
     std::vector<float> lds((size_t)pl.total + 64);
     A.slab = slabs.data(); A.slab_stride = P;
-    A.scratch = scratch.data(); A.scratch_stride = ((int64_t)max_inc / 2 + 1) * dims->D;
+    A.scratch = scratch.data(); A.scratch_stride = ((int64_t)max_cand + 1) * dims->D;
     A.loss_rows = loss_rows.data();
     for (int wg = 0; wg < G; ++wg) {
         for (int b = wg; b < B; b += G) {

@@ -204,3 +204,18 @@ def test_action_heads_read_the_fused_forwards_logits():
         elif st == 1:
             assert int(act[b, 1]) == int(road.logits[ir].argmax())
             ir += 1
+
+
+@pytest.mark.parametrize('gain,bias', [(40.0, 0.0), (1.0, 3.0), (12.0, 0.0)])
+def test_saturating_edge_mlp_on_the_fused_path(gain, bias):
+    """P | Q outside the exp-form range: the layer's flag goes up (an LDS atomic OR) and that graph walks in the linear form;
+    graphs of the same minibatch that stay in range keep the exp form."""
+    from test_gpu_parity import _check_against_oracle, _random_case
+    D, L, heads, T, n_range = 16, 2, 1, 6, (30, 60)
+    cfg, sd, replay = _random_case(D, L, heads, (64, 16), (32, 1), (32, 1), (32, 32, 1), T, n_range[1] + 5,
+                                   int(5.55 * n_range[1]) + 10, seed=33, road_fraction=0.3, n_range=n_range)
+    sd = dict(sd)
+    for k in list(sd):
+        if 'edge_fc_layers' in k:
+            sd[k] = sd[k] * gain if k.endswith('weight') else sd[k] + bias
+    _check_against_oracle(cfg, sd, replay, heads, T, tol=3e-4 if gain > 1 else 1e-4)

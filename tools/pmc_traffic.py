@@ -17,6 +17,8 @@ import os
 import re
 from collections import defaultdict
 
+from csrc_hash import csrc_hash
+
 SHORT = [      # demangled (csv output) and mangled (rocpd) spellings
     (r'gemm_nt_dma2_kernel(<2, 2|ILi2ELi2)', 'gemm_nt_128'),          # round 2: the LDS-DMA kernel is the 128 x 128 node GEMM
     (r'gemm_nt_mfma_kernel(<128, 64, 64, false, false, 1, 32|ILi128ELi64ELi64ELb0ELb0ELi1ELi32)', 'gemm_nt_128_k32'),
@@ -94,7 +96,7 @@ def main():
                            write_bytes_per_launch=r['write_bytes'] / nw,
                            hbm_bytes_per_launch=r['fetch_bytes'] / n + r['write_bytes'] / nw)
     doc = dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); FETCH_SIZE doubled '
-                      '(gfx950), KB -> bytes', command=args.command, kernels=table)
+                      '(gfx950), KB -> bytes', command=args.command, kernels=table, csrc_hash=csrc_hash())
     if args.json:
         with open(args.json, 'w') as fh:
             json.dump(doc, fh, indent=1, sort_keys=True)

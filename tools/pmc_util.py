@@ -49,9 +49,11 @@ def main():
                      '(hlg_d256, bench.py --steps 4 --warmup 1)\n\n%s\n' % text)
     if args.json:
         import json
+        from csrc_hash import csrc_hash
         with open(args.json, 'w') as fh:
             json.dump({'kernels': js, 'source': 'rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES '
-                                                'SQ_ACTIVE_INST_VALU --kernel-trace over bench.py (hlg_d256)'}, fh, indent=1)
+                                                'SQ_ACTIVE_INST_VALU --kernel-trace over bench.py (hlg_d256)',
+                       'csrc_hash': csrc_hash()}, fh, indent=1)
     print(text)
 
 

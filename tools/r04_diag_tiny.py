@@ -24,6 +24,10 @@ replay = synth.make_replay(T, w['community'], max_nodes=w['max_nodes'], max_edge
                            road_fraction=w.get('road_fraction', 0.0))
 np.random.seed(7)
 engine = up.attach()
+from drl_urban_planning_amd import native as _nat
+for kv in os.environ.get('UPAMD_TUNE', '').split(','):
+    if kv:
+        _nat.check(_nat.lib().upamd_tune(kv.split('=')[0].encode(), int(kv.split('=')[1])), 'upamd_tune')
 it = up.prepare(replay)
 torch.cuda.synchronize()
 for rep in range(3):
@@ -50,3 +54,23 @@ for k in range(ep.nb):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('cumulative').print_stats(14)
+
+# section profile of the fused kernel (workgroup 0, its first graph): 100 MHz stamps -> microseconds
+from drl_urban_planning_amd import native
+import ctypes as C
+buf = torch.zeros(32, dtype=torch.int64, device=dev)
+native.check(native.lib().upamd_tiny_profile(C.c_void_p(buf.data_ptr())))
+ep = up.make_epoch(it)
+up.step(it, ep, 0)
+torch.cuda.synchronize()
+native.check(native.lib().upamd_tiny_profile(None))
+st = buf.cpu().numpy()
+names = {0: 'lists+num encoder', 1: 'C, q chain', 2: 'encode nodes', 3: 'GCN forward', 4: 'means', 5: 'attention fwd', 6: 'SV + value head',
+         7: 'pointer head fwd', 8: 'loss seeds', 9: 'value head bwd', 10: 'num encoder bwd', 11: 'attention dense bwd',
+         12: 'attention core bwd', 13: 'pointer head bwd', 14: 'G^L', 15: 'q chain bwd', 16: 'GCN bwd layer L', 17: 'GCN bwd lower layers',
+         19: 'node encoder grads', 20: 'end'}
+keys = [k for k in sorted(names) if st[k] > 0]
+print('fused kernel sections (graph 0: n=%d e=%d), us:' % (int(it.packed.meta[int(ep.sched._host[0]), 0]), int(it.packed.meta[int(ep.sched._host[0]), 1])))
+for a, b2 in zip(keys[:-1], keys[1:]):
+    print('  %-26s %8.2f' % (names[a], (st[b2] - st[a]) / 100.0))
+print('  %-26s %8.2f' % ('total', (st[keys[-1]] - st[keys[0]]) / 100.0))
