@@ -253,6 +253,11 @@ def main():
                                seed=seed_replay, unique=w['unique'], road_fraction=w.get('road_fraction', 0.0))
     t_gen = time.time() - t_gen
     np.random.seed(seed_np)
+    # the replay is ~10^5 small python objects: a full garbage collection that happens to fall into the timed region costs
+    # 50-70 ms (seen as 2 ms 'steps' at the reference dims, where a step is 0.3 ms) -- move them out of the collector's way
+    import gc
+    gc.collect()
+    gc.freeze()
     engine = up.attach()
     # kernel-lab A/B switches (default: the library's own choices): UPAMD_TUNE="knob=value,knob=value"
     tune = dict(kv.split('=') for kv in os.environ.get('UPAMD_TUNE', '').split(',') if kv)

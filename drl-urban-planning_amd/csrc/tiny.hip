@@ -127,7 +127,7 @@ int launch_tiny(const upamd_model_desc &d, const ParamLayout &P, const PackedVie
     Args A;
     std::memset(&A, 0, sizeof(A));
     A.meta = pk.meta; A.X = pk.X; A.nmask = pk.nmask; A.rowptr = pk.rowptr; A.inc_nbr = pk.inc_nbr;
-    A.he_src = pk.he_src; A.he_dst = pk.he_dst; A.rn_node = pk.rn_node; A.hinc_nbr = pk.hinc_nbr; A.hinc_he = pk.hinc_he;
+    A.he_src = pk.he_src; A.he_dst = pk.he_dst; A.rn_node = pk.rn_node; A.hinc_nbr = pk.hinc_nbr; A.hinc_he = pk.hinc_he; A.order = pk.order;
     A.hinc_ptr = pk.hinc_ptr; A.he_live = pk.he_live; A.numerical = pk.numerical; A.cur = pk.cur;
     A.B = mb.B; A.idx = mb.idx; A.he_off = mb.he_off; A.rn_off = mb.rn_off;
     tiny_fill(d, P, &A.d, &A.o);

@@ -102,7 +102,7 @@ struct Args {
     const float *X;
     const uint8_t *nmask;
     const int32_t *rowptr;
-    const uint16_t *inc_nbr, *he_src, *he_dst, *rn_node, *hinc_nbr, *hinc_he;
+    const uint16_t *inc_nbr, *he_src, *he_dst, *rn_node, *hinc_nbr, *hinc_he, *order;
     const int32_t *hinc_ptr;
     const uint8_t *he_live;
     const float *numerical, *cur;
@@ -141,7 +141,7 @@ THD int np2(int x) {
 
 // ---- LDS plan (floats).  n / inc / cand = the LARGEST graph of the launch: one plan per launch, every graph uses its prefix.
 struct Plan {
-    int64_t H, X, PQ, rp, nb, alpha, sc, vec, total;      // offsets
+    int64_t H, X, PQ, rp, nb, ord, alpha, sc, vec, total;      // offsets
     int64_t xsize, vsize;
 };
 // head scratch inside the X region: z [nc] | candidate lists (2 u16 + 1 u8 per candidate -> 1.25 floats, kept at 1.5) | chunk buffers
@@ -156,19 +156,20 @@ THD int64_t vec_floats(const Dims &d) {
     for (int i = 0; i < d.n_value; ++i) v += d.value_hidden[i];
     const int64_t D = d.D, Hd = (int64_t)d.heads * d.D, h0 = imax(d.h0l, d.h0r);
     //     U        cur   16 D-vectors   10 head vectors   SV, dSV     V, dV      A, M (h0 x D)  const, s, w2..   partials   scalars + slack
-    return u + XPAD + 16 * D + 10 * Hd + 2 * a4(d.W) + 2 * a4(v) + 2 * h0 * D + 8 * h0 + part_floats(d) + 64 + 256;
+    return u + XPAD + 16 * D + 10 * Hd + 2 * a4(d.W) + 2 * a4(v) + 3 * h0 * D + 8 * h0 + part_floats(d) + 64 + 256;
 }
 THD Plan make_plan(const Dims &d, int n, int inc, int cand) {
     Plan p;
     const int64_t nD = (int64_t)n * d.D;
     int64_t o = 0;
     p.H = o; o += a4((int64_t)d.L * nD);                                           // H^1 .. H^L ([n][D] each; slot L becomes G)
-    const int64_t hs = head_fixed(imax(cand, 1)) + (int64_t)CHMIN * (d.D + 2 * imax(d.h0l, d.h0r));
+    const int64_t hs = head_fixed(imax(cand, 1)) + (int64_t)CHMIN * (d.D + 2 * (imax(d.h0l, d.h0r) + 1));
     p.xsize = nD > hs ? nD : hs;
     p.X = o; o += a4(p.xsize);                                                     // S / dS | head scratch
     p.PQ = o; o += a4(imax((int)(2 * nD), n * XPAD));                              // P | Q of a layer / staged raw features; backward: half | d(half)
     p.rp = o; o += a4(n + 1);
     p.nb = o; o += a4((inc + 1) / 2 + 1);                                          // u16 neighbour ids
+    p.ord = o; o += a4((n + 1) / 2 + 1);                                           // u16 node ids in processing (degree-sorted) order
     p.alpha = o; o += a4((int64_t)d.heads * n);
     p.sc = o; o += a4((int64_t)d.heads * n);
     p.vsize = vec_floats(d);
@@ -190,8 +191,35 @@ struct Bump {
 
 // sum_k w[k] x[k]: the (global-memory) weights in batches of 16 loads in flight (the layers are latency-bound: an L2 round trip per
 // batch is what a phase costs)
+struct f4 {
+    float x, y, z, w;
+};
 TDEV float dot_g(const float *w, const float *x, int K, float acc = 0.0f) {
     int k = 0;
+    if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        // 16-byte loads, 32 floats per round trip (the parameter tensors start on 4-float boundaries: rows of a K % 4 == 0
+        // layer are 16-byte aligned)
+        const f4 *w4 = reinterpret_cast<const f4 *>(w);
+        for (; k + 32 <= K; k += 32) {
+            f4 a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = w4[(k >> 2) + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                acc = fmaf(a[q].w, x[k + 4 * q + 3], fmaf(a[q].z, x[k + 4 * q + 2], fmaf(a[q].y, x[k + 4 * q + 1], fmaf(a[q].x, x[k + 4 * q], acc))));
+        }
+        if (k < K) {                           // last 4 .. 28 floats: clamped loads, masked adds (all in flight together)
+            const int rem = (K - k) >> 2;
+            f4 a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = w4[(k >> 2) + (q < rem ? q : rem - 1)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < rem)
+                    acc = fmaf(a[q].w, x[k + 4 * q + 3], fmaf(a[q].z, x[k + 4 * q + 2], fmaf(a[q].y, x[k + 4 * q + 1], fmaf(a[q].x, x[k + 4 * q], acc))));
+        }
+        return acc;
+    }
     for (; k + 16 <= K; k += 16) {
         float a[16];
 #pragma unroll
@@ -300,6 +328,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     const uint8_t *nmg = A.nmask + node_off;
     const int32_t *rpg = A.rowptr + m[13];
     const uint16_t *nbg = A.inc_nbr + 2 * (int64_t)m[10];
+    const uint16_t *og = A.order + node_off;
     const uint16_t *hsrc = A.he_src + m[11], *hdst = A.he_dst + m[11];
     const uint8_t *hlive = A.he_live + m[11];
     const uint16_t *rnn = A.rn_node + m[12];
@@ -316,6 +345,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     float *Xs = PQ;                              // ... or the graph's raw node features [n][XPAD], while P | Q is not needed
     int *rp = reinterpret_cast<int *>(lds + pl.rp);
     uint16_t *nb = reinterpret_cast<uint16_t *>(lds + pl.nb);
+    uint16_t *ord = reinterpret_cast<uint16_t *>(lds + pl.ord);      // the packer's degree-sorted order: a wave's nodes walk lists of similar length
     float *alpha = lds + pl.alpha, *sc = lds + pl.sc;
     Bump vb{lds + pl.vec, 0};
     auto slotH = [&](int l) -> float * { return Hs + (int64_t)(l - 1) * nD; };
@@ -332,7 +362,10 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     V[0] = SV;
     for (int i = 0; i < d.n_value; ++i) V[i + 1] = vb.get(d.value_hidden[i]);
     const int h0 = land ? d.h0l : d.h0r, h0m = imax(d.h0l, d.h0r);
+    const int hs = h0 + 1;                        // row stride of the candidates' hidden rows in LDS: odd, so that both a thread per
+                                                 // candidate and a thread per hidden unit walk them without bank conflicts
     float *Aeff = vb.get((int64_t)h0m * D);      // land: (Wa + Wd) + Wc diag(C);  road: R1
+    float *AeffT = vb.get((int64_t)h0m * D);     // ... and its transpose [D][h0] (a thread per hidden unit reads it stride-1)
     float *cst = vb.get(h0m);                    // land: b1 + (Wb - Wd) C;        road: rb1
     float *w2v = vb.get(h0m);
     float *part = vb.get(part_floats(d));
@@ -349,6 +382,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     // lists, per-sample inputs, the raw node features
     T_FOR(i, n + 1) rp[i] = rpg[i];
     T_FOR(i, inc) nb[i] = nbg[i];
+    T_FOR(i, n) ord[i] = og[i];
     T_FOR(i, d.Fn) U[0][i] = A.numerical[(int64_t)t * d.Fn + i];
     T_FOR(i, XPAD) cur[i] = A.cur[(int64_t)t * XPAD + i];
     T_FOR(i, MAXL + 1) bad[i] = 0;
@@ -434,22 +468,49 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         //   exp form: 1/2 (t1 + t2) = 1 - (r1 + r2),  r = 1 / (1 + E)
         T_FOR_J(c, D) {
             const float bc = bl[c], eb = t_exp2(C2 * bc);
-            T_FOR_V(v, n, D) {
+            T_FOR_V(vi, n, D) {
+                const int v = ord[vi];
                 const int k0 = rp[v], k1 = rp[v + 1];
                 float S = 0.0f;
+                // four incidences per trip: their neighbour ids, then their rows, are requested together (the walk of a hub is a
+                // chain of dependent LDS round trips); a trip past the end re-reads the last entry and adds exactly 0
                 if (ef) {
                     const float pv = PQ[v * 2 * D + c] * eb, qv = PQ[v * 2 * D + D + c] * eb;
                     float acc = 0.0f;
-                    for (int k = k0; k < k1; ++k) {
-                        const int u = nb[k];
-                        acc += t_rcp(fmaf(pv, PQ[u * 2 * D + D + c], 1.0f)) + t_rcp(fmaf(PQ[u * 2 * D + c], qv, 1.0f));
+                    for (int k = k0; k < k1; k += 4) {
+                        int u[4];
+                        float a[4], bq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) u[q] = nb[k + q < k1 ? k + q : k1 - 1];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            a[q] = PQ[u[q] * 2 * D + D + c];
+                            bq[q] = PQ[u[q] * 2 * D + c];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float r = t_rcp(fmaf(pv, a[q], 1.0f)) + t_rcp(fmaf(bq[q], qv, 1.0f));
+                            acc += k + q < k1 ? r : 0.0f;
+                        }
                     }
                     S = (float)(k1 - k0) - acc;
                 } else {
                     const float pv = PQ[v * 2 * D + c] + bc, qv = PQ[v * 2 * D + D + c] + bc;
-                    for (int k = k0; k < k1; ++k) {
-                        const int u = nb[k];
-                        S += 0.5f * (t_tanh(pv + PQ[u * 2 * D + D + c]) + t_tanh(PQ[u * 2 * D + c] + qv));
+                    for (int k = k0; k < k1; k += 4) {
+                        int u[4];
+                        float a[4], bq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) u[q] = nb[k + q < k1 ? k + q : k1 - 1];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            a[q] = PQ[u[q] * 2 * D + D + c];
+                            bq[q] = PQ[u[q] * 2 * D + c];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float r = 0.5f * (t_tanh(pv + a[q]) + t_tanh(bq[q] + qv));
+                            S += k + q < k1 ? r : 0.0f;
+                        }
                     }
                 }
                 Hout[v * D + c] = fmaf(S, t_rcp((float)(k1 - k0) + 1e-6f), Hin[v * D + c]);
@@ -485,10 +546,13 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     for (int h = 0; h < Hn; ++h) {
         float *sch = sc + (int64_t)h * n, *al = alpha + (int64_t)h * n;
         const float *r = rr + h * D;
-        T_FOR(v, n) {
+        T_FOR(v, n) {                            // (columns visited from v % D on: consecutive nodes sit on different LDS banks)
             float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k < D; ++k) acc = fmaf(r[k], HL[v * D + k], acc);
+            for (int k = 0; k < D; ++k) {
+                const int kk = (k + v) & (D - 1);
+                acc = fmaf(r[kk], HL[v * D + kk], acc);
+            }
             sch[v] = nmg[v] ? acc : -INFINITY;
         }
         T_SYNC();
@@ -561,7 +625,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     uint16_t *cl_b = cl_a + ncl;                                                   // land: dst
     uint8_t *cl_live = reinterpret_cast<uint8_t *>(cl_b + ncl);
     float *chunk = Xr + head_fixed(ncl);
-    const int per = D + 2 * h0m;
+    const int per = D + 2 * (h0m + 1);
     int CH = (int)((pl.xsize - head_fixed(ncl)) / per);
     CH = imin(imax(CH, 1), ncl);
     const float *PQl = PQ;                       // last layer's P | Q is still in place (the forward wrote it last)
@@ -597,14 +661,14 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         T_FOR_J(j, h0) {
             float a[D];
 #pragma unroll
-            for (int c = 0; c < D; ++c) a[c] = Aeff[j * D + c];
+            for (int c = 0; c < D; ++c) a[c] = AeffT[c * h0 + j];
             const float cj = cst[j];
             T_FOR_V(q, cn, h0) {
                 const float *x = mq + (int64_t)q * D;
                 float acc = cj;
 #pragma unroll
                 for (int c = 0; c < D; ++c) acc = fmaf(a[c], x[c], acc);
-                hid[q * h0 + j] = t_tanh(acc);
+                hid[q * hs + j] = t_tanh(acc);
             }
         }
         T_SYNC();
@@ -625,7 +689,9 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             T_FOR(i, h0 * D) {
                 const int j = i / D, c = i - j * D;
                 const float *w = W1 + (int64_t)j * 4 * D;
-                Aeff[i] = w[c] + w[3 * D + c] + w[2 * D + c] * C[c];
+                const float av = w[c] + w[3 * D + c] + w[2 * D + c] * C[c];
+                Aeff[i] = av;
+                AeffT[c * h0 + j] = av;
             }
             T_FOR(j, h0) {
                 const float *w = W1 + (int64_t)j * 4 * D;
@@ -636,25 +702,33 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 w2v[j] = prm[o.land_w1 + j];
             }
         } else {
-            T_FOR(i, h0 * D) Aeff[i] = prm[o.road_w0 + i];
+            T_FOR(i, h0 * D) {
+                const float av = prm[o.road_w0 + i];
+                Aeff[i] = av;
+                AeffT[(i % D) * h0 + i / D] = av;
+            }
             T_FOR(j, h0) {
                 cst[j] = prm[o.road_b0 + j];
                 w2v[j] = prm[o.road_w1 + j];
             }
         }
         T_SYNC();
+        T_MARK(21);
         for (int c0 = 0; c0 < nc; c0 += CH) {
             const int cn = imin(nc - c0, CH);
-            float *mq = chunk, *hid = chunk + (int64_t)CH * D;
+            float *mq = chunk, *hid = chunk + (int64_t)CH * D;      // [CH][D] inputs, [CH][hs] hidden
             cand_inputs(c0, cn, mq);
+            if (c0 == 0) T_MARK(22);
             cand_hidden(cn, mq, hid);
+            if (c0 == 0) T_MARK(23);
             T_FOR(q, cn) {
                 float acc = 0.0f;
-                for (int j = 0; j < h0; ++j) acc = fmaf(w2v[j], hid[q * h0 + j], acc);
+                for (int j = 0; j < h0; ++j) acc = fmaf(w2v[j], hid[q * hs + j], acc);
                 z[c0 + q] = acc;
             }
             T_SYNC();
         }
+        T_MARK(24);
         // log-softmax over the candidates, log-prob of the action, entropy
         T_FOR(g, NG) {
             float mx = -INFINITY;
@@ -831,7 +905,10 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         T_FOR(v, n) {
             float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k < D; ++k) acc = fmaf(dsv[k], HL[v * D + k], acc);
+            for (int k = 0; k < D; ++k) {
+                const int kk = (k + v) & (D - 1);
+                acc = fmaf(dsv[kk], HL[v * D + kk], acc);
+            }
             tj[v] = acc;
             al[v] *= inv;
         }
@@ -877,7 +954,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         const float lse = scal[1], Hent = scal[2];
         for (int c0 = 0; c0 < nc; c0 += CH) {
             const int cn = imin(nc - c0, CH);
-            float *mq = chunk, *hid = chunk + (int64_t)CH * D, *dpre = chunk + (int64_t)CH * (D + h0);
+            float *mq = chunk, *hid = chunk + (int64_t)CH * D, *dpre = chunk + (int64_t)CH * (D + hs);
             cand_inputs(c0, cn, mq);
             cand_hidden(cn, mq, hid);
             // dz_k = dlogp (delta_ka - p_k) - dent p_k (log p_k + H);  dpre[k][j] = dz_k w2[j] (1 - hid^2)
@@ -886,9 +963,9 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 const float lp = z[c0 + q] - lse, p = t_exp(lp);
                 float dz = -gl * p - ge * p * (lp + Hent);
                 if (c0 + q == act) dz += gl;
-                const float hv = hid[i];
-                dpre[i] = dz * w2v[j] * (1.0f - hv * hv);
-                hid[i] = dz * hv;                 // (dz hid: the summand of dw2)
+                const float hv = hid[q * hs + j];
+                dpre[q * hs + j] = dz * w2v[j] * (1.0f - hv * hv);
+                hid[q * hs + j] = dz * hv;        // (dz hid: the summand of dw2)
             }
             T_SYNC();
             // running sums over the candidates: dw2, db1 (= s), M[j][c] = sum dpre[k][j] m[k][c];  and the gradient of the
@@ -897,15 +974,15 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 if (i < h0) {
                     float a1 = dw2[i], a2 = sj[i];
                     for (int q = 0; q < cn; ++q) {
-                        a1 += hid[q * h0 + i];
-                        a2 += dpre[q * h0 + i];
+                        a1 += hid[q * hs + i];
+                        a2 += dpre[q * hs + i];
                     }
                     dw2[i] = a1;
                     sj[i] = a2;
                 } else {
                     const int ii = i - h0, j = ii / D, c = ii - j * D;
                     float acc = Mj[ii];
-                    for (int q = 0; q < cn; ++q) acc = fmaf(dpre[q * h0 + j], mq[q * D + c], acc);
+                    for (int q = 0; q < cn; ++q) acc = fmaf(dpre[q * hs + j], mq[q * D + c], acc);
                     Mj[ii] = acc;
                 }
             }
@@ -913,7 +990,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             T_FOR_J(c, D) {
                 T_FOR_V(q, cn, D) {
                     float acc = 0.0f;
-                    for (int j = 0; j < h0; ++j) acc = fmaf(Aeff[j * D + c], dpre[q * h0 + j], acc);
+                    for (int j = 0; j < h0; ++j) acc = fmaf(Aeff[j * D + c], dpre[q * hs + j], acc);
                     if (land && !cl_live[c0 + q]) acc = 0.0f;
                     dst[(int64_t)(c0 + q) * D + c] = acc;
                 }
@@ -1065,29 +1142,44 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             T_FOR_J(cc, HC) {
                 const int c = cb + cc;
                 const float bc = bl[c], eb = t_exp2(C2 * bc);
-                T_FOR_V(v, n, HC) {
+                T_FOR_V(vi, n, HC) {
+                    const int v = ord[vi];
                     const float sv = dS[v * D + c];
                     const float pv = ef ? PQh[v * D + cc] * eb : PQh[v * D + cc] + bc;
                     const float qv = ef ? PQh[v * D + HC + cc] * eb : PQh[v * D + HC + cc] + bc;
                     float aP = 0.0f, aQ = 0.0f;
-                    // one edge term: neighbour u, edge gradient dm
-                    auto term = [&](int u, float dm) {
+                    // one edge term: the neighbour's Q / P of this column, edge gradient dm (a masked term has dm = 0)
+                    auto term = [&](float qu, float pu, float dm) {
                         if (ef) {
-                            const float r1 = t_rcp(fmaf(pv, PQh[u * D + HC + cc], 1.0f)), r2 = t_rcp(fmaf(PQh[u * D + cc], qv, 1.0f));
+                            const float r1 = t_rcp(fmaf(pv, qu, 1.0f)), r2 = t_rcp(fmaf(pu, qv, 1.0f));
                             aP = fmaf(2.0f * dm, fmaf(-r1, r1, r1), aP);
                             aQ = fmaf(2.0f * dm, fmaf(-r2, r2, r2), aQ);
                         } else {
-                            const float t1 = t_tanh(pv + PQh[u * D + HC + cc]), t2 = t_tanh(PQh[u * D + cc] + qv);
+                            const float t1 = t_tanh(pv + qu), t2 = t_tanh(pu + qv);
                             aP = fmaf(0.5f * dm, 1.0f - t1 * t1, aP);
                             aQ = fmaf(0.5f * dm, 1.0f - t2 * t2, aQ);
                         }
                     };
-                    for (int k = rp[v]; k < rp[v + 1]; ++k) {
-                        const int u = nb[k];
-                        term(u, sv + dS[u * D + c]);
+                    const int k0 = rp[v], k1 = rp[v + 1];
+                    for (int k = k0; k < k1; k += 4) {      // four incidences per trip (see the forward walk)
+                        int u[4];
+                        float qu[4], pu[4], du_[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) u[q] = nb[k + q < k1 ? k + q : k1 - 1];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            qu[q] = PQh[u[q] * D + HC + cc];
+                            pu[q] = PQh[u[q] * D + cc];
+                            du_[q] = dS[u[q] * D + c];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) term(qu[q], pu[q], k + q < k1 ? sv + du_[q] : 0.0f);
                     }
                     if (last && land) {
-                        for (int k = hpg[v]; k < hpg[v + 1]; ++k) term(hnb[k], dMg[(int64_t)hhe[k] * D + c]);
+                        for (int k = hpg[v]; k < hpg[v + 1]; ++k) {
+                            const int u = hnb[k];
+                            term(PQh[u * D + HC + cc], PQh[u * D + cc], dMg[(int64_t)hhe[k] * D + c]);
+                        }
                     }
                     dPQh[v * D + cc] = aP;
                     dPQh[v * D + HC + cc] = aQ;

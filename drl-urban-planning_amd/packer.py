@@ -316,7 +316,7 @@ class _PinnedRing:
     the copy that read it has certainly finished (an event recorded behind the copy; by the time the ring comes round it is
     long past), and grows when a bigger upload comes along."""
 
-    def __init__(self, slots=4):
+    def __init__(self, slots=3):
         self.slots, self.bufs, self.events, self.next = slots, {}, {}, {}
 
     def upload(self, array, device):
@@ -329,8 +329,14 @@ class _PinnedRing:
         self.next[key] = (k + 1) % self.slots
         slot = key + (k,)
         buf = self.bufs.get(slot)
-        if buf is None or buf.numel() < t.numel():
-            buf = torch.empty(max(int(t.numel() * 1.25), 1024), dtype=t.dtype).pin_memory()
+        if buf is None:
+            # first upload of this kind: page-lock every slot of the ring NOW (a hipHostMalloc costs milliseconds and may drain
+            # the device: it belongs in the first iteration's set-up, not in a later epoch)
+            for q in range(self.slots):
+                self.bufs[key + (q,)] = torch.empty(max(int(t.numel() * 1.25), 1024), dtype=t.dtype).pin_memory()
+            buf = self.bufs[slot]
+        elif buf.numel() < t.numel():
+            buf = torch.empty(int(t.numel() * 1.25), dtype=t.dtype).pin_memory()
             self.bufs[slot] = buf
         elif slot in self.events:
             self.events[slot].synchronize()

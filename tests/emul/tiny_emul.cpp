@@ -40,6 +40,7 @@ int tiny_emul_run(const void *packed, const upamd_pack_layout *L, int B, const i
     A.hinc_ptr = reinterpret_cast<const int32_t *>(base + L->off_hinc_ptr);
     A.hinc_nbr = reinterpret_cast<const uint16_t *>(base + L->off_hinc_nbr);
     A.hinc_he = reinterpret_cast<const uint16_t *>(base + L->off_hinc_he);
+    A.order = reinterpret_cast<const uint16_t *>(base + L->off_order);
     A.numerical = reinterpret_cast<const float *>(base + L->off_numerical);
     A.cur = reinterpret_cast<const float *>(base + L->off_cur);
     A.B = B; A.idx = idx; A.he_off = he_off; A.rn_off = rn_off;

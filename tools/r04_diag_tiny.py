@@ -68,8 +68,9 @@ st = buf.cpu().numpy()
 names = {0: 'lists+num encoder', 1: 'C, q chain', 2: 'encode nodes', 3: 'GCN forward', 4: 'means', 5: 'attention fwd', 6: 'SV + value head',
          7: 'pointer head fwd', 8: 'loss seeds', 9: 'value head bwd', 10: 'num encoder bwd', 11: 'attention dense bwd',
          12: 'attention core bwd', 13: 'pointer head bwd', 14: 'G^L', 15: 'q chain bwd', 16: 'GCN bwd layer L', 17: 'GCN bwd lower layers',
-         19: 'node encoder grads', 20: 'end'}
-keys = [k for k in sorted(names) if st[k] > 0]
+         19: 'node encoder grads', 20: 'end', 21: '  head: first chunk inputs', 22: '  head: first chunk hidden', 23: '  head: rest of the chunks',
+         24: '  head: softmax stats'}
+keys = sorted([k for k in names if st[k] > 0], key=lambda k: st[k])
 print('fused kernel sections (graph 0: n=%d e=%d), us:' % (int(it.packed.meta[int(ep.sched._host[0]), 0]), int(it.packed.meta[int(ep.sched._host[0]), 1])))
 for a, b2 in zip(keys[:-1], keys[1:]):
     print('  %-26s %8.2f' % (names[a], (st[b2] - st[a]) / 100.0))
