@@ -198,6 +198,12 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak (default): the minibatch per GPU is fixed; strong: the GLOBAL minibatch is fixed and split')
     args = ap.parse_args()
+    # The learner process of the reference runs with OMP_NUM_THREADS=1 (khrylib/rl/agents/agent.py:12).  It matters here: torch's
+    # default is one OpenMP thread per core (128 on the GPU boxes), whose workers spin after every parallel region (a 64 KB host copy
+    # is enough) -- inside a container with a CPU quota (16 cores on this pool) that burns the quota and the whole process is
+    # throttled for the rest of the 100 ms period: 60-90 ms host stalls at random places, 1.1 instead of 0.4 ms per step at the
+    # reference dims (profiles/r04_lab_host_stalls.log).  cpu_baseline() sets its own thread counts for its sweep.
+    torch.set_num_threads(1)
 
     # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1 behind Python's back (RCCL prints
     # its WARN / version lines there, from its own threads, and they were found spliced INTO the JSON line) are sent to stderr

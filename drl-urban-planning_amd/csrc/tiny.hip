@@ -13,7 +13,10 @@ namespace upamd {
 
 using namespace upamd_tiny;
 
-// threads per workgroup: tune knob "tiny_threads" (1024 = 4 waves per SIMD with <= 128 VGPRs each | 512 = 2 waves with 256)
+// threads per workgroup: tune knob "tiny_threads".  1024 (default): 4 waves per SIMD at 128 VGPRs each; the program keeps ~60 LDS
+// pointers and a register-resident weight row per phase alive, so this variant spills ~70 VGPRs to scratch (272 B frame) -- and is
+// still the faster one, because the phases are latency-bound and 4 waves hide more of it: 0.337 vs 0.410 ms per step at the
+// reference dims, 0.294 vs 0.339 at grid_ref (profiles/r04_bench_small.txt).  512: 2 waves per SIMD, 256 VGPRs, no scratch.
 static int g_tiny_threads = 1024;
 void set_tiny_threads(int n) { g_tiny_threads = n == 512 ? 512 : 1024; }
 constexpr int64_t TINY_LDS_LIMIT = 160 * 1024 - 512;

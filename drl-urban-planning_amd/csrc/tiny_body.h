@@ -148,7 +148,7 @@ struct Plan {
 THD int64_t head_fixed(int nc) { return a4(nc) + a4((3 * (int64_t)nc + 1) / 2); }
 THD int part_floats(const Dims &d) {
     const int Hd = d.heads * d.D;
-    return imax(NG * 2 * imax(Hd, 32), 4 * d.D * d.D + NG * d.D);
+    return imax(imax(NG * 2 * imax(Hd, 32), 4 * d.D * d.D + NG * d.D), 2 * d.D * (XPAD + 1));
 }
 THD int64_t vec_floats(const Dims &d) {
     int64_t u = d.Fn, v = 0;
@@ -1235,16 +1235,24 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     // ---- node encoder on every node: dWe += G^0^T X, dbe += colsum(G^0)   (X staged once more: P | Q is dead)
     stage_x();
     T_SYNC();
+    constexpr int NGX = 2;                       // node groups of the partial sums
+    T_FOR(i, NGX * D * (F + 1)) {
+        const int g = i / (D * (F + 1)), r = i - g * D * (F + 1), c = r / (F + 1), f = r - c * (F + 1);
+        float acc = 0.0f;
+        if (f < F) {
+            for (int v = g; v < n; v += NGX) acc = fmaf(Gn[v * D + c], Xs[v * XPAD + f], acc);
+        } else {
+            for (int v = g; v < n; v += NGX) acc += Gn[v * D + c];
+        }
+        part[i] = acc;
+    }
+    T_SYNC();
     T_FOR(i, D * (F + 1)) {
         const int c = i / (F + 1), f = i - c * (F + 1);
         float acc = 0.0f;
-        if (f < F) {
-            for (int v = 0; v < n; ++v) acc = fmaf(Gn[v * D + c], Xs[v * XPAD + f], acc);
-            G[o.node_w + (int64_t)c * F + f] += acc;
-        } else {
-            for (int v = 0; v < n; ++v) acc += Gn[v * D + c];
-            G[o.node_b + c] += acc;
-        }
+        for (int g = 0; g < NGX; ++g) acc += part[g * D * (F + 1) + i];
+        if (f < F) G[o.node_w + (int64_t)c * F + f] += acc;
+        else G[o.node_b + c] += acc;
     }
     T_SYNC();
     T_MARK(20);

@@ -341,7 +341,7 @@ class _PinnedRing:
         elif slot in self.events:
             self.events[slot].synchronize()
         host = buf[:t.numel()]
-        host.copy_(t)
+        host.numpy()[...] = t.numpy()             # (a plain memcpy: torch's copy_ is an OpenMP region above 32 K elements)
         dev = host.to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))

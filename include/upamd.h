@@ -308,7 +308,7 @@ int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev
  *   "fold_layer1" = 2   fold only where every graph of the minibatch fits half the LDS
  *   "nt_min_wgs"  [128] workgroups a gemm_nt launch must have before the 128-wide N tile is used (tests: 1)
  *   "tiny_fused"  [1]   models with D <= 32 run the fused one-workgroup-per-graph kernels (tiny.hip); 0 = the general path
- *   "tiny_threads" [1024] threads per workgroup of the fused small-model kernels (1024 | 512)
+ *   "tiny_threads" [1024] threads per workgroup of the fused small-model kernels (1024: 4 waves/SIMD | 512: no scratch)
  *   "side_heads"  [1]   land-use pointer-head chain (forward: first Linear; backward: softmax / feature / weight-gradient kernels) on the side stream
  *   "side_wgrad"  [1]   GCN weight-gradient GEMMs on a second side stream: 1 = for minibatches of <= 98304 nodes, 0 never, 2 behind the
  *                       layer's dgrad GEMM, 3 always

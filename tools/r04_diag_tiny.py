@@ -42,6 +42,57 @@ for rep in range(3):
     t3 = time.perf_counter()
     print('%s epoch %d: make_epoch %.2f ms, %d steps: host enqueue %.3f ms/step, wall %.3f ms/step' % (
         name, rep, 1e3 * (t1 - t0), ep.nb, 1e3 * (t2 - t1) / ep.nb, 1e3 * (t3 - t1) / ep.nb))
+# the slowest host-side steps of three more epochs, and what happened in them (workspace re-allocation? device allocations?)
+slow = []
+for rep in range(3):
+    ep = up.make_epoch(it)
+    for k in range(ep.nb):
+        ws0 = engine.ws.data_ptr() if engine.ws is not None else 0
+        na0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
+        t0 = time.perf_counter()
+        up.step(it, ep, k)
+        dt = time.perf_counter() - t0
+        slow.append((dt, rep, k, engine.ws.data_ptr() != ws0, torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - na0))
+torch.cuda.synchronize()
+slow.sort(reverse=True)
+print('slowest host-side steps (ms, epoch, step, workspace moved, device allocations):')
+for dt, rep, k, moved, na in slow[:6]:
+    print('   %.3f  epoch %d step %d  ws moved %s  hipMalloc calls %d' % (1e3 * dt, rep, k, moved, na))
+import gc
+_gc_log = []
+def _gc_cb(phase, info):
+    if phase == 'start':
+        _gc_log.append([time.perf_counter(), info['generation'], None])
+    else:
+        _gc_log[-1][2] = time.perf_counter() - _gc_log[-1][0]
+gc.callbacks.append(_gc_cb)
+import cProfile as _cp
+_pr = _cp.Profile()
+# eight epochs back to back, NO synchronisation in between (what bench.py and update_params do): host time of every make_epoch
+# and every step
+torch.cuda.synchronize()
+ev = []
+t_all = time.perf_counter()
+for rep in range(8):
+    t0 = time.perf_counter()
+    _pr.enable()
+    ep = up.make_epoch(it)
+    _pr.disable()
+    ev.append((time.perf_counter() - t0, 'make_epoch %d' % rep))
+    for k in range(ep.nb):
+        t0 = time.perf_counter()
+        up.step(it, ep, k)
+        ev.append((time.perf_counter() - t0, 'epoch %d step %d' % (rep, k)))
+t_enq = time.perf_counter() - t_all
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t_all
+print('8 epochs unsynchronised: enqueue %.1f ms, until done %.1f ms (%.3f ms/step)' % (1e3 * t_enq, 1e3 * t_all, 1e3 * t_all / (8 * ep.nb)))
+ev.sort(reverse=True)
+for dt, what in ev[:10]:
+    print('   %8.3f ms  %s' % (1e3 * dt, what))
+print('garbage collections during the run:', [(g, round(1e3 * (dur or 0), 1)) for _, g, dur in _gc_log])
+import pstats as _ps
+_ps.Stats(_pr).sort_stats('tottime').print_stats(8)
 # per-call host cost inside one step
 import cProfile
 import pstats
