@@ -297,6 +297,7 @@ def main():
     if not args.no_kernel_events:
         engine.profile_reset()
         engine.profile(True)
+    up.collective_events = [] if ctx.world > 1 else None
     ctx.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -305,6 +306,13 @@ def main():
     ctx.barrier()
     dt = time.perf_counter() - t0
     engine.profile(False)
+    # the step's ONE collective (gradient all-reduce, P floats), HIP events on the stream the backward runs on: from the end of
+    # this rank's backward to the end of the collective, i.e. wire time + the wait for the slowest rank; max over ranks of the mean
+    coll = up.collective_ms() if ctx.world > 1 else []
+    up.collective_events = None
+    cmean = torch.tensor([sum(coll) / max(len(coll), 1)], dtype=torch.float64, device=dev)
+    ctx.all_reduce_max(cmean)
+    grad_bytes = int(up.grads.numel()) * 4
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     ctx.all_reduce_max(tmax)
     dt = float(tmax.item())
@@ -362,6 +370,10 @@ def main():
                                             '(--inclusive-unique times T distinct states)'},
         'dp_mode': incl.get('dp_mode'),
     }
+    if ctx.world > 1:
+        out['allreduce_ms'] = float(cmean.item())
+        out['allreduce_share_of_step'] = float(cmean.item()) / out['ms_per_step']
+        out['allreduce_bytes'] = grad_bytes
     flops_sample = algorithmic_flops_per_sample(nodes_per_sample, edges_per_sample, w['D'], w['L'])
     out['algorithmic'] = {'flops_per_sample_step': flops_sample, 'tflops': value / ctx.world * flops_sample / 1e12,
                           'frac_of_fp32_mfma_peak': value / ctx.world * flops_sample / 1e12 / PEAK_FP32_MFMA_TFLOPS}
@@ -375,7 +387,25 @@ def main():
                            'gemm_ms_per_step': sum(v['total_ms'] for v in mfma_kernels.values()) / args.steps}
     dom = 'gemm_nt_128' if 'gemm_nt_128' in kern else (sorted(mfma_kernels, key=lambda k: -mfma_kernels[k]['total_ms'])[0]
                                                        if mfma_kernels else None)
-    if dom is not None:
+    if 'tiny_step' in kern:
+        # the fused small-model step (csrc/tiny.hip): one launch = forward + loss + backward of the whole minibatch, one workgroup
+        # per graph.  SURVEY section 8d prices this regime against HBM: compulsory bytes per sample-step = the packed inputs plus
+        # the saved node embeddings (written by the forward, read by the backward), plus 16 P per step of parameter / gradient /
+        # Adam traffic.  The kernel keeps the embeddings in LDS, so it moves LESS than this figure; the fraction says how far a
+        # latency-bound per-graph program is from the bandwidth bound, which is the honest reading of "speed of light" here.
+        st = kern['tiny_step']
+        n_, e_, D, L, F, Fn = nodes_per_sample, edges_per_sample, w['D'], w['L'], 23, 52
+        per_sample = n_ * F * 4 + e_ * 2 * 4 + 2 * n_ + 2 * e_ + (F + Fn + 3) * 4 + 20 + 2 * (L + 1) * n_ * D * 4
+        nparam = sum(p.numel() for p in ac.parameters())
+        by = w['B'] * per_sample + 16 * nparam
+        ach = by / (st['total_ms'] / st['launches'] * 1e-3) / 1e9
+        out['roofline'] = {'kernel': 'tiny_step', 'bound': 'hbm', 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
+                           'traffic': None, 'traffic_reason': 'no PMC pass over this workload', 'launches': st['launches'],
+                           'avg_launch_ms': st['total_ms'] / st['launches'], 'algorithmic_bytes_per_launch': by,
+                           'algorithmic_bytes_per_sample': per_sample,
+                           'note': 'latency-bound: one workgroup per graph, %d workgroups on 256 CUs' % min(w['B'], 256)}
+        out['kernel_ms_per_step'] = {k: v['total_ms'] / args.steps for k, v in kern.items()}
+    elif dom is not None:
         st = kern[dom]
         ach = st['flops'] / (st['total_ms'] * 1e-3) / 1e12
         out['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

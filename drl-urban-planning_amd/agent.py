@@ -103,6 +103,7 @@ class PPOUpdater:
         self.fused_small = True               # small models: forward + loss + backward as one launch (csrc/tiny.hip)
         self.last_losses = None               # np [steps, 4] of the last update_params call
         self.last_timing = {}
+        self.collective_events = None         # a list: record a HIP-event pair around every step's gradient all-reduce (bench.py)
 
     # ------------------------------------------------------------------ buffers
     def _device(self):
@@ -314,7 +315,14 @@ class PPOUpdater:
     def _finish_step(self, ep, k, loss_out):
         """all-reduce, first-step clip, Adam -- everything behind the backward of a step"""
         engine, nflt = self.engine, self.engine.n_floats
+        timed = self.collective_events is not None and self.dist.world > 1
+        if timed:       # on the stream the backward was launched on: the pair brackets the collective alone (plus rank skew)
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
         self.dist.all_reduce_sum(self.grads)              # ONE collective per optimizer step (no-op for one rank)
+        if timed:
+            pair[1].record()
+            self.collective_events.append(pair)
         if self.clip_pending:
             engine.clip_first_step(self.grads, self.max_grad_norm, self.scratch)
             self.clip_pending = False
@@ -331,6 +339,13 @@ class PPOUpdater:
         engine.adam_groups(steps, self.flat, self.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
                            self.weight_decay, loss_src=self.grads[nflt:] if loss_out is not None else None,
                            loss_dst=loss_out)
+
+    def collective_ms(self):
+        """[ms per recorded step] of the gradient all-reduce (HIP events; synchronises); clears the record"""
+        pairs, self.collective_events = self.collective_events or [], []
+        if pairs:
+            pairs[-1][1].synchronize()
+        return [a.elapsed_time(b) for a, b in pairs]
 
     # ------------------------------------------------------------------ the reference's entry point
     def update_params(self, batch, iteration=0, tb_logger=None, max_steps=None):

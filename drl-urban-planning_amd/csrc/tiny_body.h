@@ -72,6 +72,7 @@ constexpr int XPAD = 24;          // UPAMD_NODE_PAD
 constexpr int MAXMLP = 4;
 constexpr int MAXL = 16;
 constexpr int NG = 32;            // partial groups of the two-level sums
+constexpr int64_t LDS_FLOATS = (160 * 1024 - 512) / 4;   // what one workgroup may use of a CU's LDS
 constexpr int CHMIN = 32;         // pointer-head candidates per chunk the LDS plan guarantees (more when the graph leaves room)
 constexpr float C2 = 2.8853900817779268f;     // 2 log2(e)
 constexpr float LOG2E = 1.4426950408889634f;
@@ -158,13 +159,14 @@ THD int64_t vec_floats(const Dims &d) {
     //     U        cur   16 D-vectors   10 head vectors   SV, dSV     V, dV      A, M (h0 x D)  const, s, w2..   partials   scalars + slack
     return u + XPAD + 16 * D + 10 * Hd + 2 * a4(d.W) + 2 * a4(v) + 3 * h0 * D + 8 * h0 + part_floats(d) + 64 + 256;
 }
-THD Plan make_plan(const Dims &d, int n, int inc, int cand) {
+THD Plan plan_layout(const Dims &d, int n, int inc, int cand, int64_t x_extra) {
     Plan p;
     const int64_t nD = (int64_t)n * d.D;
+    const int64_t per = d.D + 2 * (imax(d.h0l, d.h0r) + 1);                        // chunk floats per candidate
+    const int64_t hs = head_fixed(imax(cand, 1)) + (int64_t)CHMIN * per;
     int64_t o = 0;
     p.H = o; o += a4((int64_t)d.L * nD);                                           // H^1 .. H^L ([n][D] each; slot L becomes G)
-    const int64_t hs = head_fixed(imax(cand, 1)) + (int64_t)CHMIN * (d.D + 2 * (imax(d.h0l, d.h0r) + 1));
-    p.xsize = nD > hs ? nD : hs;
+    p.xsize = (nD > hs ? nD : hs) + x_extra;
     p.X = o; o += a4(p.xsize);                                                     // S / dS | head scratch
     p.PQ = o; o += a4(imax((int)(2 * nD), n * XPAD));                              // P | Q of a layer / staged raw features; backward: half | d(half)
     p.rp = o; o += a4(n + 1);
@@ -176,6 +178,17 @@ THD Plan make_plan(const Dims &d, int n, int inc, int cand) {
     p.vec = o; o += a4(p.vsize);
     p.total = o;
     return p;
+}
+THD Plan make_plan(const Dims &d, int n, int inc, int cand) {
+    // what the launch's largest graph leaves of the LDS goes to the head's chunk buffers, up to one chunk for every candidate
+    // (a chunk costs four barriers forward + backward: the candidate-rich graphs were the last to finish)
+    const Plan base = plan_layout(d, n, inc, cand, 0);
+    const int64_t per = d.D + 2 * (imax(d.h0l, d.h0r) + 1);
+    const int64_t want = head_fixed(imax(cand, 1)) + (int64_t)imax(cand, 1) * per - base.xsize;
+    const int64_t room = LDS_FLOATS - base.total;
+    int64_t extra = want < room ? want : room;
+    extra = extra > 0 ? extra & ~(int64_t)3 : 0;
+    return plan_layout(d, n, inc, cand, extra);
 }
 
 // bump allocator over the vec region
@@ -955,8 +968,10 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         for (int c0 = 0; c0 < nc; c0 += CH) {
             const int cn = imin(nc - c0, CH);
             float *mq = chunk, *hid = chunk + (int64_t)CH * D, *dpre = chunk + (int64_t)CH * (D + hs);
+            if (c0 == 0) T_MARK(25);
             cand_inputs(c0, cn, mq);
             cand_hidden(cn, mq, hid);
+            if (c0 == 0) T_MARK(26);
             // dz_k = dlogp (delta_ka - p_k) - dent p_k (log p_k + H);  dpre[k][j] = dz_k w2[j] (1 - hid^2)
             T_FOR(i, cn * h0) {
                 const int q = i / h0, j = i - q * h0;
@@ -968,6 +983,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 hid[q * hs + j] = dz * hv;        // (dz hid: the summand of dw2)
             }
             T_SYNC();
+            if (c0 == 0) T_MARK(27);
             // running sums over the candidates: dw2, db1 (= s), M[j][c] = sum dpre[k][j] m[k][c];  and the gradient of the
             // candidate inputs dm[k][c] = sum_j A[j][c] dpre[k][j]  (land: only live candidates carry it on)
             T_FOR(i, h0 + h0 * D) {
@@ -996,7 +1012,9 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 }
             }
             T_SYNC();
+            if (c0 == 0) T_MARK(28);
         }
+        T_MARK(29);
         if (land) {
             // feat = [m; c; m*c; m-c]:  dWa += M,  dWb += s (x) c,  dWc += M * c,  dWd += M - s (x) c;  db1 += s;  dw2
             // dC[c] += sum_j (Wb - Wd)[j][c] s[j] + Wc[j][c] M[j][c]
@@ -1117,6 +1135,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             T_FOR_V(v, n, D) dS[v * D + c] = fmaf(Gn[v * D + c], t_rcp((float)(rp[v + 1] - rp[v]) + 1e-6f), ex);
         }
         T_SYNC();
+        if (last) T_MARK(30);
         const bool ef = bad[l] == 0;             // the forward's verdict on this layer's P | Q (same values: same form)
         for (int half = 0; half < 2; ++half) {
             const int cb = half * HC;
@@ -1135,6 +1154,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 }
             }
             T_SYNC();
+            if (last && half == 0) T_MARK(31);
             // dP_v = sum_u 1/2 dm (1 - tanh^2(P_v + Q_u + b)),  dQ_v = sum_u 1/2 dm (1 - tanh^2(P_u + Q_v + b)),
             // dm = dS_v + dS_u; the row's candidate edges add their head gradient on the last layer (packer's
             // candidate-incidence lists: neighbour + candidate index per incident live candidate).
@@ -1186,6 +1206,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 }
             }
             T_SYNC();
+            if (last && half == 0) T_MARK(32);
             // partial sums over fixed node groups of the half's weight gradient (rows c of [Wa | Wb]) and bias gradient, and the
             // dgrad in place: G_v[k] += sum_c dP_v[c] Wa[c][k] + dQ_v[c] Wb[c][k]   (the walks read dS, not G)
             T_FOR(i, NGW * D * D + NG * HC) {
@@ -1214,6 +1235,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 }
             }
             T_SYNC();
+            if (last && half == 0) T_MARK(33);
             // fixed-order combine into the slab:  dW[c][side * D + k],  db[c] += sum_v dP_v[c]
             T_FOR(i, D * D + HC) {
                 if (i < D * D) {
@@ -1229,6 +1251,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 }
             }
             T_SYNC();
+            if (last && half == 0) T_MARK(34);
         }
     }
     T_MARK(19);

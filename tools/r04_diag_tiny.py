@@ -109,7 +109,7 @@ pstats.Stats(pr).sort_stats('cumulative').print_stats(14)
 # section profile of the fused kernel (workgroup 0, its first graph): 100 MHz stamps -> microseconds
 from drl_urban_planning_amd import native
 import ctypes as C
-buf = torch.zeros(32, dtype=torch.int64, device=dev)
+buf = torch.zeros(48, dtype=torch.int64, device=dev)
 native.check(native.lib().upamd_tiny_profile(C.c_void_p(buf.data_ptr())))
 ep = up.make_epoch(it)
 up.step(it, ep, 0)
@@ -120,9 +120,11 @@ names = {0: 'lists+num encoder', 1: 'C, q chain', 2: 'encode nodes', 3: 'GCN for
          7: 'pointer head fwd', 8: 'loss seeds', 9: 'value head bwd', 10: 'num encoder bwd', 11: 'attention dense bwd',
          12: 'attention core bwd', 13: 'pointer head bwd', 14: 'G^L', 15: 'q chain bwd', 16: 'GCN bwd layer L', 17: 'GCN bwd lower layers',
          19: 'node encoder grads', 20: 'end', 21: '  head: first chunk inputs', 22: '  head: first chunk hidden', 23: '  head: rest of the chunks',
-         24: '  head: softmax stats'}
+         24: '  head: softmax stats', 25: '  head bwd: zero + setup', 26: '  head bwd: chunk 0 inputs + hidden', 27: '  head bwd: chunk 0 dpre',
+         28: '  head bwd: chunk 0 sums + dm', 29: '  head bwd: other chunks', 30: '  head bwd: W1 grads, G^L, q chain bwd, dS', 31: '  gcn bwd L half 0: P|Q',
+         32: '  gcn bwd L half 0: walk', 33: '  gcn bwd L half 0: partials + dgrad', 34: '  gcn bwd L half 0: combine', }
 keys = sorted([k for k in names if st[k] > 0], key=lambda k: st[k])
-print('fused kernel sections (graph 0: n=%d e=%d), us:' % (int(it.packed.meta[int(ep.sched._host[0]), 0]), int(it.packed.meta[int(ep.sched._host[0]), 1])))
+print('fused kernel sections (graph 0: n=%d e=%d candidates=%d), us:' % tuple(int(it.packed.meta[int(ep.sched._host[0]), q]) for q in (0, 1, 2)))
 for a, b2 in zip(keys[:-1], keys[1:]):
-    print('  %-26s %8.2f' % (names[a], (st[b2] - st[a]) / 100.0))
-print('  %-26s %8.2f' % ('total', (st[keys[-1]] - st[keys[0]]) / 100.0))
+    print('  %-44s %8.2f' % (names[a], (st[b2] - st[a]) / 100.0))
+print('  %-44s %8.2f' % ('total', (st[keys[-1]] - st[keys[0]]) / 100.0))
