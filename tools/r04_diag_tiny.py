@@ -118,11 +118,11 @@ native.check(native.lib().upamd_tiny_profile(None))
 st = buf.cpu().numpy()
 names = {0: 'lists+num encoder', 1: 'C, q chain', 2: 'encode nodes', 3: 'GCN forward', 4: 'means', 5: 'attention fwd', 6: 'SV + value head',
          7: 'pointer head fwd', 8: 'loss seeds', 9: 'value head bwd', 10: 'num encoder bwd', 11: 'attention dense bwd',
-         12: 'attention core bwd', 13: 'pointer head bwd', 14: 'G^L', 15: 'q chain bwd', 16: 'GCN bwd layer L', 17: 'GCN bwd lower layers',
+         12: 'attention core bwd', 13: 'pointer head bwd: zero', 14: 'G^L', 15: 'q chain bwd', 16: 'GCN bwd layer L: dS', 17: 'GCN bwd lower layers',
          19: 'node encoder grads', 20: 'end', 21: '  head: first chunk inputs', 22: '  head: first chunk hidden', 23: '  head: rest of the chunks',
-         24: '  head: softmax stats', 25: '  head bwd: zero + setup', 26: '  head bwd: chunk 0 inputs + hidden', 27: '  head bwd: chunk 0 dpre',
-         28: '  head bwd: chunk 0 sums + dm', 29: '  head bwd: other chunks', 30: '  head bwd: W1 grads, G^L, q chain bwd, dS', 31: '  gcn bwd L half 0: P|Q',
-         32: '  gcn bwd L half 0: walk', 33: '  gcn bwd L half 0: partials + dgrad', 34: '  gcn bwd L half 0: combine', }
+         24: '  head: softmax stats', 25: '  head bwd: chunk 0 inputs + hidden', 26: '  head bwd: chunk 0 dpre', 27: '  head bwd: chunk 0 sums + dm',
+         28: '  head bwd: other chunks', 29: '  head bwd: W1 grads', 30: '  gcn bwd L half 0: P|Q', 31: '  gcn bwd L half 0: walk',
+         32: '  gcn bwd L half 0: partials + dgrad', 33: '  gcn bwd L half 0: combine', 34: '  gcn bwd L half 1'}
 keys = sorted([k for k in names if st[k] > 0], key=lambda k: st[k])
 print('fused kernel sections (graph 0: n=%d e=%d candidates=%d), us:' % tuple(int(it.packed.meta[int(ep.sched._host[0]), q]) for q in (0, 1, 2)))
 for a, b2 in zip(keys[:-1], keys[1:]):
