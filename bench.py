@@ -203,7 +203,7 @@ def main():
     # is enough) -- inside a container with a CPU quota (16 cores on this pool) that burns the quota and the whole process is
     # throttled for the rest of the 100 ms period: 60-90 ms host stalls at random places, 1.1 instead of 0.4 ms per step at the
     # reference dims (profiles/r04_lab_host_stalls.log).  cpu_baseline() sets its own thread counts for its sweep.
-    torch.set_num_threads(1)
+    torch.set_num_threads(int(os.environ.get('UPAMD_BENCH_THREADS', '1')))      # (the variable: lab A/B only)
 
     # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1 behind Python's back (RCCL prints
     # its WARN / version lines there, from its own threads, and they were found spliced INTO the JSON line) are sent to stderr
