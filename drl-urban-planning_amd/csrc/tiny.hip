@@ -32,7 +32,9 @@ __global__ __launch_bounds__(NT) void tiny_kernel(Args A, Plan pl) {
     float *slab = A.slab ? A.slab + (int64_t)blockIdx.x * A.slab_stride : nullptr;
     float *gscr = A.scratch ? A.scratch + (int64_t)blockIdx.x * A.scratch_stride : nullptr;
     if (A.mode != FWD) {
-        T_FOR(i, A.o.n_floats) slab[i] = 0.0f;
+        // (16-byte stores: slab_stride is a multiple of 4 floats and the buffer 256-byte aligned)
+        f4 *s4 = reinterpret_cast<f4 *>(slab);
+        T_FOR(i, (int)(A.slab_stride / 4)) s4[i] = f4{0.0f, 0.0f, 0.0f, 0.0f};
         T_SYNC();
     }
     for (int b = blockIdx.x; b < A.B; b += gridDim.x) graph_program<D>(A, b, slab, gscr, tiny_lds, pl);

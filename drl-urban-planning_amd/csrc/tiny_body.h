@@ -25,6 +25,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #ifdef TINY_HOST
 #include <math.h>
 #define TDEV static inline
@@ -142,7 +144,7 @@ THD int np2(int x) {
 
 // ---- LDS plan (floats).  n / inc / cand = the LARGEST graph of the launch: one plan per launch, every graph uses its prefix.
 struct Plan {
-    int64_t H, X, PQ, rp, nb, ord, alpha, sc, vec, total;      // offsets
+    int64_t H, X, PQ, rp, nb, ord, alpha, sc, nm, vec, total;      // offsets
     int64_t xsize, vsize;
 };
 // head scratch inside the X region: z [nc] | candidate lists (2 u16 + 1 u8 per candidate -> 1.25 floats, kept at 1.5) | chunk buffers
@@ -157,7 +159,8 @@ THD int64_t vec_floats(const Dims &d) {
     for (int i = 0; i < d.n_value; ++i) v += d.value_hidden[i];
     const int64_t D = d.D, Hd = (int64_t)d.heads * d.D, h0 = imax(d.h0l, d.h0r);
     //     U        cur   16 D-vectors   10 head vectors   SV, dSV     V, dV      A, M (h0 x D)  const, s, w2..   partials   scalars + slack
-    return u + XPAD + 16 * D + 10 * Hd + 2 * a4(d.W) + 2 * a4(v) + 3 * h0 * D + 8 * h0 + part_floats(d) + 64 + 256;
+    return u + XPAD + 16 * D + 10 * Hd + 2 * a4(d.W) + 2 * a4(v) + 3 * h0 * D + 8 * h0 + part_floats(d) + 64 + 256 +
+           D * XPAD;      // + the staged node-encoder rows (padded to XPAD)
 }
 THD Plan plan_layout(const Dims &d, int n, int inc, int cand, int64_t x_extra) {
     Plan p;
@@ -174,6 +177,7 @@ THD Plan plan_layout(const Dims &d, int n, int inc, int cand, int64_t x_extra) {
     p.ord = o; o += a4((n + 1) / 2 + 1);                                           // u16 node ids in processing (degree-sorted) order
     p.alpha = o; o += a4((int64_t)d.heads * n);
     p.sc = o; o += a4((int64_t)d.heads * n);
+    p.nm = o; o += a4((n + 3) / 4);                                                // node_mask bytes
     p.vsize = vec_floats(d);
     p.vec = o; o += a4(p.vsize);
     p.total = o;
@@ -256,6 +260,65 @@ TDEV float dot_g(const float *w, const float *x, int K, float acc = 0.0f) {
         for (int q = 0; q < 8; ++q) acc = k + q < K ? fmaf(a[q], x[k + q], acc) : acc;
     }
     return acc;
+}
+// Serial sums over LDS operands: a loop `acc = fmaf(a[t], b[t], acc)` that waits for its two loads in every iteration costs an LDS
+// round trip (~100 cycles) per term, and a phase's few waves cannot hide it.  These keep SB loads of each operand in flight and add
+// in index order (the same bits as the plain loop).  A short tail re-reads the last term and masks the add.
+constexpr int SB = 8;
+TDEV int cnt_s(int n, int first, int step) { return first < n ? (n - first + step - 1) / step : 0; }      // terms of `for (v = first; v < n; v += step)`
+TDEV float dot_s(const float *a, int sa, const float *b, int sb, int cnt, float acc) {
+    int t = 0;
+    for (; t + SB <= cnt; t += SB) {
+        float x[SB], y[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+            x[q] = a[(int64_t)(t + q) * sa];
+            y[q] = b[(int64_t)(t + q) * sb];
+        }
+#pragma unroll
+        for (int q = 0; q < SB; ++q) acc = fmaf(x[q], y[q], acc);
+    }
+    if (t < cnt) {
+        float x[SB], y[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+            const int tt = t + q < cnt ? t + q : cnt - 1;
+            x[q] = a[(int64_t)tt * sa];
+            y[q] = b[(int64_t)tt * sb];
+        }
+#pragma unroll
+        for (int q = 0; q < SB; ++q) acc = t + q < cnt ? fmaf(x[q], y[q], acc) : acc;
+    }
+    return acc;
+}
+TDEV float sum_s(const float *a, int sa, int cnt, float acc) {
+    int t = 0;
+    for (; t + SB <= cnt; t += SB) {
+        float x[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) x[q] = a[(int64_t)(t + q) * sa];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) acc += x[q];
+    }
+    if (t < cnt) {
+        float x[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) x[q] = a[(int64_t)(t + q < cnt ? t + q : cnt - 1) * sa];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) acc = t + q < cnt ? acc + x[q] : acc;
+    }
+    return acc;
+}
+TDEV float max_s(const float *a, int sa, int cnt, float mx) {
+    int t = 0;
+    for (; t < cnt; t += SB) {
+        float x[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) x[q] = a[(int64_t)(t + q < cnt ? t + q : cnt - 1) * sa];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) mx = fmaxf(mx, x[q]);
+    }
+    return mx;
 }
 // sum_j W[j * ld + k] in[j], j in [j0, j1): strided weights, 16 loads in flight
 TDEV float dot_t(const float *W, int ld, int k, const float *in, int j0, int j1) {
@@ -347,7 +410,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     const uint16_t *rnn = A.rn_node + m[12];
     const int32_t *hpg = A.hinc_ptr + m[13];
     const uint16_t *hnb = A.hinc_nbr + 2 * (int64_t)m[11], *hhe = A.hinc_he + 2 * (int64_t)m[11];
-    const int L = d.L, Hn = d.heads, dh = D / Hn, inc = 2 * e, F = d.F;
+    const int L = d.L, Hn = d.heads, dh = D / Hn, F = d.F;
     const int nD = n * D;
     const bool land = stage == 0 && nc > 0, road = stage == 1 && nc > 0;
     const bool bwd = A.mode != FWD;
@@ -360,6 +423,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     uint16_t *nb = reinterpret_cast<uint16_t *>(lds + pl.nb);
     uint16_t *ord = reinterpret_cast<uint16_t *>(lds + pl.ord);      // the packer's degree-sorted order: a wave's nodes walk lists of similar length
     float *alpha = lds + pl.alpha, *sc = lds + pl.sc;
+    uint8_t *nm = reinterpret_cast<uint8_t *>(lds + pl.nm);
     Bump vb{lds + pl.vec, 0};
     auto slotH = [&](int l) -> float * { return Hs + (int64_t)(l - 1) * nD; };
 
@@ -389,17 +453,38 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     float *du = vb.get(Hn * D), *ds = vb.get(Hn * D), *dr = vb.get(Hn * D), *dtk = vb.get(Hn * D);
     float *dVa = vb.get(64), *dVb = vb.get(64);  // ping-pong of the small MLPs' backward (hidden <= 64)
     float *Mj = vb.get((int64_t)h0m * D), *sj = vb.get(h0m), *dw2 = vb.get(h0m);
+    // The node encoder's weight rows (F = 23 floats: unaligned scalar loads, 23 per thread) are staged once per graph, padded to
+    // XPAD: encode_nodes went from 7.8 to 3.8 us.  (The same for the GCN layers' aligned 16-float rows bought nothing.)
+    float *weS = vb.get((int64_t)D * XPAD);      // row c = We[c][0 .. F) then zeros
 
     // =============================================================================== forward
     T_MARK(0);
     // lists, per-sample inputs, the raw node features
-    T_FOR(i, n + 1) rp[i] = rpg[i];
-    T_FOR(i, inc) nb[i] = nbg[i];
-    T_FOR(i, n) ord[i] = og[i];
+    // (global -> LDS copies: a thread's loads -- up to four, a quarter of the range apart -- are all issued before its first store;
+    // a plain strided loop waits out one HBM round trip per iteration, and the 27 KB of raw features were six of them)
+    auto copy4 = [&](auto *dst, const auto *src, int cnt) {
+        const int Q = (cnt + 3) / 4;
+        T_FOR(i, Q) {
+            typename std::remove_cv<typename std::remove_reference<decltype(*src)>::type>::type v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = src[i + q * Q < cnt ? i + q * Q : cnt - 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i + q * Q < cnt) dst[i + q * Q] = v[q];
+        }
+    };
+    copy4(rp, rpg, n + 1);
+    copy4(reinterpret_cast<uint32_t *>(nb), reinterpret_cast<const uint32_t *>(nbg), e);      // (two u16 ids per word; inc = 2 e)
+    copy4(ord, og, n);
+    copy4(nm, nmg, n);
+    T_FOR(i, D * XPAD) {
+        const int c = i / XPAD, f = i - c * XPAD;
+        weS[i] = f < F ? prm[o.node_w + (int64_t)c * F + f] : 0.0f;
+    }
     T_FOR(i, d.Fn) U[0][i] = A.numerical[(int64_t)t * d.Fn + i];
     T_FOR(i, XPAD) cur[i] = A.cur[(int64_t)t * XPAD + i];
     T_FOR(i, MAXL + 1) bad[i] = 0;
-    auto stage_x = [&]() { T_FOR(i, n * XPAD) Xs[i] = Xg[i]; };
+    auto stage_x = [&]() { copy4(reinterpret_cast<f4 *>(Xs), reinterpret_cast<const f4 *>(Xg), n * (XPAD / 4)); };      // (rows of 96 B)
     stage_x();
     T_SYNC();
     // numerical encoder (state_encoder.py:35-57,187)
@@ -430,12 +515,12 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     T_MARK(2);
 
     // node encoder on every node (:189-190): H^0 from the staged raw features; thread = one output column, its weight row in registers
-    const float *We = prm + o.node_w, *be = prm + o.node_b;
+    const float *be = prm + o.node_b;
     auto encode_nodes = [&](float *dst) {
         T_FOR_J(c, D) {
             float w[XPAD];
 #pragma unroll
-            for (int f = 0; f < XPAD; ++f) w[f] = f < F ? We[(int64_t)c * F + f] : 0.0f;
+            for (int f = 0; f < XPAD; ++f) w[f] = weS[c * XPAD + f];
             const float bc = be[c];
             T_FOR_V(v, n, D) {
                 const float *x = Xs + (int64_t)v * XPAD;
@@ -539,16 +624,27 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         const int g = i / (2 * D), c = i - g * 2 * D;
         float acc = 0.0f;
         if (c < D) {
-            for (int v = g; v < n; v += NG) acc += nmg[v] ? HL[v * D + c] : 0.0f;
+            const int cnt = cnt_s(n, g, NG);
+            for (int t0 = 0; t0 < cnt; t0 += SB) {
+                float x[SB];
+                uint8_t k8[SB];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    const int v = g + (t0 + q < cnt ? t0 + q : cnt - 1) * NG;
+                    x[q] = HL[v * D + c];
+                    k8[q] = nm[v];
+                }
+#pragma unroll
+                for (int q = 0; q < SB; ++q) acc += (t0 + q < cnt && k8[q]) ? x[q] : 0.0f;
+            }
         } else {
-            for (int v = g; v < n; v += NG) acc += Xr[v * D + c - D];
+            acc = sum_s(Xr + g * D + c - D, NG * D, cnt_s(n, g, NG), acc);
         }
         part[i] = acc;
     }
     T_SYNC();
     T_FOR(c, 2 * D) {
-        float acc = 0.0f;
-        for (int g = 0; g < NG; ++g) acc += part[g * 2 * D + c];
+        const float acc = sum_s(part + c, 2 * D, NG, 0.0f);
         if (c < D) hbarV[c] = acc * (1.0f / (float)m[6]);
         else hbarE[c - D] = acc * (0.5f / (float)e);
     }
@@ -566,39 +662,29 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 const int kk = (k + v) & (D - 1);
                 acc = fmaf(r[kk], HL[v * D + kk], acc);
             }
-            sch[v] = nmg[v] ? acc : -INFINITY;
+            sch[v] = nm[v] ? acc : -INFINITY;
         }
         T_SYNC();
         T_FOR(g, NG) {
-            float mx = -INFINITY;
-            for (int v = g; v < n; v += NG) mx = fmaxf(mx, sch[v]);
-            part[g] = mx;
+            part[g] = max_s(sch + g, NG, cnt_s(n, g, NG), -INFINITY);
         }
         T_SYNC();
         T_FOR(v, n) {                            // (every iteration combines the NG partial maxima itself: no extra phase)
-            float mx = -INFINITY;
-            for (int g = 0; g < NG; ++g) mx = fmaxf(mx, part[g]);
-            al[v] = nmg[v] ? t_exp(sch[v] - mx) : 0.0f;
+            const float mx = max_s(part, 1, NG, -INFINITY);
+            al[v] = nm[v] ? t_exp(sch[v] - mx) : 0.0f;
         }
         T_SYNC();
         // partial sums of alpha (column D) and of alpha * H^L (columns 0..D-1)
         T_FOR(i, NG * (D + 1)) {
             const int g = i / (D + 1), c = i - g * (D + 1);
             float acc = 0.0f;
-            if (c < D) {
-                for (int v = g; v < n; v += NG) acc = fmaf(al[v], HL[v * D + c], acc);
-            } else {
-                for (int v = g; v < n; v += NG) acc += al[v];
-            }
+            if (c < D) acc = dot_s(al + g, NG, HL + g * D + c, NG * D, cnt_s(n, g, NG), acc);
+            else acc = sum_s(al + g, NG, cnt_s(n, g, NG), acc);
             part[i] = acc;
         }
         T_SYNC();
         T_FOR(c, D + 1) {
-            float sum = 0.0f, acc = 0.0f;
-            for (int g = 0; g < NG; ++g) {
-                sum += part[g * (D + 1) + D];
-                acc += part[g * (D + 1) + (c < D ? c : 0)];
-            }
+            const float sum = sum_s(part + D, D + 1, NG, 0.0f), acc = sum_s(part + (c < D ? c : 0), D + 1, NG, 0.0f);
             const float inv = 1.0f / sum;
             if (c < D) ss[h * D + c] = acc * inv;
             else scal[8 + h] = inv;
@@ -735,45 +821,52 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             cand_hidden(cn, mq, hid);
             if (c0 == 0) T_MARK(23);
             T_FOR(q, cn) {
-                float acc = 0.0f;
-                for (int j = 0; j < h0; ++j) acc = fmaf(w2v[j], hid[q * hs + j], acc);
-                z[c0 + q] = acc;
+                z[c0 + q] = dot_s(w2v, 1, hid + q * hs, 1, h0, 0.0f);
             }
             T_SYNC();
         }
         T_MARK(24);
         // log-softmax over the candidates, log-prob of the action, entropy
         T_FOR(g, NG) {
-            float mx = -INFINITY;
-            for (int q = g; q < nc; q += NG) mx = fmaxf(mx, z[q]);
-            part[g] = mx;
+            part[g] = max_s(z + g, NG, cnt_s(nc, g, NG), -INFINITY);
         }
         T_SYNC();
         T_FOR(g, NG) {
-            float mx = -INFINITY;
-            for (int gg = 0; gg < NG; ++gg) mx = fmaxf(mx, part[gg]);
+            const float mx = max_s(part, 1, NG, -INFINITY);
             float sum = 0.0f;
-            for (int q = g; q < nc; q += NG) sum += t_exp(z[q] - mx);
+            const int cnt = cnt_s(nc, g, NG);
+            for (int t0 = 0; t0 < cnt; t0 += SB) {
+                float x[SB];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) x[q] = z[g + (t0 + q < cnt ? t0 + q : cnt - 1) * NG];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) sum += t0 + q < cnt ? t_exp(x[q] - mx) : 0.0f;
+            }
             part[NG + g] = sum;
             if (g == 0) scal[0] = mx;
         }
         T_SYNC();
         T_FOR(g, NG) {
-            float sum = 0.0f;
-            for (int gg = 0; gg < NG; ++gg) sum += part[NG + gg];
+            const float sum = sum_s(part + NG, 1, NG, 0.0f);
             const float lse = scal[0] + t_log(sum);
             float pz = 0.0f;
-            for (int q = g; q < nc; q += NG) {
-                const float lp = z[q] - lse;
-                pz += t_exp(lp) * lp;
+            const int cnt = cnt_s(nc, g, NG);
+            for (int t0 = 0; t0 < cnt; t0 += SB) {
+                float x[SB];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) x[q] = z[g + (t0 + q < cnt ? t0 + q : cnt - 1) * NG];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    const float lp = x[q] - lse;
+                    pz += t0 + q < cnt ? t_exp(lp) * lp : 0.0f;
+                }
             }
             part[2 * NG + g] = pz;
             if (g == 0) scal[1] = lse;
         }
         T_SYNC();
         T_FOR(g, 1) {
-            float pz = 0.0f;
-            for (int gg = 0; gg < NG; ++gg) pz += part[2 * NG + gg];
+            const float pz = sum_s(part + 2 * NG, 1, NG, 0.0f);
             scal[2] = -pz;
             scal[3] = (act >= 0 ? z[act] : PAD_LOGIT) - scal[1];
         }
@@ -927,28 +1020,21 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         }
         T_SYNC();
         T_FOR(g, NG) {
-            float sum = 0.0f;
-            for (int v = g; v < n; v += NG) sum += al[v] * tj[v];
-            part[g] = sum;
+            part[g] = dot_s(al + g, NG, tj + g, NG, cnt_s(n, g, NG), 0.0f);
         }
         T_SYNC();
         T_FOR(v, n) {
-            float T = 0.0f;
-            for (int g = 0; g < NG; ++g) T += part[g];
+            const float T = sum_s(part, 1, NG, 0.0f);
             tj[v] = al[v] * (tj[v] - T);         // dscore_j (0 on nodes outside the mask: alpha = 0)
         }
         T_SYNC();
         T_FOR(i, NG * D) {
             const int g = i / D, c = i - g * D;
-            float acc = 0.0f;
-            for (int v = g; v < n; v += NG) acc = fmaf(tj[v], HL[v * D + c], acc);
-            part[i] = acc;
+            part[i] = dot_s(tj + g, NG, HL + g * D + c, NG * D, cnt_s(n, g, NG), 0.0f);
         }
         T_SYNC();
         T_FOR(c, D) {
-            float acc = 0.0f;
-            for (int g = 0; g < NG; ++g) acc += part[g * D + c];
-            dr[h * D + c] = acc;
+            dr[h * D + c] = sum_s(part + c, D, NG, 0.0f);
         }
         T_SYNC();
     }
@@ -988,25 +1074,17 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             // candidate inputs dm[k][c] = sum_j A[j][c] dpre[k][j]  (land: only live candidates carry it on)
             T_FOR(i, h0 + h0 * D) {
                 if (i < h0) {
-                    float a1 = dw2[i], a2 = sj[i];
-                    for (int q = 0; q < cn; ++q) {
-                        a1 += hid[q * hs + i];
-                        a2 += dpre[q * hs + i];
-                    }
-                    dw2[i] = a1;
-                    sj[i] = a2;
+                    dw2[i] = sum_s(hid + i, hs, cn, dw2[i]);
+                    sj[i] = sum_s(dpre + i, hs, cn, sj[i]);
                 } else {
                     const int ii = i - h0, j = ii / D, c = ii - j * D;
-                    float acc = Mj[ii];
-                    for (int q = 0; q < cn; ++q) acc = fmaf(dpre[q * hs + j], mq[q * D + c], acc);
-                    Mj[ii] = acc;
+                    Mj[ii] = dot_s(dpre + j, hs, mq + c, D, cn, Mj[ii]);
                 }
             }
             float *dst = land ? dMg : dXR;
             T_FOR_J(c, D) {
                 T_FOR_V(q, cn, D) {
-                    float acc = 0.0f;
-                    for (int j = 0; j < h0; ++j) acc = fmaf(Aeff[j * D + c], dpre[q * hs + j], acc);
+                    float acc = dot_s(Aeff + c, D, dpre + q * hs, 1, h0, 0.0f);
                     if (land && !cl_live[c0 + q]) acc = 0.0f;
                     dst[(int64_t)(c0 + q) * D + c] = acc;
                 }
@@ -1035,9 +1113,19 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 } else {
                     const int c = i - h0 * D - h0;
                     float acc = 0.0f;
-                    for (int j = 0; j < h0; ++j) {
-                        const float *w = W1 + (int64_t)j * 4 * D;
-                        acc += (w[D + c] - w[3 * D + c]) * sj[j] + w[2 * D + c] * Mj[j * D + c];
+                    for (int j0 = 0; j0 < h0; j0 += SB) {       // (h0 % 16 == 0; the weights come from L2: all of a batch in flight)
+                        float wb[SB], wd[SB], wc[SB], s8[SB], m8[SB];
+#pragma unroll
+                        for (int q = 0; q < SB; ++q) {
+                            const float *w = W1 + (int64_t)(j0 + q) * 4 * D;
+                            wb[q] = w[D + c];
+                            wd[q] = w[3 * D + c];
+                            wc[q] = w[2 * D + c];
+                            s8[q] = sj[j0 + q];
+                            m8[q] = Mj[(j0 + q) * D + c];
+                        }
+#pragma unroll
+                        for (int q = 0; q < SB; ++q) acc += (wb[q] - wd[q]) * s8[q] + wc[q] * m8[q];
                     }
                     dC[c] = acc;
                 }
@@ -1056,7 +1144,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     T_FOR_J(c, D) {
         const float gm = dhbarV[c] / (float)m[6];
         T_FOR_V(v, n, D) {
-            float g = nmg[v] ? gm : 0.0f;
+            float g = nm[v] ? gm : 0.0f;
             for (int h = 0; h < Hn; ++h) g += alpha[(int64_t)h * n + v] * ds[h * D + c] + sc[(int64_t)h * n + v] * rr[h * D + c];
             HL[v * D + c] = g;
         }
@@ -1212,14 +1300,10 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             T_FOR(i, NGW * D * D + NG * HC) {
                 if (i < NGW * D * D) {
                     const int g = i / (D * D), r = i - g * D * D, jj = r / D, k = r - jj * D;
-                    float acc = 0.0f;
-                    for (int v = g; v < n; v += NGW) acc = fmaf(dPQh[v * D + jj], Hprev[v * D + k], acc);
-                    part[i] = acc;
+                    part[i] = dot_s(dPQh + g * D + jj, NGW * D, Hprev + g * D + k, NGW * D, cnt_s(n, g, NGW), 0.0f);
                 } else {
                     const int ii = i - NGW * D * D, g = ii / HC, cc = ii - g * HC;
-                    float acc = 0.0f;
-                    for (int v = g; v < n; v += NG) acc += dPQh[v * D + cc];
-                    part[i] = acc;
+                    part[i] = sum_s(dPQh + g * D + cc, NG * D, cnt_s(n, g, NG), 0.0f);
                 }
             }
             T_FOR_J(k, D) {
@@ -1245,9 +1329,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                     gW[(int64_t)(cb + jj % HC) * (2 * D) + (jj / HC) * D + k] += acc;
                 } else {
                     const int cc = i - D * D;
-                    float acc = 0.0f;
-                    for (int g = 0; g < NG; ++g) acc += part[NGW * D * D + g * HC + cc];
-                    gB[cb + cc] += acc;
+                    gB[cb + cc] += sum_s(part + NGW * D * D + cc, HC, NG, 0.0f);
                 }
             }
             T_SYNC();
@@ -1261,13 +1343,8 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     constexpr int NGX = 2;                       // node groups of the partial sums
     T_FOR(i, NGX * D * (F + 1)) {
         const int g = i / (D * (F + 1)), r = i - g * D * (F + 1), c = r / (F + 1), f = r - c * (F + 1);
-        float acc = 0.0f;
-        if (f < F) {
-            for (int v = g; v < n; v += NGX) acc = fmaf(Gn[v * D + c], Xs[v * XPAD + f], acc);
-        } else {
-            for (int v = g; v < n; v += NGX) acc += Gn[v * D + c];
-        }
-        part[i] = acc;
+        if (f < F) part[i] = dot_s(Gn + g * D + c, NGX * D, Xs + g * XPAD + f, NGX * XPAD, cnt_s(n, g, NGX), 0.0f);
+        else part[i] = sum_s(Gn + g * D + c, NGX * D, cnt_s(n, g, NGX), 0.0f);
     }
     T_SYNC();
     T_FOR(i, D * (F + 1)) {

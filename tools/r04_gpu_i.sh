@@ -1,5 +1,5 @@
-# round 4: column-pair walks in the fused small-model kernel
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r04i; mkdir -p $O
+# round 4: batched serial LDS sums in the fused small-model kernel
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r04m; mkdir -p $O
 (timeout 900 python -m pytest tests/test_gpu_tiny.py -m gpu -q -x 2>&1 | tail -5) > $O/gpu_tests_tiny.log 2>&1
 OMP_NUM_THREADS=1 timeout 300 python tools/r04_diag_tiny.py > $O/diag.log 2>&1
 for t in 1024 512; do
