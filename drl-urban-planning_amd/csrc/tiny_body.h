@@ -49,11 +49,19 @@ static inline float t_log(float x) { return logf(x); }
 #define TDEV __device__ __forceinline__
 #define TMEM __device__ __forceinline__
 #define THD __host__ __device__ inline
-#define T_FOR(i, N) for (int i = (int)threadIdx.x; i < (N); i += (int)blockDim.x)
+// The thread id of a phase is laundered through an empty asm: what a phase derives from it (tid / 16, LDS addresses, ...) is then
+// recomputed per phase (a few VALU instructions) instead of being shared across ALL phases by common-subexpression elimination and
+// held live for the whole program -- which is what had the 128-VGPR variant spill ~100 registers and serialise loads through scratch.
+static __device__ __forceinline__ int t_tid() {
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+#define T_FOR(i, N) for (int i = t_tid(); i < (N); i += (int)blockDim.x)
 // thread -> (j = tid % NJP, first v = tid / NJP), NJP = NJ rounded up to a power of two (it divides the block size)
-#define T_FOR_J(j, NJ) for (int j = (int)threadIdx.x & (upamd_tiny::np2(NJ) - 1), _once = 1; _once && j < (NJ); _once = 0)
+#define T_FOR_J(j, NJ) for (int j = t_tid() & (upamd_tiny::np2(NJ) - 1), _once = 1; _once && j < (NJ); _once = 0)
 #define T_FOR_V(v, NV, NJ) \
-    for (int v = (int)threadIdx.x / upamd_tiny::np2(NJ), _vs = (int)blockDim.x / upamd_tiny::np2(NJ); v < (NV); v += _vs)
+    for (int v = t_tid() / upamd_tiny::np2(NJ), _vs = (int)blockDim.x / upamd_tiny::np2(NJ); v < (NV); v += _vs)
 #define T_SYNC() __syncthreads()
 // section time stamps (100 MHz wall clock) of the FIRST graph of workgroup 0 into A.prof (lab hook, null in production)
 #define T_MARK(k)                                                                                \
@@ -211,6 +219,32 @@ struct Bump {
 struct f4 {
     float x, y, z, w;
 };
+// A row of K floats (16-byte aligned, K % 4 == 0) out of LDS into registers with ALL its 16-byte loads issued before the first use.
+// Written as `acc = fmaf(w[k], row[k], acc)` over the LDS pointer, hipcc pairs every 8-byte read with its two FMAs and waits for
+// each one: eight serial LDS round trips per 16-float row (seen in the ISA), 3 of a P | Q phase's 7 us.
+#ifdef TINY_HOST
+template <int K>
+TDEV void ld_row(const float *p, float (&x)[K]) {
+    for (int k = 0; k < K; ++k) x[k] = p[k];
+}
+#else
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int K>
+TDEV void ld_row(const float *p, float (&x)[K]) {
+    const f4v *p4 = reinterpret_cast<const f4v *>(p);
+    f4v v[K / 4];
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q) v[q] = p4[q];
+    __builtin_amdgcn_sched_barrier(0);           // (keeps the loads together: the scheduler otherwise sinks each to its consumer)
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q) {
+        x[4 * q] = v[q].x;
+        x[4 * q + 1] = v[q].y;
+        x[4 * q + 2] = v[q].z;
+        x[4 * q + 3] = v[q].w;
+    }
+}
+#endif
 TDEV float dot_g(const float *w, const float *x, int K, float acc = 0.0f) {
     int k = 0;
     if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
@@ -473,19 +507,87 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
                 if (i + q * Q < cnt) dst[i + q * Q] = v[q];
         }
     };
-    copy4(rp, rpg, n + 1);
-    copy4(reinterpret_cast<uint32_t *>(nb), reinterpret_cast<const uint32_t *>(nbg), e);      // (two u16 ids per word; inc = 2 e)
-    copy4(ord, og, n);
-    copy4(nm, nmg, n);
-    T_FOR(i, D * XPAD) {
-        const int c = i / XPAD, f = i - c * XPAD;
-        weS[i] = f < F ? prm[o.node_w + (int64_t)c * F + f] : 0.0f;
-    }
-    T_FOR(i, d.Fn) U[0][i] = A.numerical[(int64_t)t * d.Fn + i];
-    T_FOR(i, XPAD) cur[i] = A.cur[(int64_t)t * XPAD + i];
-    T_FOR(i, MAXL + 1) bad[i] = 0;
     auto stage_x = [&]() { copy4(reinterpret_cast<f4 *>(Xs), reinterpret_cast<const f4 *>(Xg), n * (XPAD / 4)); };      // (rows of 96 B)
-    stage_x();
+    const uint32_t *nbg2 = reinterpret_cast<const uint32_t *>(nbg);      // (two u16 ids per word; inc = 2 e)
+    uint32_t *nb2 = reinterpret_cast<uint32_t *>(nb);
+    const f4 *Xg4 = reinterpret_cast<const f4 *>(Xg);
+    f4 *Xs4 = reinterpret_cast<f4 *>(Xs);
+    const int nx4 = n * (XPAD / 4);
+#ifdef TINY_HOST
+    for (int i = 0; i < n + 1; ++i) rp[i] = rpg[i];
+    for (int i = 0; i < e; ++i) nb2[i] = nbg2[i];
+    for (int i = 0; i < n; ++i) ord[i] = og[i];
+    for (int i = 0; i < n; ++i) nm[i] = nmg[i];
+    for (int i = 0; i < nx4; ++i) Xs4[i] = Xg4[i];
+    for (int i = 0; i < D * XPAD; ++i) weS[i] = i % XPAD < F ? prm[o.node_w + (int64_t)(i / XPAD) * F + i % XPAD] : 0.0f;
+    for (int i = 0; i < d.Fn; ++i) U[0][i] = A.numerical[(int64_t)t * d.Fn + i];
+    for (int i = 0; i < XPAD; ++i) cur[i] = A.cur[(int64_t)t * XPAD + i];
+#else
+    {
+        // EVERY global load of the staging phase is issued before the first LDS store.  Written as one copy loop per array, each loop
+        // waited for its own loads before storing -- eight dependent HBM round trips, 38 us of a 250 us graph (barrier trace,
+        // tools/lab_trace).  A thread takes elements tid, tid + NT, ... of each array (clamped loads, masked stores); what an array
+        // has beyond the fixed count goes through a plain loop afterwards (never at the shipped sizes).
+        const int tid = t_tid(), NT = (int)blockDim.x;
+        constexpr int K_RP = 2, K_NB = 4, K_ORD = 2, K_X = 4, K_WE = 2;
+        int r_rp[K_RP];
+        uint32_t r_nb[K_NB];
+        uint16_t r_ord[K_ORD];
+        uint8_t r_nm[K_ORD];
+        f4 r_x[K_X];
+        float r_we[K_WE], r_u = 0.0f, r_cur = 0.0f;
+        auto at = [&](int k, int cnt) { const int idx = tid + k * NT; return idx < cnt ? idx : (cnt > 0 ? cnt - 1 : 0); };
+#pragma unroll
+        for (int k = 0; k < K_RP; ++k) r_rp[k] = rpg[at(k, n + 1)];
+#pragma unroll
+        for (int k = 0; k < K_NB; ++k) r_nb[k] = nbg2[at(k, e)];
+#pragma unroll
+        for (int k = 0; k < K_ORD; ++k) {
+            r_ord[k] = og[at(k, n)];
+            r_nm[k] = nmg[at(k, n)];
+        }
+#pragma unroll
+        for (int k = 0; k < K_X; ++k) r_x[k] = Xg4[at(k, nx4)];
+#pragma unroll
+        for (int k = 0; k < K_WE; ++k) {
+            const int idx = at(k, D * XPAD), c = idx / XPAD, f = idx - c * XPAD;
+            r_we[k] = prm[o.node_w + (int64_t)c * F + (f < F ? f : 0)];
+            if (f >= F) r_we[k] = 0.0f;
+        }
+        if (tid < d.Fn) r_u = A.numerical[(int64_t)t * d.Fn + tid];
+        if (tid < XPAD) r_cur = A.cur[(int64_t)t * XPAD + tid];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < K_RP; ++k)
+            if (tid + k * NT < n + 1) rp[tid + k * NT] = r_rp[k];
+#pragma unroll
+        for (int k = 0; k < K_NB; ++k)
+            if (tid + k * NT < e) nb2[tid + k * NT] = r_nb[k];
+#pragma unroll
+        for (int k = 0; k < K_ORD; ++k)
+            if (tid + k * NT < n) {
+                ord[tid + k * NT] = r_ord[k];
+                nm[tid + k * NT] = r_nm[k];
+            }
+#pragma unroll
+        for (int k = 0; k < K_X; ++k)
+            if (tid + k * NT < nx4) Xs4[tid + k * NT] = r_x[k];
+#pragma unroll
+        for (int k = 0; k < K_WE; ++k)
+            if (tid + k * NT < D * XPAD) weS[tid + k * NT] = r_we[k];
+        if (tid < d.Fn) U[0][tid] = r_u;
+        if (tid < XPAD) cur[tid] = r_cur;
+        for (int i = tid + K_RP * NT; i < n + 1; i += NT) rp[i] = rpg[i];
+        for (int i = tid + K_NB * NT; i < e; i += NT) nb2[i] = nbg2[i];
+        for (int i = tid + K_ORD * NT; i < n; i += NT) {
+            ord[i] = og[i];
+            nm[i] = nmg[i];
+        }
+        for (int i = tid + K_X * NT; i < nx4; i += NT) Xs4[i] = Xg4[i];
+        for (int i = tid + NT; i < d.Fn; i += NT) U[0][i] = A.numerical[(int64_t)t * d.Fn + i];
+    }
+#endif
+    T_FOR(i, MAXL + 1) bad[i] = 0;
     T_SYNC();
     // numerical encoder (state_encoder.py:35-57,187)
     {
@@ -523,7 +625,8 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             for (int f = 0; f < XPAD; ++f) w[f] = weS[c * XPAD + f];
             const float bc = be[c];
             T_FOR_V(v, n, D) {
-                const float *x = Xs + (int64_t)v * XPAD;
+                float x[XPAD];
+                ld_row<XPAD>(Xs + (int64_t)v * XPAD, x);
                 float acc = bc;
 #pragma unroll
                 for (int f = 0; f < XPAD; ++f) acc = fmaf(w[f], x[f], acc);
@@ -547,7 +650,8 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             for (int k = 0; k < D; ++k) w[k] = wr[k];
             float mx = fabsf(bl[j % D]) * (EF_LIMIT / EF_BIAS);          // (the bias limit folded into the same test)
             T_FOR_V(v, n, 2 * D) {
-                const float *h = Hin + (int64_t)v * D;
+                float h[D];
+                ld_row<D>(Hin + (int64_t)v * D, h);
                 float acc = 0.0f;
 #pragma unroll
                 for (int k = 0; k < D; ++k) acc = fmaf(w[k], h[k], acc);
@@ -763,7 +867,8 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             for (int c = 0; c < D; ++c) a[c] = AeffT[c * h0 + j];
             const float cj = cst[j];
             T_FOR_V(q, cn, h0) {
-                const float *x = mq + (int64_t)q * D;
+                float x[D];
+                ld_row<D>(mq + (int64_t)q * D, x);
                 float acc = cj;
 #pragma unroll
                 for (int c = 0; c < D; ++c) acc = fmaf(a[c], x[c], acc);
@@ -1234,7 +1339,8 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
 #pragma unroll
                 for (int k = 0; k < D; ++k) w[k] = wr[k];
                 T_FOR_V(v, n, D) {
-                    const float *h = Hprev + (int64_t)v * D;
+                    float h[D];
+                    ld_row<D>(Hprev + (int64_t)v * D, h);
                     float acc = 0.0f;
 #pragma unroll
                     for (int k = 0; k < D; ++k) acc = fmaf(w[k], h[k], acc);
@@ -1311,7 +1417,8 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
 #pragma unroll
                 for (int jj = 0; jj < D; ++jj) w[jj] = Wl[(int64_t)(cb + jj % HC) * (2 * D) + (jj / HC) * D + k];
                 T_FOR_V(v, n, D) {
-                    const float *dp = dPQh + (int64_t)v * D;
+                    float dp[D];
+                    ld_row<D>(dPQh + (int64_t)v * D, dp);
                     float acc = Gn[v * D + k];
 #pragma unroll
                     for (int jj = 0; jj < D; ++jj) acc = fmaf(dp[jj], w[jj], acc);
