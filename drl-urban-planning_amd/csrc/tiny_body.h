@@ -430,7 +430,20 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     const Offs &o = A.o;
     const float *prm = A.prm;
     const int t = A.idx[b];
-    const int32_t *m = A.meta + (int64_t)t * META;
+    const int32_t *mrow = A.meta + (int64_t)t * META;
+    int m[META];                                 // the row's 16 ints in ONE round trip (read field by field they were five)
+#ifdef TINY_HOST
+    for (int q = 0; q < META; ++q) m[q] = mrow[q];
+#else
+    {
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        const i4v *m4 = reinterpret_cast<const i4v *>(mrow);
+        const i4v a0 = m4[0], a1 = m4[1], a2 = m4[2], a3 = m4[3];
+        __builtin_amdgcn_sched_barrier(0);
+        m[0] = a0.x; m[1] = a0.y; m[2] = a0.z; m[3] = a0.w; m[4] = a1.x; m[5] = a1.y; m[6] = a1.z; m[7] = a1.w;
+        m[8] = a2.x; m[9] = a2.y; m[10] = a2.z; m[11] = a2.w; m[12] = a3.x; m[13] = a3.y; m[14] = a3.z; m[15] = a3.w;
+    }
+#endif
     const int n = m[0], e = m[1], stage = m[4], act = m[5];
     const int nc = stage == 0 ? m[2] : (stage == 1 ? m[3] : 0);      // candidates of the row's pointer head
     const int64_t node_off = m[9];

@@ -45,7 +45,10 @@ s = s.replace('#define T_FOR(i, N) for (int i = t_tid();', '''#define T_TRACE(ta
 anchors = [('    const int t = A.idx[b];\n', '    T_TRACE(1);\n', 'before'),
            ('    const int64_t node_off = m[9];\n', '    T_TRACE(2000 + (n & 1));\n', 'after'),
            ('    T_MARK(0);\n', '    T_TRACE(3);\n', 'before'),
-           ('    T_FOR(i, MAXL + 1) bad[i] = 0;\n', '    T_TRACE(4);\n', 'before')]
+           ('    T_FOR(i, MAXL + 1) bad[i] = 0;\n', '    T_TRACE(4);\n', 'before'),
+           ('        if (tid < XPAD) r_cur = A.cur[(int64_t)t * XPAD + tid];\n        __builtin_amdgcn_sched_barrier(0);\n',
+            '        if (tid < XPAD) r_cur = A.cur[(int64_t)t * XPAD + tid];\n        T_TRACE(31);\n        __builtin_amdgcn_sched_barrier(0);\n        T_TRACE(32000 + ((r_rp[0] + (int)r_nb[0] + (int)r_x[0].x + (int)r_we[0] + (int)r_u + (int)r_cur) & 1));\n', 'replace'),
+           ('        if (tid < XPAD) cur[tid] = r_cur;\n', '        T_TRACE(33);\n', 'after')]
 for anchor, ins, how in anchors:
     assert s.count(anchor) == 1, anchor
     if how == 'before':
