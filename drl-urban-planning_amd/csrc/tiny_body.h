@@ -35,6 +35,10 @@
 #define T_FOR(i, N) for (int i = 0; i < (N); ++i)
 #define T_FOR_J(j, NJ) for (int j = 0; j < (NJ); ++j)
 #define T_FOR_V(v, NV, NJ) for (int v = 0; v < (NV); ++v)
+#define T_FORM(i, N) T_FOR(i, N)
+#define T_FORM_J(j, NJ) T_FOR_J(j, NJ)
+#define T_FORM_V(v, NV, NJ) T_FOR_V(v, NV, NJ)
+#define T_FOR_SIDE(j, N) for (int j = 0; j < (N); ++j)
 #define T_SYNC() \
     do {         \
     } while (0)
@@ -57,11 +61,25 @@ static __device__ __forceinline__ int t_tid() {
     asm volatile("" : "+v"(t));
     return t;
 }
+static __device__ __forceinline__ int t_tidm() {      // ... of a main thread; beyond every range for the side wave
+    const int t = t_tid();
+    return t < (int)blockDim.x - 64 ? t : 0x3fffffff;
+}
 #define T_FOR(i, N) for (int i = t_tid(); i < (N); i += (int)blockDim.x)
 // thread -> (j = tid % NJP, first v = tid / NJP), NJP = NJ rounded up to a power of two (it divides the block size)
 #define T_FOR_J(j, NJ) for (int j = t_tid() & (upamd_tiny::np2(NJ) - 1), _once = 1; _once && j < (NJ); _once = 0)
 #define T_FOR_V(v, NV, NJ) \
     for (int v = t_tid() / upamd_tiny::np2(NJ), _vs = (int)blockDim.x / upamd_tiny::np2(NJ); v < (NV); v += _vs)
+// A phase may carry SIDE work: one layer of the per-sample chains (numerical encoder, query path), which depend on nothing the
+// graph phases produce until the attention.  The workgroup's last wave does it (T_FOR_SIDE) while the others do the phase's own
+// loops (T_FORM*: the same loops over blockDim - 64 threads); the phase's barrier publishes both.  A chain layer is one L2 round
+// trip for its weights and a barrier -- ~1.2 us as a phase of its own, nothing underneath a graph phase.
+#define T_MAIN ((int)blockDim.x - 64)
+#define T_FORM(i, N) for (int i = t_tidm(); i < (N); i += T_MAIN)
+#define T_FORM_J(j, NJ) \
+    for (int _t = t_tid(), j = _t & (upamd_tiny::np2(NJ) - 1), _once = _t < T_MAIN; _once && j < (NJ); _once = 0)
+#define T_FORM_V(v, NV, NJ) for (int v = t_tid() / upamd_tiny::np2(NJ), _vs = T_MAIN / upamd_tiny::np2(NJ); v < (NV); v += _vs)
+#define T_FOR_SIDE(j, N) for (int j = t_tid() - T_MAIN; (unsigned)j < (unsigned)(N); j += 64)
 #define T_SYNC() __syncthreads()
 // section time stamps (100 MHz wall clock) of the FIRST graph of workgroup 0 into A.prof (lab hook, null in production)
 #define T_MARK(k)                                                                                \
@@ -602,42 +620,48 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
 #endif
     T_FOR(i, MAXL + 1) bad[i] = 0;
     T_SYNC();
-    // numerical encoder (state_encoder.py:35-57,187)
-    {
-        int K = d.Fn;
-        for (int i = 0; i < d.n_num; ++i) {
-            lin(U[i + 1], U[i], prm + o.num_w[i], prm + o.num_b[i], d.num_hidden[i], K, 1);
-            K = d.num_hidden[i];
-        }
-    }
-    T_MARK(1);
-    // current node through the node encoder (:191), attention query path (:150-156 + MultiheadAttention's q projection)
-    lin(C, cur, prm + o.node_w, prm + o.node_b, D, F, 0);
-    lin(q0, C, prm + o.q_w, prm + o.q_b, D, D, 0);
+    // ---- per-sample chains of the forward, as SIDE work of the graph phases below (one layer per phase, in this order):
+    //   numerical encoder (state_encoder.py:35-57,187);  current node through the node encoder (:191);  attention query path
+    //   (:150-156 + MultiheadAttention's q projection);  r_h = Wk^T (Wik[head rows]^T q1[head rows]):  score_j = r_h . h_j
+    //   (key-side biases are softmax-shift invariant)
     const float scale = 1.0f / sqrtf((float)dh);
-    lin(q1, q0, prm + o.inproj_w, prm + o.inproj_b, D, D, 0, scale);
-    // r_h = Wk^T (Wik[head rows]^T q1[head rows]):  score_j = r_h . h_j   (key-side biases are softmax-shift invariant)
-    T_FOR(i, Hn * D) {
-        const int h = i / D, k = i - h * D;
-        tk[i] = dot_t(prm + o.inproj_w + (int64_t)D * D, D, k, q1, h * dh, (h + 1) * dh);
-    }
-    T_SYNC();
-    T_FOR(i, Hn * D) {
-        const int h = i / D, k = i - h * D;
-        rr[i] = dot_t(prm + o.k_w, D, k, tk + h * D, 0, D);
-    }
-    T_SYNC();
+    int side_k = 0;
+    const int side_n = d.n_num + 5;
+    auto side_step = [&]() {
+        const int k = side_k++;
+#pragma unroll
+        for (int i = 0; i < MAXMLP; ++i)
+            if (k == i && i < d.n_num) {
+                const int K = i == 0 ? d.Fn : d.num_hidden[i > 0 ? i - 1 : 0];
+                T_FOR_SIDE(jj, d.num_hidden[i])
+                    U[i + 1][jj] = t_tanh(dot_g(prm + o.num_w[i] + (int64_t)jj * K, U[i], K, prm[o.num_b[i] + jj]));
+            }
+        const int kc = k - d.n_num;
+        if (kc == 0) T_FOR_SIDE(jj, D) C[jj] = dot_g(prm + o.node_w + (int64_t)jj * F, cur, F, prm[o.node_b + jj]);
+        if (kc == 1) T_FOR_SIDE(jj, D) q0[jj] = dot_g(prm + o.q_w + (int64_t)jj * D, C, D, prm[o.q_b + jj]);
+        if (kc == 2) T_FOR_SIDE(jj, D) q1[jj] = dot_g(prm + o.inproj_w + (int64_t)jj * D, q0, D, prm[o.inproj_b + jj]) * scale;
+        if (kc == 3) T_FOR_SIDE(ii, Hn * D) {
+            const int h = ii / D, kk = ii - h * D;
+            tk[ii] = dot_t(prm + o.inproj_w + (int64_t)D * D, D, kk, q1, h * dh, (h + 1) * dh);
+        }
+        if (kc == 4) T_FOR_SIDE(ii, Hn * D) {
+            const int h = ii / D, kk = ii - h * D;
+            rr[ii] = dot_t(prm + o.k_w, D, kk, tk + h * D, 0, D);
+        }
+    };
+    T_MARK(1);
     T_MARK(2);
 
     // node encoder on every node (:189-190): H^0 from the staged raw features; thread = one output column, its weight row in registers
     const float *be = prm + o.node_b;
-    auto encode_nodes = [&](float *dst) {
-        T_FOR_J(c, D) {
+    auto encode_nodes = [&](float *dst, bool side) {
+        if (side) side_step();
+        T_FORM_J(c, D) {
             float w[XPAD];
 #pragma unroll
             for (int f = 0; f < XPAD; ++f) w[f] = weS[c * XPAD + f];
             const float bc = be[c];
-            T_FOR_V(v, n, D) {
+            T_FORM_V(v, n, D) {
                 float x[XPAD];
                 ld_row<XPAD>(Xs + (int64_t)v * XPAD, x);
                 float acc = bc;
@@ -648,7 +672,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         }
         T_SYNC();
     };
-    encode_nodes(slotH(1));                      // layer 1 updates it in place
+    encode_nodes(slotH(1), true);                // layer 1 updates it in place
     T_MARK(3);
     for (int l = 1; l <= L; ++l) {
         const float *Hin = l == 1 ? slotH(1) : slotH(l - 1);
@@ -656,13 +680,14 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         const float *Wl = prm + o.edge_w[l - 1], *bl = prm + o.edge_b[l - 1];
         const bool last = l == L;
         // P | Q of the layer: PQ[v][j] = sum_k Wl[j % D][(j / D) * D + k] Hin[v][k]   (linear_0.weight is [D][2D] = [Wa | Wb])
-        T_FOR_J(j, 2 * D) {
+        side_step();
+        T_FORM_J(j, 2 * D) {
             float w[D];
             const float *wr = Wl + (int64_t)(j % D) * (2 * D) + (j / D) * D;
 #pragma unroll
             for (int k = 0; k < D; ++k) w[k] = wr[k];
             float mx = fabsf(bl[j % D]) * (EF_LIMIT / EF_BIAS);          // (the bias limit folded into the same test)
-            T_FOR_V(v, n, 2 * D) {
+            T_FORM_V(v, n, 2 * D) {
                 float h[D];
                 ld_row<D>(Hin + (int64_t)v * D, h);
                 float acc = 0.0f;
@@ -681,9 +706,10 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         }
         // node-centric segment sum (:110-148): S_v = sum over incidences 1/2 [tanh(P_v + Q_u + b) + tanh(P_u + Q_v + b)]
         //   exp form: 1/2 (t1 + t2) = 1 - (r1 + r2),  r = 1 / (1 + E)
-        T_FOR_J(c, D) {
+        side_step();
+        T_FORM_J(c, D) {
             const float bc = bl[c], eb = t_exp2(C2 * bc);
-            T_FOR_V(vi, n, D) {
+            T_FORM_V(vi, n, D) {
                 const int v = ord[vi];
                 const int k0 = rp[v], k1 = rp[v + 1];
                 float S = 0.0f;
@@ -737,7 +763,8 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     T_MARK(4);
     float *HL = slotH(L);
     // masked node mean, edge mean (:179-182,199-200; every message is summed at both endpoints): one two-level pass for both
-    T_FOR(i, NG * 2 * D) {
+    side_step();
+    T_FORM(i, NG * 2 * D) {
         const int g = i / (2 * D), c = i - g * 2 * D;
         float acc = 0.0f;
         if (c < D) {
@@ -760,12 +787,17 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         part[i] = acc;
     }
     T_SYNC();
-    T_FOR(c, 2 * D) {
+    side_step();
+    T_FORM(c, 2 * D) {
         const float acc = sum_s(part + c, 2 * D, NG, 0.0f);
         if (c < D) hbarV[c] = acc * (1.0f / (float)m[6]);
         else hbarE[c - D] = acc * (0.5f / (float)e);
     }
     T_SYNC();
+    while (side_k < side_n) {                    // (chains longer than the phases above: the rest as phases of their own)
+        side_step();
+        T_SYNC();
+    }
     T_MARK(5);
     // single-query attention over the node_mask nodes (:150-161).  alpha is kept UNNORMALISED (exp(score - max)) until the
     // backward, its normaliser as scal[8 + h]
@@ -1190,13 +1222,16 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             if (c0 == 0) T_MARK(27);
             // running sums over the candidates: dw2, db1 (= s), M[j][c] = sum dpre[k][j] m[k][c];  and the gradient of the
             // candidate inputs dm[k][c] = sum_j A[j][c] dpre[k][j]  (land: only live candidates carry it on)
-            T_FOR(i, h0 + h0 * D) {
-                if (i < h0) {
-                    dw2[i] = sum_s(hid + i, hs, cn, dw2[i]);
-                    sj[i] = sum_s(dpre + i, hs, cn, sj[i]);
+            T_FOR(i, h0 * D + 2 * h0) {                 // (the two plain sums behind the products: waves of their own, one sum each)
+                if (i < h0 * D) {
+                    const int j = i / D, c = i - j * D;
+                    Mj[i] = dot_s(dpre + j, hs, mq + c, D, cn, Mj[i]);
+                } else if (i < h0 * D + h0) {
+                    const int j = i - h0 * D;
+                    dw2[j] = sum_s(hid + j, hs, cn, dw2[j]);
                 } else {
-                    const int ii = i - h0, j = ii / D, c = ii - j * D;
-                    Mj[ii] = dot_s(dpre + j, hs, mq + c, D, cn, Mj[ii]);
+                    const int j = i - h0 * D - h0;
+                    sj[j] = sum_s(dpre + j, hs, cn, sj[j]);
                 }
             }
             float *dst = land ? dMg : dXR;
@@ -1329,7 +1364,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
             Hprev = slotH(1);                    // H^1 is dead (layer 2 is done): recompute H^0 in its place
             stage_x();
             T_SYNC();
-            encode_nodes(Hprev);
+            encode_nodes(Hprev, false);
         } else {
             Hprev = slotH(l - 1);
         }
