@@ -181,6 +181,38 @@ def test_fused_and_general_paths_agree_and_fall_back_where_they_must(tune):
     assert not eng_1.step_fused_ok(mb_1)
 
 
+@pytest.mark.parametrize('D,L,heads,S,value_head', [(16, 2, 1, (48, 32, 24, 16), (32, 1)), (16, 4, 4, (16,), (64, 32, 16, 1))])
+def test_other_model_shapes_fused_and_general_agree(D, L, heads, S, value_head, tune):
+    """More per-sample chain layers than graph phases to host them (the rest run as phases of their own), and fewer: the fused kernel
+    against the general kernels (the emulator checks the same shapes against the oracle on the CPU, tests/test_tiny_emul.py)."""
+    from drl_urban_planning_amd import synth
+    T = 9
+    cfg = helpers.make_cfg(D=D, L=L, heads=heads, S=S, value_head=value_head, max_nodes=400, max_edges=2300)
+    _, _, ac = helpers.build_product(cfg, seed=61)
+    sd = helpers.perturbed_state_dict(ac, 62)
+    rep = synth.make_replay(T, 'hlg', max_nodes=400, max_edges=2300, seed=63, road_fraction=0.3,
+                            n_range=None if L <= 2 else (60, 150))       # (four layers' H slots: smaller graphs fit the LDS)
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, rep.states, rep.actions)
+    assert eng.step_fused_ok(mb)
+    g = torch.Generator().manual_seed(5)
+    seeds = [torch.randn(T, generator=g).to(DEV) for _ in range(3)]
+
+    def run():
+        value, logp, ent = _forward(eng, pk, mb, flat)
+        grads = torch.zeros(eng.n_floats, device=DEV)
+        eng.backward(pk, mb, flat, seeds[0], seeds[1], seeds[2], grads)
+        torch.cuda.synchronize()
+        return value, logp, ent, grads
+    a = run()
+    tune('tiny_fused', 0)
+    b = run()
+    tune('tiny_fused', 1)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    scale = float(b[3].abs().max())
+    assert float((a[3] - b[3]).abs().max()) <= 2e-5 * scale
+
+
 def test_action_heads_read_the_fused_forwards_logits():
     """policy_net.forward / select_action on a GPU module read the candidate logits back (upamd_ws_tensor 'z_he' / 'z_rn'):
     greedy actions of the fused path == the oracle's arg-max."""

@@ -203,6 +203,36 @@ def test_backward_from_given_seeds_and_reference_dims(emul):
     assert np.isfinite(fwd['z_he']).all() and np.isfinite(fwd['z_rn']).all()
 
 
+@pytest.mark.parametrize('D,L,heads,S,value_head', [(32, 3, 2, (64, 16), (32, 32, 1)),        # wider, deeper, two attention heads
+                                                     (16, 2, 1, (48, 32, 24, 16), (32, 1)),     # 4 numerical layers: more chain layers
+                                                     (16, 4, 4, (16,), (64, 32, 16, 1))])       #   than hosting phases / fewer
+def test_other_model_shapes_match_the_oracle(emul, D, L, heads, S, value_head):
+    """The per-sample chains ride as side work on the graph phases (one layer per phase): models with more chain layers than GCN
+    phases, fewer, several heads, D = 32 -- forward rows and every gradient against the oracle's autograd."""
+    from drl_urban_planning_amd import synth
+    cfg = helpers.make_cfg(D=D, L=L, heads=heads, S=S, value_head=value_head, max_nodes=120, max_edges=700)
+    policy_net, value_net, ac = helpers.build_product(cfg, seed=11)
+    sd = helpers.perturbed_state_dict(ac, seed=12)
+    rep = synth.make_replay(5, 'grid', max_nodes=120, max_edges=700, seed=33, road_fraction=0.4, n_range=(40, 110))
+    B = len(rep.states)
+    g = np.random.default_rng(4)
+    seeds = [g.standard_normal(B).astype(np.float32) for _ in range(3)]
+    fwd = run_emul(emul, cfg, sd, rep.states, rep.actions, 0)
+    out = run_emul(emul, cfg, sd, rep.states, rep.actions, 1, groups=2, seeds=seeds)
+    P = helpers.oracle_params(sd)
+    xs = orc.tensorfy(rep.states)
+    value = orc.value_forward(P, xs, heads)
+    logp, ent = orc.get_log_prob_entropy(P, xs, torch.from_numpy(np.asarray(rep.actions, dtype=np.float32)), heads)
+    np.testing.assert_allclose(fwd['value'], value.detach().numpy().reshape(-1), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(fwd['logp'], logp.detach().numpy().reshape(-1), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(fwd['ent'], ent.detach().numpy().reshape(-1), rtol=1e-4, atol=1e-5)
+    loss = (value.reshape(-1) * torch.from_numpy(seeds[0])).sum() + (logp.reshape(-1) * torch.from_numpy(seeds[1])).sum() + \
+        (ent.reshape(-1) * torch.from_numpy(seeds[2])).sum()
+    loss.backward()
+    ref = {k: (p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)) for k, p in P.items()}
+    check_grads(out, lambda nm: ref[nm], atol_scale=2e-5, rtol_l2=2e-4)
+
+
 @pytest.mark.parametrize('gain,bias', [(40.0, 0.0), (1.0, 3.0), (12.0, 0.0)])
 def test_saturating_edge_mlp_takes_the_linear_walk(emul, gain, bias):
     """Edge-MLP pre-activations outside the exp-form range (|2 log2e x| > 40, or the bias beyond its limit): the layer's flag
