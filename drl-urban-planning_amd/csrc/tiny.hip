@@ -66,19 +66,31 @@ __global__ __launch_bounds__(256) void tiny_reduce_kernel(const float *__restric
         }
         return;
     }
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
+    // 64 parameters x 4 slab groups per block: a thread sums a contiguous quarter of the slabs (eight loads in flight, slab order),
+    // the four partial sums are combined as (q0 + q1) + (q2 + q3).  (One thread per parameter over all 256 slabs: 54 blocks on 256
+    // CUs and 32 dependent batches each -- 13 us for 14 MB.)
+    __shared__ float part[4][64];
+    const int p = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + p;
+    const int Gq = (G + 3) / 4, g0 = sg * Gq, g1 = g0 + Gq < G ? g0 + Gq : G;
     float acc = 0.f;
-    int g = 0;
-    for (; g + 8 <= G; g += 8) {             // eight loads in flight, added in slab order
-        float v[8];
+    if (i < P) {
+        int g = g0;
+        for (; g + 8 <= g1; g += 8) {
+            float v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = slab[(int64_t)(g + q) * stride + i];
+            for (int q = 0; q < 8; ++q) v[q] = slab[(int64_t)(g + q) * stride + i];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc += v[q];
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; g < g1; ++g) acc += slab[(int64_t)g * stride + i];
     }
-    for (; g < G; ++g) acc += slab[(int64_t)g * stride + i];
-    grads[i] = accumulate ? grads[i] + acc : acc;
+    part[sg][p] = acc;
+    __syncthreads();
+    if (sg == 0 && i < P) {
+        const float tot = (part[0][p] + part[1][p]) + (part[2][p] + part[3][p]);
+        grads[i] = accumulate ? grads[i] + tot : tot;
+    }
 }
 
 static void tiny_fill(const upamd_model_desc &d, const ParamLayout &P, Dims *x, Offs *o) {
@@ -162,7 +174,7 @@ int launch_tiny(const upamd_model_desc &d, const ParamLayout &P, const PackedVie
     UPAMD_HIP(hipGetLastError());
     if (io.mode != FWD) {
         const int64_t Pn = P.n_floats;
-        const unsigned blocks = (unsigned)((Pn + 255) / 256) + 1;
+        const unsigned blocks = (unsigned)((Pn + 63) / 64) + 1;
         hipLaunchKernelGGL(tiny_reduce_kernel, dim3(blocks), dim3(256), 0, st, io.slab, A.slab_stride, G, Pn, io.grads,
                            io.accumulate, io.loss_rows, mb.B, io.inv_rows, io.inv_ind, io.cv, io.ce,
                            io.mode == STEP ? io.losses : nullptr);
