@@ -185,8 +185,7 @@ THD int64_t vec_floats(const Dims &d) {
     for (int i = 0; i < d.n_value; ++i) v += d.value_hidden[i];
     const int64_t D = d.D, Hd = (int64_t)d.heads * d.D, h0 = imax(d.h0l, d.h0r);
     //     U        cur   16 D-vectors   10 head vectors   SV, dSV     V, dV      A, M (h0 x D)  const, s, w2..   partials   scalars + slack
-    return u + XPAD + 16 * D + 10 * Hd + 2 * a4(d.W) + 2 * a4(v) + 3 * h0 * D + 8 * h0 + part_floats(d) + 64 + 256 +
-           D * XPAD;      // + the staged node-encoder rows (padded to XPAD)
+    return u + XPAD + 16 * D + 10 * Hd + 2 * a4(d.W) + 2 * a4(v) + 3 * h0 * D + 8 * h0 + part_floats(d) + 64 + 256;
 }
 THD Plan plan_layout(const Dims &d, int n, int inc, int cand, int64_t x_extra) {
     Plan p;
@@ -518,9 +517,11 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
     float *du = vb.get(Hn * D), *ds = vb.get(Hn * D), *dr = vb.get(Hn * D), *dtk = vb.get(Hn * D);
     float *dVa = vb.get(64), *dVb = vb.get(64);  // ping-pong of the small MLPs' backward (hidden <= 64)
     float *Mj = vb.get((int64_t)h0m * D), *sj = vb.get(h0m), *dw2 = vb.get(h0m);
-    // The node encoder's weight rows (F = 23 floats: unaligned scalar loads, 23 per thread) are staged once per graph, padded to
-    // XPAD: encode_nodes went from 7.8 to 3.8 us.  (The same for the GCN layers' aligned 16-float rows bought nothing.)
-    float *weS = vb.get((int64_t)D * XPAD);      // row c = We[c][0 .. F) then zeros
+    // The node encoder's weight rows (F = 23 floats: unaligned scalar loads, 23 per thread) are staged, padded to XPAD, where
+    // encode_nodes reads them: 7.8 -> 3.8 us.  (The same for the GCN layers' aligned 16-float rows bought nothing.)  They live in
+    // the partial-sum scratch, which no phase between the staging and encode_nodes uses (forward: the first phases; backward:
+    // staged again next to the raw features) -- 1.5 KB that the largest DHM graphs (397 nodes) need to stay in one workgroup's LDS.
+    float *weS = part;                           // row c = We[c][0 .. F) then zeros   (D * XPAD <= part_floats)
 
     // =============================================================================== forward
     T_MARK(0);
@@ -1363,6 +1364,7 @@ TDEV void graph_program(const Args &A, int b, float *slab, float *gscr, float *l
         if (l == 1) {
             Hprev = slotH(1);                    // H^1 is dead (layer 2 is done): recompute H^0 in its place
             stage_x();
+            T_FOR(i, D * XPAD) weS[i] = i % XPAD < F ? prm[o.node_w + (int64_t)(i / XPAD) * F + i % XPAD] : 0.0f;
             T_SYNC();
             encode_nodes(Hprev, false);
         } else {

@@ -17,6 +17,10 @@ extern "C" {
 
 int tiny_emul_sizeof_dims() { return (int)sizeof(Dims); }
 int tiny_emul_sizeof_offs() { return (int)sizeof(Offs); }
+// LDS bytes of the plan for a launch whose largest graph has (n nodes, inc incidences, cand candidates), before the chunk buffers
+// take what is left; and the budget of one workgroup
+long long tiny_emul_plan_base_bytes(const Dims *d, int n, int inc, int cand) { return plan_layout(*d, n, inc, cand, 0).total * 4; }
+long long tiny_emul_lds_budget_bytes() { return LDS_FLOATS * 4; }
 
 // grads (out, [n_floats]): sum of the per-workgroup slabs in workgroup order;  losses (out, [4]): STEP mode only
 int tiny_emul_run(const void *packed, const upamd_pack_layout *L, int B, const int32_t *idx, const int32_t *he_off,

@@ -203,6 +203,23 @@ def test_backward_from_given_seeds_and_reference_dims(emul):
     assert np.isfinite(fwd['z_he']).all() and np.isfinite(fwd['z_rn']).all()
 
 
+def test_the_largest_shipped_graphs_fit_one_workgroups_lds(emul):
+    """LDS plan at the shipped dims (hlg.yaml / dhm.yaml: D = 16, L = 2) for the largest live graphs of SURVEY section 8d -- HLG 345
+    nodes / 1920 edges, DHM 397 / 2216 -- with the most candidates a row can have (20 % of the edges): both must fit the budget
+    of one workgroup (otherwise a minibatch that contains one falls back to the general kernels, at twice the step time)."""
+    d = Dims()
+    d.D, d.L, d.heads, d.F, d.Fn, d.n_num, d.n_value, d.h0l, d.h0r, d.S_last, d.W = 16, 2, 1, 23, 52, 2, 3, 32, 32, 16, 3 * 16 + 16 + 3
+    d.num_hidden[0], d.num_hidden[1] = 64, 16
+    d.value_hidden[0], d.value_hidden[1], d.value_hidden[2] = 32, 32, 1
+    emul.tiny_emul_plan_base_bytes.restype = C.c_longlong
+    emul.tiny_emul_lds_budget_bytes.restype = C.c_longlong
+    budget = emul.tiny_emul_lds_budget_bytes()
+    assert budget <= 160 * 1024
+    for n, e in ((345, 1920), (397, 2216)):
+        need = emul.tiny_emul_plan_base_bytes(C.byref(d), n, 2 * e, e // 5)
+        assert need <= budget, (n, e, need, budget)
+
+
 @pytest.mark.parametrize('D,L,heads,S,value_head', [(32, 3, 2, (64, 16), (32, 32, 1)),        # wider, deeper, two attention heads
                                                      (16, 2, 1, (48, 32, 24, 16), (32, 1)),     # 4 numerical layers: more chain layers
                                                      (16, 4, 4, (16,), (64, 32, 16, 1))])       #   than hosting phases / fewer
