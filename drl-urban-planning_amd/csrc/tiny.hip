@@ -1,7 +1,8 @@
 // Fused small-model path (gcn_node_dim <= 32): the per-graph program of tiny_body.h as a HIP kernel -- one 1024-thread
 // workgroup per graph, persistent over the minibatch, everything of a graph in LDS -- plus the fixed-order reduction of the
 // per-workgroup gradient slabs.  An optimizer step at the reference's shipped dims (hlg.yaml:21-33: D = 16, L = 2) is THREE
-// launches: tiny_kernel<STEP> (forward + loss seeds + backward), tiny_reduce (slabs -> gradients, loss scalars), Adam.
+// launches: tiny_kernel<STEP> (forward + loss seeds + backward, ~0.21 ms for 256 rows), tiny_reduce (slabs -> gradients, loss
+// scalars, ~7 us), Adam (5 us).
 // Replaces, for such models, the ~35 dependent launches of the general path (engine.hip), which stays the path of every
 // other model and of graphs too large for one workgroup's LDS.
 #include <cstring>
@@ -13,10 +14,9 @@ namespace upamd {
 
 using namespace upamd_tiny;
 
-// threads per workgroup: tune knob "tiny_threads".  1024 (default): 4 waves per SIMD at 128 VGPRs each; the program keeps ~60 LDS
-// pointers and a register-resident weight row per phase alive, so this variant spills ~70 VGPRs to scratch (272 B frame) -- and is
-// still the faster one, because the phases are latency-bound and 4 waves hide more of it: 0.337 vs 0.410 ms per step at the
-// reference dims, 0.294 vs 0.339 at grid_ref (profiles/r04_bench_small.txt).  512: 2 waves per SIMD, 256 VGPRs, no scratch.
+// threads per workgroup: tune knob "tiny_threads".  1024 (default): 4 waves per SIMD at <= 128 VGPRs each (the program needs ~100
+// since the per-phase thread id, see t_tid() in tiny_body.h); the phases are latency-bound and 4 waves hide more of it than the 2
+// of the 512-thread variant: ~12 % faster at the reference dims (profiles/r04_lab_tiny_sections.log).
 static int g_tiny_threads = 1024;
 void set_tiny_threads(int n) { g_tiny_threads = n == 512 ? 512 : 1024; }
 constexpr int64_t TINY_LDS_LIMIT = 160 * 1024 - 512;
