@@ -5,6 +5,8 @@ Tolerances (fp32): per-row value / log-prob / entropy abs 
 loss scalars rel <= 1e-5 (abs 1e-6); parameter gradients rel-L2 <= 1e-4 and max-abs <= 1e-5 * scale;
 parameters after the update rel-L2 <= 1e-4; GAE bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -68,7 +70,8 @@ def _check_grads(eng, grads_flat, ref_of, atol_scale=1e-5, rtol_l2=1e-4):
 def tune():
     """set native tune knobs for one test; every knob is put back to its default afterwards"""
     from drl_urban_planning_amd import native
-    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1, 'pq_exp': 1, 'nt_min_wgs': 128, 'bwd_nb_global': 1, 'side_heads': 1, 'side_wgrad': 1, 'tiny_fused': 1, 'tiny_threads': 1024}
+    defaults = {'fold_layer1': 1, 'gemm_split': 0, 'he_fused': 1, 'side_stream': 1, 'fe_half': 1, 'pq_exp': 1, 'nt_min_wgs': 128, 'bwd_nb_global': 1, 'side_heads': 1, 'side_wgrad': 1, 'tiny_fused': 1,
+                'tiny_threads': int(os.environ.get('UPAMD_TEST_TINY_THREADS', '1024'))}      # (the variable: run the suite on the 512-thread variant)
     touched = []
 
     def _set(name, value):
