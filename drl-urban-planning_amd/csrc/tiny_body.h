@@ -7,21 +7,25 @@
 // entropy), value.py:15-39 (value head), urban_planning_agent.py:326-333,363-371 + khrylib/rl/agents/agent_pg.py:19-23
 // (loss); the hand-derived backward is the one of tests/csr_model.py, stage by stage.
 //
-// This header holds the PER-GRAPH program and nothing target specific: tiny.hip instantiates it as a HIP kernel; the test
-// infrastructure (tests/emul/tiny_emul.cpp, TINY_HOST) compiles the very same text with g++ and runs it on the CPU against the
-// oracle before any GPU time is spent.  The contract that makes that possible:
+// This header holds the PER-GRAPH program: tiny.hip instantiates it as a HIP kernel; the test infrastructure
+// (tests/emul/tiny_emul.cpp, TINY_HOST) compiles the same text with g++ and runs it on the CPU against the oracle before any GPU
+// time is spent.  Target-specific are only the macros below and four small #ifdef'd helpers that load the same values another way
+// (the meta row, the staging loads of the first phase, ld_row, t_tid).  The contract that makes that possible:
 //   * all parallelism is "for every index of a range, independent iterations" -- T_FOR(i, N), or T_FOR_J(j, NJ) { .. T_FOR_V(v,
 //     NV, NJ) { .. } } where a thread keeps ONE j (its weight row in registers) and strides over v -- closed by T_SYNC() (a
-//     workgroup barrier on the GPU, nothing on the host where the ranges run sequentially); no wave intrinsics, no atomics,
-//     no thread-private state that survives a T_SYNC();
+//     workgroup barrier on the GPU, nothing on the host where the ranges run sequentially); no wave intrinsics, no float
+//     atomics (the one atomic is T_FLAG, an OR of a range flag: order independent), no thread-private state that survives a
+//     T_SYNC();
+//   * a phase may carry SIDE work (T_FOR_SIDE: one layer of a per-sample chain, run by the last wave) next to its own loops
+//     (T_FORM*: the same loops on the other waves); on the host both are plain loops, side work first;
 //   * an iteration writes only elements it owns; every sum is a serial loop in a fixed order inside one iteration (two-level
 //     sums: fixed partial groups, then a fixed combine) => bit-reproducible run to run and for any block size;
 //   * gradients of the parameters go to the workgroup's own slab in global memory (`+=` by the owning iteration); the slabs
 //     are added in a fixed order by the reduction launch.
 //
-// What bounds the kernel is the LATENCY of its ~70 dependent phases, not arithmetic (1 MFLOP per graph): weight rows are
-// hoisted into registers, the raw node features and the candidate lists are staged in LDS once per use, long node sums are
-// split over fixed partial groups, and the small per-sample layers read their weights with many loads in flight.
+// What bounds the kernel is the LATENCY of its ~95 dependent phases, not arithmetic (1 MFLOP per graph).  What that took is in
+// profiles/r04_lab_tiny_sections.log: weight rows in registers, every serial LDS sum with eight loads in flight, LDS rows loaded
+// whole before their FMAs, a per-phase thread id (no cross-phase CSE of address math), staging loads issued together.
 #pragma once
 #include <stdint.h>
 
