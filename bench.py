@@ -195,6 +195,9 @@ def main():
     ap.add_argument('--inclusive-unique', action='store_true',
                     help='time the update_params_inclusive leg on T DISTINCT host states (default: the replay tiles a pool '
                          'of `unique` states, so the host packer reads a small working set)')
+    ap.add_argument('--strong-proxy', default='auto', choices=['auto', 'on', 'off'],
+                    help='N = 1: also time the step on 1/8 of the minibatch (the per-GPU share of an 8-GPU strong-scaling run) and '
+                         'report strong_proxy = ms(full) / (ms(share) + exposed all-reduce); auto = for the default workload only')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak (default): the minibatch per GPU is fixed; strong: the GLOBAL minibatch is fixed and split')
     args = ap.parse_args()
@@ -317,6 +320,40 @@ def main():
     ctx.all_reduce_max(tmax)
     dt = float(tmax.item())
 
+    # ---- strong-scaling proxy on one GPU (north-star: >= 6x at 8 GPUs): the same resident replay stepped at 1/8 of the
+    # minibatch = what each of 8 ranks computes per optimizer step of a strong-scaling run (dp 'global': B / world rows per rank)
+    proxy = None
+    want_proxy = args.strong_proxy == 'on' or (args.strong_proxy == 'auto' and args.workload == 'hlg_d256' and not args.minibatch)
+    if ctx.world == 1 and want_proxy and w['B'] % 8 == 0:
+        engine.profile(False)
+        full_B = up.mini_batch_size
+        up.mini_batch_size = w['B'] // 8
+        run(24, False)
+        torch.cuda.synchronize(dev)
+        n_share = 96
+        t1 = time.perf_counter()
+        run(n_share, True)
+        torch.cuda.synchronize(dev)
+        ms_share = 1e3 * (time.perf_counter() - t1) / n_share
+        bk = engine.grad_buckets()                      # the ranges the last backward finalised, in readiness order
+        up.mini_batch_size = full_B
+        nfl = engine.n_floats
+        tail_bytes = 4 * (bk[-1][1] - bk[-1][0]) if len(bk) > 1 else 4 * (nfl + 4)
+        # the all-reduce itself cannot be measured on one GPU.  Model of an 8-rank ring over xGMI, stated so that it can be
+        # replaced by a measurement: 2 (N - 1) hops of ALPHA us + 2 (N - 1) / N of the bytes over one link direction at LINK GB/s
+        ALPHA_US, LINK_GBPS, NR = 2.5, 50.0, 8
+        model = lambda nbytes: 1e-3 * (2 * (NR - 1) * ALPHA_US + 2.0 * (NR - 1) / NR * nbytes / (LINK_GBPS * 1e3))
+        exposed = model(tail_bytes)
+        ms_full = 1e3 * dt / args.steps
+        proxy = {'ms_full': ms_full, 'rows_full': w['B'], 'ms_share': ms_share, 'rows_share': w['B'] // 8, 'steps_share': n_share,
+                 'grad_buckets': [[int(b), int(e)] for b, e in bk], 'exposed_allreduce_bytes': int(tail_bytes),
+                 'exposed_allreduce_ms': exposed, 'single_collective_ms': model(4 * (nfl + 4)),
+                 'allreduce_source': 'MODEL, not measured (one GPU): 8-rank ring, %.1f us per hop, %.0f GB/s per link direction; '
+                                     'bucketed form = only the range that is final with the last launch of the backward is exposed'
+                                     % (ALPHA_US, LINK_GBPS),
+                 'value': ms_full / (ms_share + exposed), 'value_without_collective': ms_full / ms_share,
+                 'value_single_collective': ms_full / (ms_share + model(4 * (nfl + 4))), 'ideal': 8.0}
+
     kern = {}
     if not args.no_kernel_events:
         for name in ('gemm_nt_128', 'gemm_nt_128_k32', 'gemm_nt_64', 'gemm_nt_32', 'gemm_nt_128_rm', 'gemm_nt_64_rm',
@@ -370,7 +407,12 @@ def main():
                                             '(--inclusive-unique times T distinct states)'},
         'dp_mode': incl.get('dp_mode'),
     }
+    if proxy is not None:
+        out['strong_proxy'] = proxy
     if ctx.world > 1:
+        # how long the backward's stream WAITS for the step's gradient all-reduce (HIP events on that stream): all of a single
+        # collective, the exposed tail of the bucketed form (UPAMD_GRAD_BUCKETS=0 switches the buckets off)
+        out['allreduce_buckets'] = [[int(b), int(e)] for b, e in (up.last_buckets or [])]
         out['allreduce_ms'] = float(cmean.item())
         out['allreduce_share_of_step'] = float(cmean.item()) / out['ms_per_step']
         out['allreduce_bytes'] = grad_bytes

@@ -104,6 +104,11 @@ class PPOUpdater:
         self.last_losses = None               # np [steps, 4] of the last update_params call
         self.last_timing = {}
         self.collective_events = None         # a list: record a HIP-event pair around every step's gradient all-reduce (bench.py)
+        # data parallelism: all-reduce the gradient buffer bucket by bucket on a communication stream while the backward of the
+        # layers below is still running (engine.grad_buckets); False = ONE collective behind the whole backward.  Same bits.
+        self.bucketed_allreduce = os.environ.get('UPAMD_GRAD_BUCKETS', '1') != '0'
+        self.last_buckets = None              # [(begin, end)] of the last bucketed step (tests, bench.py)
+        self._comm = None
 
     # ------------------------------------------------------------------ buffers
     def _device(self):
@@ -242,16 +247,32 @@ class PPOUpdater:
         engine.gae(rewards, masks, values, self.gamma, self.tau, adv, ret)
         return IterationState(packed, T, exps_np, exps, values, logp, adv, ret)
 
+    def draw_permutations(self, it, n_epochs):
+        """'global' data parallelism: the iteration's ``n_epochs`` shuffles drawn up front -- one ``np.random.shuffle`` per
+        epoch on the numpy GLOBAL RNG, exactly the draws (and the order of draws) of the reference's epoch loop (:306-312),
+        nothing else touches that RNG in between -- and rank 0's draws handed to every rank in ONE broadcast per iteration
+        (a broadcast per epoch drained the GPU pipeline once per epoch).  Every rank draws, so identically seeded ranks stay
+        aligned; rank 0's stream is the one all of them use, so no rank-local np.random use (env code, another thread) can
+        make the ranks slice different global minibatches."""
+        perms = np.empty((n_epochs, it.T), dtype=np.int64)
+        for e in range(n_epochs):
+            perm = np.arange(it.T)
+            np.random.shuffle(perm)
+            perms[e] = perm
+        it.perms = self.dist.broadcast_array(perms, self.engine.device) if n_epochs else perms
+        it.perm_next = 0
+
     def make_epoch(self, it):
         """Next epoch's schedule: numpy-global-RNG shuffle composed onto the running order (:306-319)."""
         T, dev, d = it.T, self.engine.device, self.dist
-        perm = np.arange(T)
-        np.random.shuffle(perm)
-        if self._mode == 'global':
-            # every rank draws (so identically seeded ranks stay aligned), rank 0's draw -- the reference's numpy stream
-            # (:306-312) -- is the one all of them use: no rank-local np.random use (env code, another thread) between two
-            # epochs can make the ranks slice different global minibatches
-            perm = d.broadcast_array(perm, dev)
+        if getattr(it, 'perms', None) is not None and it.perm_next < len(it.perms):
+            perm = it.perms[it.perm_next]
+            it.perm_next += 1
+        else:
+            perm = np.arange(T)
+            np.random.shuffle(perm)
+            if self._mode == 'global':
+                perm = d.broadcast_array(perm, dev)
         it.order = it.order[perm]
         meta = it.packed.meta
         stage_np = meta[:, packer.M_STAGE]
@@ -303,7 +324,7 @@ class PPOUpdater:
             engine.step_fused(it.packed, mb, self.flat, idx, it.adv, it.ret, it.old_logp, it.exps, self.clip_epsilon,
                               self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind, value_b, logp_b, ent_b,
                               self.grads[:nflt], self.grads[nflt:])
-            return self._finish_step(ep, k, loss_out)
+            return self._finish_step(ep, k, loss_out, buckets=False)
         engine.forward(it.packed, mb, self.flat, value_b, logp_b, ent_b, keep=True)
         # gathers of the minibatch rows, the loss and zero_grad in one launch
         engine.ppo_loss_rows(B, value_b, logp_b, ent_b, idx, it.adv, it.ret, it.old_logp, it.exps,
@@ -312,14 +333,40 @@ class PPOUpdater:
         engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
         self._finish_step(ep, k, loss_out)
 
-    def _finish_step(self, ep, k, loss_out):
+    def _reduce_gradients(self, buckets):
+        """The step's gradient all-reduce.  Bucketed: the engine's backward has recorded one event per
+        range of the flat buffer, in the order the ranges became final; each range is reduced on the communication stream as
+        soon as ITS event has fired, i.e. underneath the backward of the layers below it, and only the last range -- numerical
+        + node encoder and the first GCN layer, final with the backward's last launch -- is exposed.  The ranges are disjoint
+        and a sum over ranks is element-wise: bucketed and single-collective steps give the same bits."""
+        d, nflt = self.dist, self.engine.n_floats
+        ranges = self.engine.grad_buckets() if (buckets and self.bucketed_allreduce and d.active and d.world > 1) else []
+        if len(ranges) <= 1:
+            self.last_buckets = None
+            d.all_reduce_sum(self.grads)                  # ONE collective per optimizer step (no-op for one rank)
+            return
+        dev = self.engine.device
+        if self._comm is None or self._comm.device != dev:
+            self._comm = torch.cuda.Stream(device=dev, priority=-1)
+        ranges = [(b, e + 4 if e == nflt else e) for b, e in ranges]      # the 4 loss scalars ride behind the last parameter
+        works = []
+        for j, (b, e) in enumerate(ranges):
+            self.engine.grad_bucket_wait(j, self._comm)
+            with torch.cuda.stream(self._comm):
+                works.append(d.all_reduce_sum_async(self.grads[b:e]))
+        for w in works:
+            w.wait()                                      # the caller's stream continues behind every bucket
+        self.last_buckets = ranges
+
+    def _finish_step(self, ep, k, loss_out, buckets=True):
         """all-reduce, first-step clip, Adam -- everything behind the backward of a step"""
         engine, nflt = self.engine, self.engine.n_floats
         timed = self.collective_events is not None and self.dist.world > 1
-        if timed:       # on the stream the backward was launched on: the pair brackets the collective alone (plus rank skew)
+        if timed:       # on the stream the backward was launched on, right behind its last launch: the pair measures how long that
+            # stream WAITS for the collective(s) -- all of a single collective, the exposed tail of the bucketed form (plus rank skew)
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record()
-        self.dist.all_reduce_sum(self.grads)              # ONE collective per optimizer step (no-op for one rank)
+        self._reduce_gradients(buckets)
         if timed:
             pair[1].record()
             self.collective_events.append(pair)
@@ -361,6 +408,9 @@ class PPOUpdater:
         loss_log = torch.zeros(max(steps_total, 1), 4, device=dev)
         step = 0
         epoch_ranges = []
+        if self._mode == 'global':
+            per_epoch = int(math.floor(it.T / self.mini_batch_size))
+            self.draw_permutations(it, -(-steps_total // per_epoch) if per_epoch else 0)
         for _ in range(self.num_optim_epoch):
             if step >= steps_total:
                 break

@@ -148,6 +148,7 @@ extern "C" int upamd_tune(const char *name, int32_t value) {
     if (!strcmp(name, "gemm_split")) { set_gemm_nt_split(value); return UPAMD_OK; }
     if (!strcmp(name, "he_fused")) { set_he_feat_fused(value); return UPAMD_OK; }
     if (!strcmp(name, "side_wgrad")) { set_side_wgrad(value); return UPAMD_OK; }
+    if (!strcmp(name, "grad_buckets")) { set_grad_buckets(value); return UPAMD_OK; }
     if (!strcmp(name, "side_priority")) { set_side_priority(value); return UPAMD_OK; }
     if (!strcmp(name, "side_heads")) { set_side_heads(value); return UPAMD_OK; }
     if (!strcmp(name, "side_stream")) { set_side_stream(value); return UPAMD_OK; }

@@ -27,6 +27,12 @@ struct SideCtx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_join2 = nullptr;
     hipEvent_t pool[8] = {};             // round-robin events of the finer-grained hand-overs (stream_after / event_on)
     int pool_next = 0;
+    // gradient buckets of the LAST backward enqueued on this caller stream (upamd_grad_buckets): float ranges of the flat
+    // gradient buffer in the order they became final, each with the event recorded behind its last writer
+    static constexpr int MAX_BUCKETS = 20;
+    int n_buckets = 0;
+    int64_t b_begin[MAX_BUCKETS] = {}, b_end[MAX_BUCKETS] = {};
+    hipEvent_t b_ev[MAX_BUCKETS] = {};
 };
 
 struct upamd_engine {
@@ -324,6 +330,7 @@ static int side_ready(upamd_engine *eng, hipStream_t st, SideCtx **out) {
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_a, hipEventDisableTiming));
         UPAMD_HIP(hipEventCreateWithFlags(&c.ev_b, hipEventDisableTiming));
         for (hipEvent_t &e : c.pool) UPAMD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : c.b_ev) UPAMD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     *out = &c;
     return 0;
@@ -364,6 +371,21 @@ struct SideGuard {
         if (armed && c && c->side2) (void)hipStreamSynchronize(c->side2);
     }
 };
+
+// tune knob "grad_buckets" (default on): the backward finalises the gradient buffer range by range -- heads + attention + value
+// head right behind the per-sample products, every GCN layer's weight behind its weight-gradient GEMM, the rest at the end -- and
+// records an event per range, so that a data-parallel caller can all-reduce a range while the layers below are still in their
+// backward (upamd_grad_buckets / upamd_grad_bucket_wait).  The arithmetic and the order of every sum are those of the
+// single-range form (0): the same bits, only the launch that performs a reduction moves.
+static int g_grad_buckets = 1;
+static int bucket_done(SideCtx *c, int64_t begin, int64_t end, hipStream_t on) {
+    if (c->n_buckets >= SideCtx::MAX_BUCKETS) return fail(UPAMD_E_LIMIT, "too many gradient buckets");
+    const int k = c->n_buckets++;
+    c->b_begin[k] = begin;
+    c->b_end[k] = end;
+    UPAMD_HIP(hipEventRecord(c->b_ev[k], on));
+    return 0;
+}
 
 // UPAMD_DEBUG_SYNC=1: synchronise after every launch and name the one that faulted (debugging aid; off by default)
 static const bool g_debug_sync = getenv("UPAMD_DEBUG_SYNC") && atoi(getenv("UPAMD_DEBUG_SYNC")) != 0;
@@ -525,6 +547,7 @@ void upamd::set_side_stream(int on) { g_side_stream = on ? 1 : 0; }
 void upamd::set_side_priority(int v) { g_side_priority = (v >= 0 && v <= 2) ? v : 1; }
 void upamd::set_side_heads(int on) { g_side_heads = on ? 1 : 0; }
 void upamd::set_side_wgrad(int on) { g_side_wgrad = (on >= 0 && on <= 3) ? on : 1; }
+void upamd::set_grad_buckets(int on) { g_grad_buckets = on ? 1 : 0; }
 
 extern "C" int upamd_engine_create(const upamd_model_desc *desc, upamd_engine **out) {
     if (!out) return fail(UPAMD_E_INVALID, "upamd_engine_create: out is null");
@@ -905,14 +928,13 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
 // =============================================================================================
 // backward
 // =============================================================================================
-extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout,
-                              const upamd_minibatch *mbp, const float *prm, void *ws_dev, int64_t ws_bytes,
-                              const float *dvalue_dev, const float *dlogp_dev, const float *dent_dev,
-                              float *grads, void *stream) {
+static int backward_impl(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout,
+                         const upamd_minibatch *mbp, const float *prm, void *ws_dev, int64_t ws_bytes,
+                         const float *dvalue_dev, const float *dlogp_dev, const float *dent_dev,
+                         float *grads, hipStream_t st, SideCtx *bk) {
     Plan pl;
     CK(check_args(eng, packed_dev, layout, mbp, prm, ws_dev, ws_bytes, &pl));
     if (!dvalue_dev || !dlogp_dev || !dent_dev || !grads) return fail(UPAMD_E_INVALID, "null seed/grad pointer");
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const upamd_model_desc &d = eng->d;
     const ParamLayout &P = eng->P;
     const Dims x = dims_of(d);
@@ -968,6 +990,13 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     // forked step: the big slab sets (the GCN layers' weight gradients, the land-use head's) are reduced on the side stream as
     // soon as their producer has run, underneath the following GEMM / message-passing launches, instead of in the final flush
     Reducer redS;
+    // gradient buckets (tune knob grad_buckets, forked step only): `redE` takes every reduction whose destination lies in the
+    // attention / value-head / pointer-head part of the flat buffer; it is flushed on the side stream right behind the grouped
+    // per-sample products, followed there by the prepared-parameter mappings of that range -- bucket 0 is final before the last
+    // GCN layer's backward has finished.  Not forked: `rE` IS red1 and everything happens where it always did.
+    Reducer redE;
+    const bool early = g_grad_buckets != 0 && g_side_stream != 0 && !defer_node_tn(x.D) && !x.mlp;
+    Reducer &rE = early ? redE : red1;
 
     if (x.mlp) {
         // ===== rl-mlp encoder: value head / numerical encoder -> pooled means + pointer heads -> node encoder
@@ -1124,8 +1153,8 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                                land ? W(S_CSP0) : nullptr, land ? W(S_DCONST) : nullptr, road ? W(S_CSP2) : nullptr, road ? W(S_CSP3) : nullptr, hs));
     if (land) {
         // dw2 = sum_rows (sum_k dz hid), db1 = sum_rows dconst: the row sums come out of pointer_bwd2
-        CK(red1.add(W(S_CSP0), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
-        CK(red1.add(W(S_DCONST), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
+        CK(rE.add(W(S_CSP0), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_w[1]), x.h0l));
+        CK(rE.add(W(S_DCONST), B, x.h0l, 1, x.h0l, 0, x.h0l, GR(P.land_b0), x.h0l));
         if (heads_side) {
             // feature backward first (the last GCN layer's backward on the caller's stream waits for its dM), then the weight gradient
             CK(launch_he_feat_bwd_fused(pk, mb, D, W(S_FE), W(S_C), W(S_DPREL), W(S_W1FT), W(S_DMHE), W(S_DC_HEAD), hs));
@@ -1141,11 +1170,11 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                 CK(redS.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
                 CK(redS.flush());
             } else {
-                CK(red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
+                CK(rE.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1));
             }
         } else {
             CK(node_tn_red(W(S_FE), 2 * D, W(S_DPREL), x.h0l, mb.Nhe, W(S_SLAB_FE), [&](int Sn) {
-                return red1.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
+                return rE.add(W(S_SLAB_FE), Sn, 2LL * D * x.h0l, 2 * D, x.h0l, 1, x.h0l, W(S_DW1F), 2 * D, nullptr, 1);
             }));
         }
         // dFE = dpre W1f, then the feature backward (dMhe for the last GCN layer, dC from the m*c term); with the shipped
@@ -1160,10 +1189,10 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         }
     }
     if (road) {
-        CK(red1.add(W(S_CSP2), B, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
-        CK(red1.add(W(S_CSP3), B, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
+        CK(rE.add(W(S_CSP2), B, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_w[1]), x.h0r));
+        CK(rE.add(W(S_CSP3), B, x.h0r, 1, x.h0r, 0, x.h0r, GR(P.road_b0), x.h0r));
         CK(node_tn_red(W(S_XR), D, W(S_DPRER), x.h0r, mb.Nrn, W(S_SLAB_XR), [&](int Sn) {
-            return red1.add(W(S_SLAB_XR), Sn, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D);
+            return rE.add(W(S_SLAB_XR), Sn, (int64_t)D * x.h0r, D, x.h0r, 1, x.h0r, GR(P.road_w[0]), D);
         }));
         CK(launch_gemm_nt(W(S_DPRER), mb.Nrn, x.h0r, W(S_R1T), D, nullptr, nullptr, W(S_DXR), 0, st, prof));
         CK(launch_road_scatter_add(pk, mb, D, W(S_DXR), G, st));
@@ -1192,28 +1221,28 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
             const int N = d.value_hidden[i];
             const int K = i == 0 ? x.W : d.value_hidden[i - 1];
             const float *X = i == 0 ? W(S_SV) : W(S_V + i);
-            CK(job(red1, W(S_DAV + i), N, N, X, i == 0 ? x.Wp : K, K, GR(P.value_w[i]), K, 0));
-            CK(job(red1, W(S_DAV + i), N, N, nullptr, 0, 1, GR(P.value_b[i]), 1, 0));
+            CK(job(rE, W(S_DAV + i), N, N, X, i == 0 ? x.Wp : K, K, GR(P.value_w[i]), K, 0));
+            CK(job(rE, W(S_DAV + i), N, N, nullptr, 0, 1, GR(P.value_b[i]), 1, 0));
         }
         for (int i = 0; i < d.n_num; ++i) {         // numerical encoder
             const int N = d.num_hidden[i];
             const int K = i == 0 ? x.Fn : d.num_hidden[i - 1];
-            CK(job(red1, W(S_DAN + i), N, N, W(S_U + i), K, K, GR(P.num_w[i]), K, 0));
-            CK(job(red1, W(S_DAN + i), N, N, nullptr, 0, 1, GR(P.num_b[i]), 1, 0));
+            CK(job(rE, W(S_DAN + i), N, N, W(S_U + i), K, K, GR(P.num_w[i]), K, 0));
+            CK(job(rE, W(S_DAN + i), N, N, nullptr, 0, 1, GR(P.num_b[i]), 1, 0));
         }
-        CK(job(red1, W(S_DATT), D, D, W(S_O), D, D, GR(P.outproj_w), D, 0));
-        CK(job(red1, W(S_DATT), D, D, nullptr, 0, 1, GR(P.outproj_b), 1, 0));
+        CK(job(rE, W(S_DATT), D, D, W(S_O), D, D, GR(P.outproj_w), D, 0));
+        CK(job(rE, W(S_DATT), D, D, nullptr, 0, 1, GR(P.outproj_b), 1, 0));
         for (int h = 0; h < x.heads; ++h) {
             // dWvv[h-slice,:] = do[:,h-slice]^T s[:,h,:] ;  dWkk[h-slice,:] = q1[:,h-slice]^T dr[:,h,:]
-            CK(job(red1, W(S_DO) + h * x.dh, D, x.dh, W(S_S) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWVV) + (int64_t)h * x.dh * D, D, 1));
-            CK(job(red1, W(S_Q1) + h * x.dh, D, x.dh, W(S_DR) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWKK) + (int64_t)h * x.dh * D, D, 1));
+            CK(job(rE, W(S_DO) + h * x.dh, D, x.dh, W(S_S) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWVV) + (int64_t)h * x.dh * D, D, 1));
+            CK(job(rE, W(S_Q1) + h * x.dh, D, x.dh, W(S_DR) + (int64_t)h * D, (int64_t)x.heads * D, D, W(S_DWKK) + (int64_t)h * x.dh * D, D, 1));
         }
-        CK(job(red1, W(S_DO), D, D, nullptr, 0, 1, W(S_DBVV), 1, 1));
-        CK(job(red1, W(S_DQ1), D, D, W(S_Q0), D, D, gWin, D, 0));                    // in_proj, q rows
-        CK(job(red1, W(S_DQ1), D, D, nullptr, 0, 1, gbin, 1, 0));
-        CK(job(red1, W(S_DQ0), D, D, W(S_C), D, D, GR(P.q_w), D, 0));
-        CK(job(red1, W(S_DQ0), D, D, nullptr, 0, 1, GR(P.q_b), 1, 0));
-        if (land) CK(job(red1, W(S_DCONST), x.h0l, x.h0l, W(S_C), D, D, W(S_DWBD), D, 1));
+        CK(job(rE, W(S_DO), D, D, nullptr, 0, 1, W(S_DBVV), 1, 1));
+        CK(job(rE, W(S_DQ1), D, D, W(S_Q0), D, D, gWin, D, 0));                    // in_proj, q rows
+        CK(job(rE, W(S_DQ1), D, D, nullptr, 0, 1, gbin, 1, 0));
+        CK(job(rE, W(S_DQ0), D, D, W(S_C), D, D, GR(P.q_w), D, 0));
+        CK(job(rE, W(S_DQ0), D, D, nullptr, 0, 1, GR(P.q_b), 1, 0));
+        if (land) CK(job(rE, W(S_DCONST), x.h0l, x.h0l, W(S_C), D, D, W(S_DWBD), D, 1));
         // the current node's pass through the node encoder: after the collapsed-product gradients (same destination)
         CK(job(red2, W(S_DC), D, D, W(S_CURG), UPAMD_NODE_PAD, x.F, GR(P.node_w), x.F, 0));
         CK(job(red2, W(S_DC), D, D, nullptr, 0, 1, GR(P.node_b), 1, 0));
@@ -1237,6 +1266,42 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
         CK(launch_chain_bwd_pre(a, forked ? sc->side : st));
     }
     if (forked) CK(grouped_launch(sc->side));
+    // the attention mappings Wkk = Wik Wk, Wvv = Wiv Wv, bvv = Wiv bv + biv back onto the stored parameters
+    auto attention_smm = [&](SmmJobs *sj, int *blocks) -> int {
+        // Wkk = Wik Wk:  dWik += dWkk Wk^T,  dWk += Wik^T dWkk
+        CK(smm_add(sj, blocks, D, D, D, W(S_DWKK), D, 1, PR(P.k_w), 1, D, nullptr, gWin + (int64_t)D * D, D, 1, 1.f));
+        CK(smm_add(sj, blocks, D, D, D, Wik, 1, D, W(S_DWKK), D, 1, nullptr, GR(P.k_w), D, 1, 1.f));
+        // Wvv = Wiv Wv, bvv = Wiv bv + biv:  dWiv += dWvv Wv^T + dbvv (x) bv,  dWv += Wiv^T dWvv,  dbv += Wiv^T dbvv
+        CK(smm_add(sj, blocks, D, D, D, W(S_DWVV), D, 1, PR(P.v_w), 1, D, nullptr, gWin + 2LL * D * D, D, 1, 1.f, nullptr, 0, W(S_DBVV), PR(P.v_b)));
+        CK(smm_add(sj, blocks, D, D, D, Wiv, 1, D, W(S_DWVV), D, 1, nullptr, GR(P.v_w), D, 1, 1.f));
+        CK(smm_add(sj, blocks, 1, D, D, W(S_DBVV), 0, 1, Wiv, D, 1, nullptr, GR(P.v_b), D, 1, 1.f));
+        return 0;
+    };
+    auto land_scatter = [&](hipStream_t ps) -> int {
+        PermJobs pj;
+        int blocks = 0;
+        CK(perm_add(&pj, &blocks, PERM_LAND_SCATTER, W(S_DW1F), W(S_DWBD), GR(P.land_w[0]), nullptr, nullptr, nullptr, x.h0l, D, 0));
+        return launch_permute(pj, blocks, ps);
+    };
+    const bool early_done = early && forked;
+    if (early_done) {
+        // ---- bucket 0 on the side stream: every producer of the range has been enqueued on it (or on the caller's stream
+        // before the fork / before ev_a); same jobs, same per-destination order as the final flush of the single-range form
+        redE.st = sc->side;
+        for (const Pending &q : pending)
+            if (q.rd == &redE) CK(redE.add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
+        CK(redE.flush());
+        if (land) CK(land_scatter(sc->side));
+        {
+            SmmJobs sj;
+            int blocks = 0;
+            CK(attention_smm(&sj, &blocks));
+            CK(launch_gsmm(sj, blocks, sc->side));
+        }
+        CK(redE.add(W(S_DBVV), 1, 0, 1, D, 0, D, gbin + 2 * D, D));
+        CK(redE.flush());
+        CK(bucket_done(bk, P.tensors[P.inproj_w].offset, P.n_floats, sc->side));
+    }
     // ---- 5. GCN layers, last to first
     const bool fold = fold_layer1(mb, x.L, x.K);      // the forward's decision (same minibatch): PQ_1 was never written
     const FoldArgs fa{W(S_XP), W(S_W1C), W(S_B1C), W(S_WE_PAD), PR(P.node_b)};
@@ -1276,7 +1341,9 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                                expf ? reinterpret_cast<const uint8_t *>(W(S_PQF + l)) : nullptr));
         }
         // column sums of dP | dQ over the minibatch (P/Q panel order); the layer's bias gradient is the P half
-        CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
+        // (layer bucket: reduced next to the layer's weight-gradient slabs instead of in the final flush)
+        const bool layer_early = early_done && l > 1 && x.K == 1 && g_side_heads && tn_shape_mfma_ok(2 * D, D);
+        if (!layer_early) CK(red1.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
         if (l > 1) {
             // side_wgrad = 1: the weight gradient starts next to this layer's dgrad; 2: behind it, i.e. next to the NEXT layer's
             // message-passing backward (the dgrad is launched first and the side stream waits for it)
@@ -1297,7 +1364,11 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
                     if (!wgrad_side) CK(stream_after(sc->side, st, tn_done));
                     redS.st = wgrad_side ? sc->side2 : sc->side;
                     CK(redS.add(W(S_SLAB_W + l), Sn, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D));
-                    return redS.flush();
+                    if (layer_early) CK(redS.add(W(S_DBIAS + l), B, 2LL * D, 1, 2 * D, 3, 2 * D, GR(P.edge_b[l - 1]), 0, W(S_CS + l)));
+                    CK(redS.flush());
+                    if (layer_early)
+                        CK(bucket_done(bk, P.tensors[P.edge_w[l - 1]].offset, P.tensors[P.edge_b[l - 1] + 1].offset, redS.st));
+                    return 0;
                 }
                 return red1.add(W(S_SLAB_W + l), Sn, 2LL * D * D, 2 * D, D, 2, D, GR(P.edge_w[l - 1]), 2 * D);
             }));
@@ -1345,27 +1416,18 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     } else {
         CK(grouped_launch(st));
     }
-    for (const Pending &q : pending) CK(q.rd->add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
+    for (const Pending &q : pending)
+        if (!(early_done && q.rd == &redE)) CK(q.rd->add(q.slab, q.S, (int64_t)q.N * q.K, q.N, q.K, 0, q.K, q.dst, q.ldd, nullptr, q.overwrite));
     for (auto &f : after_gtn) CK(f());
     // ---- 8. reduction #1: every split-K slab / partial sum of the step, fixed order
+    if (early && !early_done) CK(redE.flush());      // (unreachable today: early implies forked; kept so that no job can be lost)
     CK(red1.flush());
     // ---- 9. gradients of the prepared parameters mapped back onto the stored ones
-    if (land) {
-        PermJobs pj;
-        int blocks = 0;
-        CK(perm_add(&pj, &blocks, PERM_LAND_SCATTER, W(S_DW1F), W(S_DWBD), GR(P.land_w[0]), nullptr, nullptr, nullptr, x.h0l, D, 0));
-        CK(launch_permute(pj, blocks, st));
-    }
+    if (land && !early_done) CK(land_scatter(st));
     {
         SmmJobs sj;
         int blocks = 0;
-        // Wkk = Wik Wk:  dWik += dWkk Wk^T,  dWk += Wik^T dWkk
-        CK(smm_add(&sj, &blocks, D, D, D, W(S_DWKK), D, 1, PR(P.k_w), 1, D, nullptr, gWin + (int64_t)D * D, D, 1, 1.f));
-        CK(smm_add(&sj, &blocks, D, D, D, Wik, 1, D, W(S_DWKK), D, 1, nullptr, GR(P.k_w), D, 1, 1.f));
-        // Wvv = Wiv Wv, bvv = Wiv bv + biv:  dWiv += dWvv Wv^T + dbvv (x) bv,  dWv += Wiv^T dWvv,  dbv += Wiv^T dbvv
-        CK(smm_add(&sj, &blocks, D, D, D, W(S_DWVV), D, 1, PR(P.v_w), 1, D, nullptr, gWin + 2LL * D * D, D, 1, 1.f, nullptr, 0, W(S_DBVV), PR(P.v_b)));
-        CK(smm_add(&sj, &blocks, D, D, D, Wiv, 1, D, W(S_DWVV), D, 1, nullptr, GR(P.v_w), D, 1, 1.f));
-        CK(smm_add(&sj, &blocks, 1, D, D, W(S_DBVV), 0, 1, Wiv, D, 1, nullptr, GR(P.v_b), D, 1, 1.f));
+        if (!early_done) CK(attention_smm(&sj, &blocks));
         // first GCN layer: dWcat_1 = Tn We^T + cs1 (x) be;  dWe += Wcat_1^T Tn;  dbe += Wcat_1^T cs1   (Tn = dPQ_1^T Xp)
         CK(smm_add(&sj, &blocks, 2 * D, D, 32, W(S_TN), 32, 1, W(S_WE_PAD), 1, 32, nullptr, W(S_DWC1), D, 0, 1.f, nullptr, 0, W(S_CS + 1), PR(P.node_b)));
         CK(smm_add(&sj, &blocks, D, x.F, 2 * D, W(S_WCAT + 0), 1, D, W(S_TN), 32, 1, nullptr, GR(P.node_w), x.F, 1, 1.f));
@@ -1374,8 +1436,55 @@ extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const u
     }
     // ---- 10. reduction #2: dWcat_1 un-permuted into the layer's weight, dbiv += dbvv, the current node's encoder pass
     CK(red2.add(W(S_DWC1), 1, 0, 2 * D, D, 2, D, GR(P.edge_w[0]), 2 * D));
-    CK(red2.add(W(S_DBVV), 1, 0, 1, D, 0, D, gbin + 2 * D, D));
+    if (!early_done) CK(red2.add(W(S_DBVV), 1, 0, 1, D, 0, D, gbin + 2 * D, D));
     CK(red2.flush());
+    if (bk->n_buckets > 0) {
+        // the rest of the buffer: everything in front of the earliest bucket (numerical + node encoder, first GCN layer, and the
+        // layers whose weight gradient was not reduced on a side stream)
+        int64_t lo = P.n_floats;
+        for (int k = 0; k < bk->n_buckets; ++k) lo = std::min(lo, bk->b_begin[k]);
+        if (lo > 0) CK(bucket_done(bk, 0, lo, st));
+    }
+    return UPAMD_OK;
+}
+
+extern "C" int upamd_backward(upamd_engine *eng, const void *packed_dev, const upamd_pack_layout *layout,
+                              const upamd_minibatch *mbp, const float *prm, void *ws_dev, int64_t ws_bytes,
+                              const float *dvalue_dev, const float *dlogp_dev, const float *dent_dev,
+                              float *grads, void *stream) {
+    if (!eng) return fail(UPAMD_E_INVALID, "engine is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SideCtx *bk = nullptr;
+    CK(side_ready(eng, st, &bk));
+    bk->n_buckets = 0;
+    int rc = backward_impl(eng, packed_dev, layout, mbp, prm, ws_dev, ws_bytes, dvalue_dev, dlogp_dev, dent_dev, grads, st, bk);
+    if (rc) {
+        bk->n_buckets = 0;
+        return rc;
+    }
+    if (bk->n_buckets == 0) CK(bucket_done(bk, 0, eng->P.n_floats, st));      // paths that finalise everything at the end
+    return UPAMD_OK;
+}
+
+extern "C" int upamd_grad_buckets(upamd_engine *eng, void *stream, int32_t cap, int32_t *n_out, int64_t *begin, int64_t *end) {
+    if (!eng || !n_out) return fail(UPAMD_E_INVALID, "upamd_grad_buckets: null argument");
+    auto it = eng->sides.find(static_cast<hipStream_t>(stream));
+    const int n = it == eng->sides.end() ? 0 : it->second.n_buckets;
+    *n_out = n;
+    if (n > cap) return fail(UPAMD_E_LIMIT, "upamd_grad_buckets: %d buckets, room for %d", n, cap);
+    for (int k = 0; k < n; ++k) {
+        if (begin) begin[k] = it->second.b_begin[k];
+        if (end) end[k] = it->second.b_end[k];
+    }
+    return UPAMD_OK;
+}
+
+extern "C" int upamd_grad_bucket_wait(upamd_engine *eng, void *stream, int32_t k, void *waiter) {
+    if (!eng) return fail(UPAMD_E_INVALID, "engine is null");
+    auto it = eng->sides.find(static_cast<hipStream_t>(stream));
+    if (it == eng->sides.end() || k < 0 || k >= it->second.n_buckets)
+        return fail(UPAMD_E_INVALID, "upamd_grad_bucket_wait: no bucket %d recorded on that stream", k);
+    UPAMD_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(waiter), it->second.b_ev[k], 0));
     return UPAMD_OK;
 }
 

@@ -142,6 +142,7 @@ struct FoldArgs {
 bool edge_fold_ok(const MbView &mb);        // every graph of the minibatch fits the staged (LDS-resident) size classes
 bool edge_fold_pays(const MbView &mb);      // ... and fits half the LDS (two workgroups per CU), where the fold beats the K = 32 GEMMs
 void set_fwd_h_hbm(int on);                // tune knob: large-graph size class of the forward with H left in HBM (default on)
+void set_grad_buckets(int on);             // tune knob "grad_buckets" (default 1): the backward finalises the gradient buffer range by range (engine.hip)
 void set_side_wgrad(int on);               // tune knob "side_wgrad" (default 1 = adaptive: on for minibatches of <= 98304 nodes; 0 never, 2 behind the dgrad, 3 always): GCN weight-gradient GEMMs on a side stream
 void set_side_priority(int v);             // tune knob "side_priority": priority level of the side streams created from now on (1 high, 0 normal, 2 low)
 void set_side_heads(int on);               // tune knob "side_heads" (default on): the land-use pointer-head chain on the side stream

@@ -30,6 +30,22 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+class _StreamDone:
+    """completion of work enqueued on ``stream``: ``wait()`` orders the current stream behind it"""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+        return True
+
+
 class DistContext:
     """rank / world + the collectives the update needs.  world == 1 -> every call is a no-op."""
 
@@ -93,6 +109,22 @@ class DistContext:
 
     def all_reduce_sum(self, tensor):
         return self._all_reduce(tensor, dist.ReduceOp.SUM)
+
+    def all_reduce_sum_async(self, tensor):
+        """Sum-all-reduce of ``tensor`` ordered behind the CURRENT stream (the caller has made that stream wait for whatever
+        produces the tensor); returns an object whose ``wait()`` orders the stream that is current THEN behind the result.
+        RCCL: the collective runs on the process group's own stream, nothing blocks the host.  gloo on a device tensor (test
+        ranks sharing a GPU): staged through the host, so the HOST blocks until the producer is done -- the device work
+        already enqueued on other streams carries on underneath, which is all the overlap a host-memory backend can give."""
+        if not self.active:
+            return _Done()
+        if tensor.is_cuda and self.backend == 'gloo':
+            stream = torch.cuda.current_stream(tensor.device)
+            host = tensor.detach().cpu()                  # (synchronises the current stream only)
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            tensor.copy_(host)
+            return _StreamDone(stream)
+        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def all_reduce_max(self, tensor):
         return self._all_reduce(tensor, dist.ReduceOp.MAX)

@@ -143,6 +143,22 @@ class NativeEngine:
                                                  _ptr(flat_params), wsp, wsb, _ptr(dvalue), _ptr(dlogp), _ptr(dent),
                                                  _ptr(grads), self._st()), 'upamd_backward')
 
+    # ---- gradient buckets of the last backward on the caller's stream (data parallelism; include/upamd.h)
+    def grad_buckets(self):
+        """[(begin, end)] float ranges of the flat gradient buffer in the order the last `backward` on the current stream
+        made them final (one range for the paths that finalise everything at the end)."""
+        n = C.c_int32()
+        b, e = (C.c_int64 * 24)(), (C.c_int64 * 24)()
+        with self.lock, self._on_device():
+            native.check(self.lib.upamd_grad_buckets(self.handle, self._st(), 24, C.byref(n), b, e), 'upamd_grad_buckets')
+        return [(int(b[i]), int(e[i])) for i in range(n.value)]
+
+    def grad_bucket_wait(self, k, waiter):
+        """`waiter` (a torch.cuda.Stream) waits until bucket k of the last backward on the current stream is final"""
+        with self.lock, self._on_device():
+            native.check(self.lib.upamd_grad_bucket_wait(self.handle, self._st(), int(k), C.c_void_p(waiter.cuda_stream)),
+                         'upamd_grad_bucket_wait')
+
     # ---- fused optimizer-step front end of small models (csrc/tiny.hip)
     def step_fused_ok(self, mb):
         """True when forward + PPO loss + backward of this minibatch run as ONE launch (gcn_node_dim <= 32, graphs that fit

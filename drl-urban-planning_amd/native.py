@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libupamd.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_MLP = 4
 MAX_EDGE_FC = 4
 META_STRIDE = 16
@@ -64,6 +64,8 @@ SYMBOLS = {
                                 C.c_int32, _P]),
     'upamd_backward': (C.c_int, [_P, _P, C.POINTER(PackLayout), C.POINTER(Minibatch), _P, _P, C.c_int64, _P, _P, _P,
                                  _P, _P]),
+    'upamd_grad_buckets': (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'upamd_grad_bucket_wait': (C.c_int, [_P, _P, C.c_int32, _P]),
     'upamd_step_fused_ok': (C.c_int, [_P, C.POINTER(Minibatch)]),
     'upamd_step_fused': (C.c_int, [_P, _P, C.POINTER(PackLayout), C.POINTER(Minibatch), _P, _P, C.c_int64, _P, _P, _P, _P, _P,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),

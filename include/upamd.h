@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define UPAMD_ABI_VERSION 5
+#define UPAMD_ABI_VERSION 6
 
 #define UPAMD_OK 0
 #define UPAMD_E_INVALID (-1)   /* bad argument / unsupported configuration            */
@@ -194,6 +194,18 @@ int upamd_backward(upamd_engine *eng, const void *packed_dev, const upamd_pack_l
                    const float *dvalue_dev, const float *dlogp_dev, const float *dent_dev,
                    float *grads_dev, void *stream);
 
+/* Gradient buckets of the LAST upamd_backward enqueued on `stream` (data parallelism, SURVEY.md section 8e: the reference has one
+ * optimizer.step() per minibatch, urban_planning_agent.py:334-337, and no collective; the north-star adds ONE all-reduce of the
+ * flat gradient buffer per step).  The backward finalises that buffer range by range -- attention + value head + pointer heads
+ * right behind the per-sample products, each GCN layer's weight + bias behind that layer's weight-gradient GEMM, the rest (numerical
+ * + node encoder, first layer) at its end -- and records one event per range: begin[k], end[k]) are float offsets in readiness
+ * order, disjoint, together [0, n_floats).  upamd_grad_bucket_wait makes `waiter_stream` wait for range k, so the caller can
+ * all-reduce it on a communication stream while the layers below are still in their backward.  Paths that finalise everything at
+ * the end (small / rl-mlp models, tune knob "grad_buckets" = 0) report one range.  Same sums in the same order either way: a
+ * bucketed step is bit-identical to a single-range one.  Not updated by upamd_step_fused (one range by construction). */
+int upamd_grad_buckets(upamd_engine *eng, void *stream, int32_t cap, int32_t *n_out, int64_t *begin, int64_t *end);
+int upamd_grad_bucket_wait(upamd_engine *eng, void *stream, int32_t k, void *waiter_stream);
+
 /* Small models (gcn_node_dim <= 32 -- the dims of every shipped YAML, hlg.yaml:21-33 -- single-Linear edge MLPs, graphs that fit one
  * workgroup's LDS): ONE launch runs forward + PPO loss seeds + backward of the whole minibatch, one workgroup per graph, and a second
  * one adds the per-workgroup gradient slabs in a fixed order.  Replaces the upamd_forward / upamd_ppo_loss_rows / upamd_backward
@@ -312,6 +324,7 @@ int upamd_gemm_tn(const float *A_dev, int32_t I, int64_t lda, const float *B_dev
  *   "side_heads"  [1]   land-use pointer-head chain (forward: first Linear; backward: softmax / feature / weight-gradient kernels) on the side stream
  *   "side_wgrad"  [1]   GCN weight-gradient GEMMs on a second side stream: 1 = for minibatches of <= 98304 nodes, 0 never, 2 behind the
  *                       layer's dgrad GEMM, 3 always
+ *   "grad_buckets" [1]  upamd_backward finalises the gradient buffer range by range (upamd_grad_buckets); 0 = everything in the final flush
  *   "side_priority" [1] priority level of the side streams created from now on: 1 high, 0 normal, 2 low
  *   "gemm_lds_pad", "gemm_stagger_mode", "gemm_stagger_cycles": residency / first-round stagger of the LDS-DMA gemm_nt */
 int upamd_tune(const char *name, int32_t value);

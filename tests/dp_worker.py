@@ -67,7 +67,9 @@ def main():
     if rank == 0:
         out = {'losses1': logs[0], 'losses2': logs[1], 'loss_iter': np.int64(agent.loss_iter),
                'mode': np.array(up.last_timing['dp_mode']), 'rows_per_step': np.int64(up.last_timing['rows_per_step']),
-               'n_scalars': np.int64(len(agent.tb_logger.scalars))}
+               'n_scalars': np.int64(len(agent.tb_logger.scalars)),
+               'buckets': np.array(up.last_buckets if up.last_buckets else np.zeros((0, 2)), dtype=np.int64),
+               'n_floats': np.int64(up.engine.n_floats)}
         out.update({'sd1/' + k: v for k, v in sd1.items()})
         out.update({'sd2/' + k: v for k, v in sd2.items()})
         np.savez(os.path.join(out_dir, 'rank0.npz'), **out)

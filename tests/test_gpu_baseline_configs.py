@@ -154,6 +154,53 @@ def test_two_per_cu_forms_of_the_large_size_class_are_bit_identical_to_the_one_p
     assert float(new[-1].abs().max()) > 0
 
 
+@pytest.mark.parametrize('family', ['hlg', 'mixed_stage'])
+def test_gradient_buckets_cover_the_buffer_and_leave_the_bits_alone(family):
+    """upamd_grad_buckets (data parallelism): at the BASELINE model size the backward finalises the flat
+    gradient buffer in >= 3 ranges -- attention + value head + pointer heads first, each upper GCN layer behind its weight-gradient
+    GEMM, the front of the buffer last -- which are disjoint and cover it; moving the reductions there (tune knob grad_buckets = 1,
+    the default) must not change a single bit of any gradient against the single final flush (0).  'mixed_stage' has road
+    rows, i.e. the pointer-head chain on the caller's stream instead of the side stream."""
+    from drl_urban_planning_amd import native, synth
+    cfg, sd = _model()
+    replay = synth.make_replay(24, 'hlg', max_nodes=1000, max_edges=3000, seed=41,
+                               road_fraction=0.3 if family == 'mixed_stage' else 0.0)
+    T = len(replay.states)
+    g = torch.Generator().manual_seed(10)
+    dv, dl, de = (torch.randn(T, generator=g).to(DEV) for _ in range(3))
+
+    def run(on):
+        native.check(native.lib().upamd_tune(b'grad_buckets', on), 'upamd_tune')
+        _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, replay.states, replay.actions)
+        _forward(eng, pk, mb, flat)
+        grads = torch.zeros(eng.n_floats, device=DEV)
+        eng.backward(pk, mb, flat, dv, dl, de, grads)
+        buckets = eng.grad_buckets()
+        # every bucket's event can be waited for from another stream
+        side = torch.cuda.Stream()
+        for k in range(len(buckets)):
+            eng.grad_bucket_wait(k, side)
+        side.synchronize()
+        torch.cuda.synchronize()
+        return grads, buckets, eng
+
+    try:
+        (g1, b1, eng), (g0, b0, _) = run(1), run(0)
+    finally:
+        native.check(native.lib().upamd_tune(b'grad_buckets', 1), 'upamd_tune')
+    assert b0 == [(0, eng.n_floats)]
+    assert len(b1) >= 3 and b1[-1][0] == 0, b1
+    ordered = sorted(b1)
+    assert ordered[0][0] == 0 and ordered[-1][1] == eng.n_floats
+    assert all(a[1] == b[0] for a, b in zip(ordered, ordered[1:])), b1
+    first = dict((name, off) for name, off, _, _, _ in eng.table)
+    assert b1[0] == (first['shared_net.attention_layer.in_proj_weight'], eng.n_floats)
+    assert b1[1][0] == first['shared_net.edge_fc_layers.2.linear_0.weight']
+    assert b1[-1][1] == first['shared_net.edge_fc_layers.1.linear_0.weight']
+    assert torch.equal(g1, g0)
+    assert float(g1.abs().max()) > 0
+
+
 def test_b2048_minibatch_rows_match_oracle_on_a_subsample():
     """BASELINE cfg-2 at full size (2048 HLG-shaped graphs, D = 256, L = 3): 64 of its rows are compared with the
     oracle evaluated on those rows alone -- forward rows directly; the backward through seeds that are zero outside the
