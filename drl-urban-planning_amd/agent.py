@@ -108,6 +108,7 @@ class PPOUpdater:
         # layers below is still running (engine.grad_buckets); False = ONE collective behind the whole backward.  Same bits.
         self.bucketed_allreduce = os.environ.get('UPAMD_GRAD_BUCKETS', '1') != '0'
         self.last_buckets = None              # [(begin, end)] of the last bucketed step (tests, bench.py)
+        self.pending_state = None             # a checkpoint's optimizer state waiting for the GPU buffers (load_state_dict at the next update_params)
         self._comm = None
 
     # ------------------------------------------------------------------ buffers
@@ -401,6 +402,9 @@ class PPOUpdater:
         dev = engine.device
         self.policy_net.train(True)
         self.value_net.train(True)
+        if self.pending_state is not None:
+            state, self.pending_state = self.pending_state, None
+            self.load_state_dict(state)
         it = self.prepare(batch)
         t_loop = time.time()
         cap = self.num_optim_epoch * int(math.floor(it.T / self.mini_batch_size))      # upper bound on the steps
@@ -478,6 +482,8 @@ class HipUpdateMixin:
                             dist_ctx=ctx, dp_mode=os.environ.get('UPAMD_DP_MODE', 'auto'),
                             legacy_zero_grad=self._legacy_zero_grad())
             up.loss_iter = self.loss_iter
+            up.pending_state = getattr(self, '_upamd_pending_opt', None)       # a checkpoint loaded before the updater existed
+            self._upamd_pending_opt = None
             self._upamd_updater = up
         return up
 

@@ -36,6 +36,7 @@ import torch
 
 from .agent import HipUpdateMixin
 from .dist import DistContext, broadcast_batch
+from .rollout_binding import CheckpointMixin, RolloutMixin
 
 _RANK_SEED_STRIDE = 7919
 
@@ -147,12 +148,14 @@ class TorchrunPolicyMixin:
 def bind_reference_agent(cls):
     """``cls`` = the reference's ``UrbanPlanningAgent``; returns the class that replaces it (same name, same module,
     same constructor): ``update_params`` runs on the HIP engine, the torchrun policies sit in front of ``sample`` /
-    ``eval_agent`` / ``save_checkpoint`` / ``setup_logger``, everything else is inherited."""
+    ``eval_agent`` / ``save_checkpoint`` / ``setup_logger``, behind them the rollout side of SURVEY section 8f
+    (``rollout_binding``: ``UPAMD_ROLLOUT=server`` -- batched GPU action serving + shared-memory replay arenas in
+    ``sample``, evaluation behind a client; optimizer state in the checkpoint files), everything else is inherited."""
     if getattr(cls, '_upamd_bound', False):
         return cls
     if 'update_params' not in cls.__dict__ and not any('update_params' in b.__dict__ for b in cls.__mro__[1:]):
         raise TypeError('%r has no update_params to replace' % (cls,))
-    bound = type(cls.__name__, (HipUpdateMixin, TorchrunPolicyMixin, cls),
+    bound = type(cls.__name__, (HipUpdateMixin, TorchrunPolicyMixin, RolloutMixin, CheckpointMixin, cls),
                  {'__module__': cls.__module__, '__doc__': cls.__doc__, '_upamd_bound': True,
                   '_upamd_reference_class': cls})
     bound.__qualname__ = cls.__qualname__

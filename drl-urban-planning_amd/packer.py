@@ -204,6 +204,14 @@ def compact_from_arrays(numerical, node_features, edge_index, current_node, land
                              grow(rm, nr), st])
 
 
+def record_bytes_bound(pad_n, pad_e, node_dim, numerical_len, stage_len=3):
+    """Largest compact record a state with these pad sizes can produce (every padded row in use)."""
+    h = np.zeros((), dtype=_REC_HEADER)
+    h['node_dim'], h['numerical_len'], h['cur_len'], h['stage_len'] = node_dim, numerical_len, node_dim, stage_len
+    h['n_rows'], h['e_rows'] = pad_n, pad_e
+    return _record_sections(h)[1]
+
+
 def is_record(obj):
     return isinstance(obj, np.ndarray) and obj.dtype == np.uint8 and obj.ndim == 1 and obj.size >= _REC_HEADER.itemsize \
         and int(obj[:4].view('<u4')[0]) == _REC_MAGIC

@@ -1,0 +1,277 @@
+"""SURVEY.md section 8f rows 1-3 bound into the class ``bind_reference_agent`` returns (opt-in, per process):
+
+``UPAMD_ROLLOUT=server``
+    ``sample()`` (khrylib/rl/agents/agent.py:75-100) keeps the networks on the GPU and forks ``nthreads`` env workers
+    that run the reference's OWN ``sample_worker`` (urban_planning/agents/urban_planning_agent.py:49-91) unchanged --
+    only two names it looks up are different in the child: ``self.policy_net`` is a ``rollout.ActionClient`` (same
+    ``select_action(x, mean_action)``; the learner process answers every pending request with ONE batched HIP forward
+    and samples on the device) and ``Memory()`` makes a ``rollout.ArenaMemory`` (same ``push``; the transition lands
+    as a compact record in the worker's shared-memory arena).  Nothing is pickled but the worker's ``LoggerRL``; the
+    batch handed to ``update_params`` is a ``rollout.RecordBatch`` whose states are views into the arenas, which
+    ``packer.pack_replay`` reads in place.  In the reference worker 0 is the learner process itself; here the learner
+    serves, so all ``nthreads`` workers are children: worker 0 is seeded from the learner's RNG streams (which advance
+    once per ``sample()``), workers 1.. seed themselves exactly as the reference does (``seed_worker``, agent.py:66-69).
+    Actions are drawn by ``Categorical.sample`` on the GPU's generator: the same distribution as the reference's CPU
+    draw, not the same stream ("re-baselined").
+
+    ``eval_agent()`` (urban_planning_agent.py:402-467) runs the reference's own body in one more forked child behind a
+    client: the model never makes the CPU <-> GPU round trip of ``to_cpu`` (:406).
+
+``UPAMD_EVAL=overlap`` (needs the server)
+    the greedy evaluation episode becomes one more client of the SAME serving phase as the sampling workers, i.e. it runs
+    concurrently with them on the weights sampling uses.  ``optimize_policy`` (:225-246) is untouched, so its
+    ``eval_agent`` call after the update receives that log: ``eval_R_eps`` of iteration i then describes the weights the
+    iteration STARTED with (one update behind the reference's number, whose T_eval it removes from the iteration).  The
+    evaluated weights are kept (a CPU ``state_dict``), and ``save_checkpoint`` writes ``best.p`` from THEM, so a best
+    checkpoint still pairs a reward with the weights that earned it.
+
+Checkpoints (always on, no switch): ``save_checkpoint`` adds ``'hip_optimizer'`` -- ``PPOUpdater.state_dict()``: Adam
+moments, per-group step counts, the first-step clipping flag -- to every file the reference's ``save_checkpoint``
+(:172-194) has just written, and ``load_checkpoint`` (:153-170) of a FRESH process restores it, so a resumed run
+continues the Adam trajectory instead of restarting it (the reference omits optimizer state).  Files without the key load
+as before; a load in the middle of a run (``freeze_land_use``, :215-222) leaves Adam alone, as the reference's does.
+"""
+import glob
+import math
+import os
+import pickle
+import time
+import traceback
+
+import numpy as np
+import torch
+
+from . import packer
+
+
+def _rollout_child(client, agent, kind, pid, arena_spec, n, mean_action, seeds, out_q):
+    """Body of one forked env worker.  The child never touches the (GPU) modules or the HIP runtime."""
+    from . import rollout
+    arena = None
+    try:
+        agent.policy_net = client               # what sample_worker / eval_agent call select_action on
+        agent.sample_modules = []               # to_test / to_cpu (agent.py:79-80, urban_planning_agent.py:404-406) see nothing
+        if kind == 'sample':
+            arena = rollout.SharedArena(arena_spec[1], arena_spec[2], name=arena_spec[0])
+            worker = agent.sample_worker
+            getattr(worker, '__func__', worker).__globals__['Memory'] = lambda: rollout.ArenaMemory(arena)
+            if pid == 0 and seeds is not None:
+                torch.manual_seed(int(seeds[0]))
+                np.random.seed(int(seeds[1]))
+            memory, logger = agent.sample_worker(pid, None, n, mean_action)
+            out_q.put((kind, pid, len(memory), logger, None))
+        else:
+            out_q.put((kind, pid, 0, agent._upamd_eval_reference(n, mean_action), None))
+    except BaseException as exc:                # report instead of dying silently: the learner is waiting on the queue
+        out_q.put((kind, pid, -1, None, '%s: %s\n%s' % (type(exc).__name__, exc, traceback.format_exc())))
+    finally:
+        try:
+            client.close()
+            if arena is not None:
+                arena.close(unlink=False)
+        except Exception:
+            pass
+
+
+class RolloutMixin:
+    """``sample`` / ``eval_agent`` through ``rollout.ActionServer`` + ``rollout.SharedArena`` (module docstring)."""
+
+    # ---- switches
+    @staticmethod
+    def _upamd_rollout_mode():
+        mode = os.environ.get('UPAMD_ROLLOUT', 'reference')
+        if mode not in ('reference', 'server'):
+            raise ValueError("UPAMD_ROLLOUT must be 'reference' or 'server'")
+        return mode
+
+    @staticmethod
+    def _upamd_eval_overlap():
+        mode = os.environ.get('UPAMD_EVAL', 'serial')
+        if mode not in ('serial', 'overlap'):
+            raise ValueError("UPAMD_EVAL must be 'serial' or 'overlap'")
+        return mode == 'overlap'
+
+    def _upamd_eval_reference(self, num_samples=1, mean_action=True, visualize=False):
+        """The reference's own eval_agent body (urban_planning_agent.py:402-467), past every mixin."""
+        return super(RolloutMixin, self).eval_agent(num_samples, mean_action, visualize)
+
+    def _upamd_arena_caps(self, rows):
+        specs = getattr(self.cfg, 'state_encoder_specs', None) or {}
+        pad_n, pad_e = int(specs.get('max_num_nodes', 1000)), int(specs.get('max_num_edges', 3000))
+        rec = packer.record_bytes_bound(pad_n, pad_e, int(self.node_dim), int(self.numerical_feature_size))
+        # a worker appends whole episodes until it has `rows` steps (urban_planning_agent.py:54): room for the overshoot.
+        # Shared memory is committed page by page as it is written, so the worst-case byte bound costs nothing up front
+        cap_rows = int(rows) + max(int(getattr(self.cfg, 'max_sequence_length', 0) or 0), 256)
+        return cap_rows, cap_rows * rec
+
+    # ---- one serving phase: fork the children, serve until every one of them has reported
+    def _upamd_serve(self, jobs, arenas, seeds=None, timeout_s=None):
+        """jobs: [(kind, pid, n, mean_action)], arenas: {job index: SharedArena}.  Returns the children's reports in job
+        order: (kind, pid, rows, logger)."""
+        from . import rollout
+        import multiprocessing
+        ctx = multiprocessing.get_context('fork')
+        out_q = ctx.Queue()
+        server = rollout.ActionServer(self.policy_net, len(jobs), slot_bytes=int(os.environ.get('UPAMD_ROLLOUT_SLOT', 1 << 20)),
+                                      mp_context=ctx)
+        args = []
+        for j, (kind, pid, n, mean) in enumerate(jobs):
+            a = arenas.get(j)
+            args.append((self, kind, pid, (a.name, a.cap_rows, a.cap_bytes) if a is not None else None, n, mean, seeds, out_q))
+        procs = server.launch(_rollout_child, args, ctx)       # forks FIRST, then starts the serving thread
+        reports, failed = {}, None
+        deadline = None if timeout_s is None else time.time() + timeout_s
+        try:
+            while len(reports) < len(jobs) and failed is None:
+                try:
+                    kind, pid, rows, logger, err = out_q.get(timeout=1.0)
+                except Exception:               # queue.Empty: is everyone still alive, is the server still serving?
+                    dead = [p for p in procs if p.exitcode not in (None, 0)]
+                    if dead:
+                        failed = 'an env worker died with exit code %s' % dead[0].exitcode
+                    elif server.last_error and server._thread is not None and not server._thread.is_alive():
+                        failed = 'the action server stopped: %s' % server.last_error
+                    elif deadline is not None and time.time() > deadline:
+                        failed = 'rollout timed out after %.0f s' % timeout_s
+                    continue
+                if err is not None:
+                    failed = 'env worker %s %d failed:\n%s' % (kind, pid, err)
+                    break
+                reports[(kind, pid)] = (kind, pid, rows, logger)
+        finally:
+            for p in procs:
+                p.join(timeout=5.0 if failed is None else 0.5)
+                if p.is_alive():
+                    p.terminate()
+            self._upamd_server_stats = dict(server.stats)
+            server.close()
+        if failed is not None:
+            raise RuntimeError('UPAMD_ROLLOUT=server: %s' % failed)
+        return [reports[(kind, pid)] for kind, pid, _, _ in jobs]
+
+    def _upamd_release_arenas(self):
+        for a in getattr(self, '_upamd_arenas', None) or []:
+            try:
+                a.close()
+            except Exception:
+                pass
+        self._upamd_arenas = []
+
+    # ---- Agent.sample (khrylib/rl/agents/agent.py:75-100)
+    def sample(self, num_samples, mean_action=False, nthreads=None):
+        if self._upamd_rollout_mode() != 'server':
+            return super().sample(num_samples, mean_action, nthreads)
+        from . import rollout
+        if nthreads is None:
+            nthreads = self.num_threads
+        t_start = time.time()
+        for m in self.sample_modules:           # to_test (:79); the modules stay where they are (no to_cpu, :80)
+            m.train(False)
+        thread_num_samples = int(math.floor(num_samples / nthreads))
+        self._upamd_release_arenas()            # the previous iteration's batch has been consumed by update_params
+        cap_rows, cap_bytes = self._upamd_arena_caps(thread_num_samples)
+        arenas = [rollout.SharedArena(cap_rows, cap_bytes) for _ in range(nthreads)]
+        self._upamd_arenas = arenas
+        if os.environ.get('UPAMD_ROLLOUT_PIN') == '1':
+            for a in arenas:
+                a.pin()
+        # worker 0 is a child here (the learner serves): it gets its seeds from the learner's streams, which therefore advance
+        # once per call -- so do the states workers 1.. derive their seeds from (seed_worker, agent.py:66-69)
+        seeds = (int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), int(np.random.randint(2 ** 31 - 1)))
+        jobs = [('sample', i, thread_num_samples, mean_action) for i in range(nthreads)]
+        overlap = self._upamd_eval_overlap() and getattr(self, 'training', True) and not mean_action
+        if overlap:
+            jobs.append(('eval', nthreads, 1, True))
+            self._upamd_eval_sd = {k: v.detach().to('cpu', copy=True) for k, v in self.actor_critic_net.state_dict().items()}
+        with torch.no_grad():
+            reports = self._upamd_serve(jobs, {i: arenas[i] for i in range(nthreads)}, seeds)
+        if overlap:
+            self._upamd_eval_ahead = reports[-1][3]
+        memories = [rollout.ArenaMemory(a) for a in arenas]
+        for (kind, pid, rows, _), m in zip(reports[:nthreads], memories):
+            if rows != len(m):
+                raise RuntimeError('env worker %d reported %d rows, its arena holds %d' % (pid, rows, len(m)))
+        traj_batch = rollout.RecordBatch(memories)
+        logger = self.logger_cls.merge([r[3] for r in reports[:nthreads]], **self.logger_kwargs)
+        logger.sample_time = time.time() - t_start
+        return traj_batch, logger
+
+    # ---- UrbanPlanningAgent.eval_agent (urban_planning_agent.py:402-467)
+    def eval_agent(self, num_samples=1, mean_action=True, visualize=False):
+        if self._upamd_rollout_mode() != 'server' or visualize:
+            return super().eval_agent(num_samples, mean_action, visualize)
+        ahead = getattr(self, '_upamd_eval_ahead', None)
+        if ahead is not None and num_samples == 1 and mean_action:
+            self._upamd_eval_ahead = None       # the episode that ran next to this iteration's sampling workers
+            return ahead
+        t_start = time.time()
+        for m in self.sample_modules:
+            m.train(False)
+        self._upamd_eval_sd = None              # evaluated == current weights
+        with torch.no_grad():
+            log = self._upamd_serve([('eval', 0, num_samples, mean_action)], {})[0][3]
+        log.sample_time = time.time() - t_start
+        return log
+
+
+class CheckpointMixin:
+    """Optimizer state in the reference's checkpoint files (module docstring)."""
+
+    def _upamd_cp_path(self, checkpoint):
+        cfg = self.cfg          # (:155-160)
+        return '%s/iteration_%04d.p' % (cfg.model_dir, checkpoint) if isinstance(checkpoint, int) else '%s/%s.p' % (cfg.model_dir, checkpoint)
+
+    def load_checkpoint(self, checkpoint, restore_best_rewards):
+        start = super().load_checkpoint(checkpoint, restore_best_rewards)
+        try:
+            with open(self._upamd_cp_path(checkpoint), 'rb') as fh:
+                state = pickle.load(fh).get('hip_optimizer')
+        except (OSError, AttributeError):
+            state = None
+        # the updater is built lazily (its hyper-parameters are set by AgentPPO.__init__, which runs AFTER load_checkpoint,
+        # urban_planning_agent.py:38-47) and Adam's buffers live on the GPU: parked here, applied by the next update_params
+        up = getattr(self, '_upamd_updater', None)
+        if up is not None and up.m is not None:
+            # a load in the middle of a run (freeze_land_use re-loads best.p, :215-222): the reference keeps its optimizer
+            # OBJECT, i.e. Adam carries on from the current moments -- so does this
+            return start
+        self._upamd_pending_opt = state
+        if up is not None:
+            up.pending_state = state
+        return start
+
+    def save_checkpoint(self, iteration):
+        model_dir = self.cfg.model_dir
+        before = {p: os.stat(p).st_mtime_ns for p in glob.glob(os.path.join(model_dir, '*.p'))}
+        swap = getattr(self, '_upamd_eval_sd', None) if (getattr(self, 'save_best_flag', False) and
+                                                         os.environ.get('UPAMD_EVAL') == 'overlap') else None
+        if swap is None:
+            super().save_checkpoint(iteration)
+        else:
+            # UPAMD_EVAL=overlap: the reward that set save_best_flag belongs to the weights the iteration started with.  The
+            # periodic file gets the current weights, the best files the evaluated ones
+            net, cfg = self.actor_critic_net, self.cfg
+            self.save_best_flag = False
+            super().save_checkpoint(iteration)
+            current = {k: v.detach().clone() for k, v in net.state_dict().items()}
+            interval, cfg.save_model_interval = cfg.save_model_interval, 0
+            try:
+                net.load_state_dict(swap)
+                self.save_best_flag = True
+                super().save_checkpoint(iteration)
+            finally:
+                cfg.save_model_interval = interval
+                net.load_state_dict(current)
+        up = getattr(self, '_upamd_updater', None)
+        state = up.state_dict() if (up is not None and up.m is not None) else getattr(self, '_upamd_pending_opt', None)
+        if state is None:
+            return
+        for p in glob.glob(os.path.join(model_dir, '*.p')):
+            if before.get(p) == os.stat(p).st_mtime_ns:
+                continue                        # not written by this call
+            with open(p, 'rb') as fh:
+                cp = pickle.load(fh)
+            if isinstance(cp, dict) and 'actor_critic_dict' in cp:
+                cp['hip_optimizer'] = state
+                with open(p, 'wb') as fh:
+                    pickle.dump(cp, fh)

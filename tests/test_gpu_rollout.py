@@ -115,3 +115,196 @@ def test_gpu_action_server_with_sampling_and_eval_clients():
     server.close()
     for a in arenas:
         a.close()
+
+
+# ------------------------------------------------------------------------------------------------ bound into the agent class
+class _ReferenceLikeAgent:
+    """The methods of ``UrbanPlanningAgent`` / ``Agent`` the rollout + checkpoint binding wraps, restated with the reference's
+    signatures and file format (urban_planning_agent.py:49-91 sample_worker, :153-194 load / save_checkpoint, :402-467
+    eval_agent; khrylib/rl/agents/agent.py:75-100 sample is never reached in server mode) -- the REAL class is exercised on
+    the CPU in tests/test_reference_binding.py, where /root/reference exists; this stand-in carries the same contract to
+    the GPU box."""
+
+    def __init__(self, cfg, env, policy_net, value_net, actor_critic, hy, num_optim_epoch, mini_batch_size, num_threads):
+        import logging
+        from oracle.ref_import import ScalarLog
+        self.cfg, self.env, self.training, self.loss_iter = cfg, env, True, 0
+        self.node_dim, self.numerical_feature_size = 23, 52
+        self.policy_net, self.value_net, self.actor_critic_net = policy_net, value_net, actor_critic
+        self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=hy['lr'], eps=hy['eps'], weight_decay=hy['weight_decay'])
+        self.gamma, self.tau, self.clip_epsilon = hy['gamma'], hy['tau'], hy['clip_epsilon']
+        self.value_pred_coef, self.entropy_coef = hy['value_pred_coef'], hy['entropy_coef']
+        self.opt_num_epochs, self.mini_batch_size, self.num_threads = num_optim_epoch, mini_batch_size, num_threads
+        self.noise_rate, self.sample_modules, self.logger_kwargs = 1.0, [policy_net], {}
+        self.logger_cls = _EpisodeLog
+        self.tb_logger, self.logger = ScalarLog(), logging.getLogger('upamd-gpu-test')
+        self.thread_loggers = [self.logger] * num_threads
+        self.best_rewards, self.best_plans, self.current_rewards, self.current_plans, self.save_best_flag = -1000.0, [], -1000.0, [], False
+
+    def seed_worker(self, pid):
+        if pid > 0:
+            torch.manual_seed(torch.randint(0, 5000, (1,)) * pid)
+            np.random.seed(np.random.randint(5000) * pid)
+
+    def push_memory(self, memory, state, action, mask, next_state, reward, exp):
+        memory.push(state, action, mask, next_state, reward, exp)
+
+    def sample_worker(self, pid, queue, num_samples, mean_action):
+        self.seed_worker(pid)
+        memory = Memory()                       # noqa: F821 -- a module global in the reference too (the binding swaps it in the child)
+        logger = self.logger_cls(**self.logger_kwargs)
+        while logger.num_steps < num_samples:
+            state = self.env.reset()
+            messages = []
+            for t in range(10000):
+                state_var = [[torch.tensor(x) for x in state]]
+                use_mean_action = mean_action or torch.bernoulli(torch.tensor([1 - self.noise_rate])).item()
+                action = self.policy_net.select_action(state_var, use_mean_action).numpy().squeeze(0)
+                next_state, reward, done, info = self.env.step(action, self.thread_loggers[pid])
+                messages.append([state, action, 0 if done else 1, next_state, reward, 1 - use_mean_action])
+                if done:
+                    break
+                state = next_state
+            logger.num_episodes += 1
+            for m in messages:
+                logger.num_steps += 1
+                logger.total_reward += m[4]
+                self.push_memory(memory, *m)
+        if queue is not None:
+            queue.put([pid, memory, logger])
+        else:
+            return memory, logger
+
+    def eval_agent(self, num_samples=1, mean_action=True, visualize=False):
+        self.env.eval()
+        logger = self.logger_cls()
+        while logger.num_steps < num_samples:
+            state = self.env.reset()
+            for t in range(1, 10000):
+                action = self.policy_net.select_action([[torch.tensor(x) for x in state]], mean_action).numpy().squeeze(0)
+                state, reward, done, info = self.env.step(action, self.logger)
+                logger.num_steps += 1
+                logger.total_reward += reward
+                if done:
+                    break
+            logger.num_episodes += 1
+        self.env.train()
+        return self.logger_cls.merge([logger])
+
+    def save_checkpoint(self, iteration):
+        import pickle
+        cp = {'actor_critic_dict': {k: v.detach().cpu() for k, v in self.actor_critic_net.state_dict().items()},
+              'loss_iter': self.loss_iter, 'best_rewards': self.best_rewards, 'iteration': iteration}
+        with open('%s/iteration_%04d.p' % (self.cfg.model_dir, iteration + 1), 'wb') as fh:
+            pickle.dump(cp, fh)
+
+    def load_checkpoint(self, checkpoint, restore_best_rewards):
+        import pickle
+        cp = pickle.load(open('%s/iteration_%04d.p' % (self.cfg.model_dir, checkpoint), 'rb'))
+        self.actor_critic_net.load_state_dict(cp['actor_critic_dict'])
+        self.loss_iter = cp['loss_iter']
+        return cp['iteration'] + 1
+
+    def update_params(self, batch, iteration):
+        raise AssertionError('the reference update ran')
+
+
+class _EpisodeLog:
+    def __init__(self, **kw):
+        self.num_steps, self.num_episodes, self.total_reward, self.sample_time = 0, 0, 0.0, 0.0
+
+    @classmethod
+    def merge(cls, logs, **kw):
+        out = cls()
+        out.num_steps, out.num_episodes = sum(x.num_steps for x in logs), sum(x.num_episodes for x in logs)
+        out.total_reward = sum(x.total_reward for x in logs)
+        out.avg_episode_reward = out.total_reward / max(out.num_episodes, 1)
+        return out
+
+
+def _bound_agent(tmp_path, name, num_threads=3, seed=None, load_sd=True):
+    import types
+    from drl_urban_planning_amd.binding import bind_reference_agent
+    from stub_env import StubCityEnv
+    from test_oracle_golden import CASE_B, CASE_EPOCHS, CASE_HYPER
+    z, sd, states = helpers.load_case(name)
+    kw = helpers.CASE_MODEL[name]
+    cfg = helpers.make_cfg(**kw)
+    cfg.model_dir = str(tmp_path)
+    policy_net, value_net, ac = helpers.build_product(cfg, seed=0 if seed is None else seed)
+    if load_sd:
+        ac.load_state_dict(sd)
+    ac.to(DEV)
+    cls = bind_reference_agent(_ReferenceLikeAgent)
+    env = StubCityEnv(max_nodes=kw['max_nodes'], max_edges=kw['max_edges'], episode_len=6, pool=48, seed=8)
+    return cls(cfg, env, policy_net, value_net, ac, CASE_HYPER[name], CASE_EPOCHS[name], CASE_B[name], num_threads), z, states
+
+
+def test_bound_agent_samples_through_the_server_and_updates_on_the_records(tmp_path, monkeypatch):
+    """UPAMD_ROLLOUT=server on the bound class with the HIP modules: ``sample()`` -> forked ``sample_worker`` children behind
+    action clients (ONE batched GPU forward per serving round) -> RecordBatch -> ``update_params`` on the arenas; greedy
+    evaluation behind a client equals the in-process greedy episode; UPAMD_EVAL=overlap runs it inside the sampling phase."""
+    from drl_urban_planning_amd import rollout
+    from stub_env import StubCityEnv
+    ag, z, _ = _bound_agent(tmp_path, 'case_a')
+    with torch.no_grad():                   # the HIP library is initialised before the first fork
+        ag.policy_net.select_action(StubCityEnv(max_nodes=40, max_edges=96).states[:2], True)
+    monkeypatch.setenv('UPAMD_ROLLOUT', 'server')
+    batch, log = ag.sample(36)              # 3 workers x 12 steps = 2 episodes of 6 each
+    assert isinstance(batch, rollout.RecordBatch) and len(batch) == 36 and log.num_episodes == 6
+    st = ag._upamd_server_stats
+    assert st['requests'] == 36 and st['max_rows'] >= 2, st
+    for rec, a in zip(batch.states, batch.actions):
+        s = __import__('drl_urban_planning_amd').packer.expand_state(rec, padded=True)
+        stage = int(np.argmax(s[8]))
+        assert (s[6] if stage == 0 else s[7])[int(a[stage])] and a[1 - stage] == 0
+    np.random.seed(5)
+    ag.update_params(batch, 0)
+    losses = ag._hip_updater().last_losses
+    assert losses.shape[0] > 0 and np.isfinite(losses).all()
+    # evaluation behind a client == the same greedy episode computed in this process on the GPU modules
+    ag.env.episode = -1
+    want = _ReferenceLikeAgent.eval_agent(ag, 1, True)
+    ag.env.episode = -1
+    got = ag.eval_agent(num_samples=1, mean_action=True)
+    assert got.total_reward == want.total_reward and ag._upamd_server_stats['requests'] == 6
+    monkeypatch.setenv('UPAMD_EVAL', 'overlap')
+    ag.env.episode = -1
+    batch, log = ag.sample(36)
+    assert ag._upamd_server_stats['requests'] == 42 and ag._upamd_eval_ahead is not None
+    ahead = ag.eval_agent(num_samples=1, mean_action=True)
+    assert ahead.num_episodes == 1 and ag._upamd_server_stats['requests'] == 42 and ag._upamd_eval_ahead is None
+    ag._upamd_release_arenas()
+
+
+@pytest.mark.parametrize('name', ['case_a'])
+def test_bound_agent_checkpoint_resumes_adam_on_the_reference_trajectory(name, tmp_path):
+    """save_checkpoint / load_checkpoint of the bound class carry 'hip_optimizer': first update_params -> save -> a FRESH
+    agent (other initial weights, no optimizer history) -> load -> second update_params must land on the parameters the
+    uninterrupted REFERENCE run reaches after its second call (golden upd2_sd), which restarting Adam does not."""
+    import pickle
+    from drl_urban_planning_amd import synth
+    from test_oracle_golden import CASE_SEED
+    ag, z, states = _bound_agent(tmp_path, name)
+    replay = synth.Replay(states, z['actions'], z['masks'], z['rewards'], z['exps'])
+    np.random.seed(CASE_SEED[name] + 11)
+    ag.update_params(replay, 0)
+    ag.save_checkpoint(0)
+    cp = pickle.load(open('%s/iteration_0001.p' % tmp_path, 'rb'))
+    assert cp['hip_optimizer']['clip_pending'] is False and sum(cp['hip_optimizer']['group_steps']) > 0
+    assert cp['loss_iter'] == int(z['upd/loss_iter'])
+
+    def second_call(with_optimizer):
+        fresh, _, _ = _bound_agent(tmp_path, name, seed=99, load_sd=False)
+        if not with_optimizer:              # what the reference's own checkpoint holds
+            stripped = dict(cp)
+            stripped.pop('hip_optimizer')
+            pickle.dump(stripped, open('%s/iteration_0002.p' % tmp_path, 'wb'))
+        assert fresh.load_checkpoint(1 if with_optimizer else 2, True) == 1 and fresh.loss_iter == cp['loss_iter']
+        np.random.seed(CASE_SEED[name] + 12)
+        fresh.update_params(replay, 1)
+        mine = {k: v.detach().cpu().numpy() for k, v in fresh.actor_critic_net.state_dict().items()}
+        return max(float(np.linalg.norm(mine[k] - z['upd2_sd/' + k]) / max(np.linalg.norm(z['upd2_sd/' + k]), 1e-30)) for k in mine)
+
+    assert second_call(True) <= 2e-4
+    assert second_call(False) > 5e-4        # Adam restarted (and the first-step clip re-applied): a different trajectory

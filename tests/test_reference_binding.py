@@ -194,7 +194,7 @@ from drl_urban_planning_amd import HipUpdateMixin, models
 assert UrbanPlanningAgent.update_params is HipUpdateMixin.update_params
 assert m.create_sgnn_model is models.create_sgnn_model
 assert __name__ == '__main__' and sys.argv[1:] == ['--cfg', 'hlg']
-print('BOUND', UrbanPlanningAgent.__name__, [c.__name__ for c in UrbanPlanningAgent.__mro__[1:4]])
+print('BOUND', UrbanPlanningAgent.__name__, [c.__name__ for c in UrbanPlanningAgent.__mro__[1:6]])
 '''
 
 
@@ -209,7 +209,8 @@ def test_launcher_binds_an_unedited_reference_tree(tmp_path):
     res = subprocess.run([sys.executable, '-m', 'drl_urban_planning_amd.launch', str(tmp_path / 'entry.py'), '--cfg', 'hlg'],
                          env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "BOUND UrbanPlanningAgent ['HipUpdateMixin', 'TorchrunPolicyMixin', 'UrbanPlanningAgent']" in res.stdout
+    assert ("BOUND UrbanPlanningAgent ['HipUpdateMixin', 'TorchrunPolicyMixin', 'RolloutMixin', 'CheckpointMixin', "
+            "'UrbanPlanningAgent']") in res.stdout
 
 
 # --------------------------------------------------------------------------------------------- rank -> device mapping
@@ -381,3 +382,152 @@ def test_torchrun_policies_world_2(tmp_path):
     mp.spawn(_policy_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(str(tmp_path / 'ok'))
     assert len(os.listdir(str(tmp_path / 'tb_dir'))) == 2          # rank 0's event file + the rank1/ directory
+
+
+# --------------------------------------------------- SURVEY section 8f rows 1-3 bound into the REAL class (rollout_binding)
+def _rollout_agent(tmp_path, num_threads=2, seed=3, cls=None, ref=None):
+    """The REAL bound class built the way the reference builds it, with the stub env and the reference's own LoggerRL."""
+    import logging
+    ref = ref or ref_import.load_reference()                # (stubs + sys.path before the reference imports below)
+    from khrylib.rl.core import LoggerRL
+    from urban_planning.utils.tools import TrajBatchDisc
+    from stub_env import StubCityEnv
+    cls = cls or patched_module(tmp_path).UrbanPlanningAgent
+    cfg = reference_cfg(tmp_path)
+    torch.manual_seed(seed)
+    ag = build_like_the_reference(cls, ref, cfg)
+    ag.env = StubCityEnv()
+    ag.logger_cls, ag.logger_kwargs, ag.traj_cls, ag.num_threads = LoggerRL, {}, TrajBatchDisc, num_threads
+    ag.thread_loggers = [logging.getLogger('upamd-test-%d' % i) for i in range(num_threads)]
+    ag.logger = logging.getLogger('upamd-test')
+    return ag, ref
+
+
+@needs_reference
+def test_server_rollout_through_the_real_sample_worker(tmp_path, monkeypatch):
+    """UPAMD_ROLLOUT=server: ``sample()`` of the REAL bound class runs the reference's own ``sample_worker`` (:49-91) in
+    forked children behind action clients and shared-memory arenas.  Episodes come back as a RecordBatch whose rows are,
+    bit for bit, the env's states in worker order; greedy sampling gives exactly the actions of the module's own
+    ``select_action`` (policy.py:67-85); the default (reference) mode still returns the reference's TrajBatchDisc."""
+    from drl_urban_planning_amd import packer, rollout
+    from stub_env import StubCityEnv
+    # the reference's learner runs with OMP_NUM_THREADS=1 (khrylib/rl/agents/agent.py:12): its workers fork() and run torch
+    # forwards, which deadlocks in a child of a process whose OpenMP pool has already started
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    request_finalizer = lambda: torch.set_num_threads(threads)
+    ag, ref = _rollout_agent(tmp_path)
+    assert [c.__name__ for c in type(ag).__mro__[1:6]] == ['HipUpdateMixin', 'TorchrunPolicyMixin', 'RolloutMixin',
+                                                           'CheckpointMixin', 'UrbanPlanningAgent']
+    monkeypatch.setenv('UPAMD_ROLLOUT', 'server')
+    np.random.seed(1)
+    torch.manual_seed(1)
+    batch, log = ag.sample(20, mean_action=True)            # 2 workers x 2 episodes x 5 steps, greedy
+    assert isinstance(batch, rollout.RecordBatch) and len(batch) == 20 and log.num_steps == 20 and log.num_episodes == 4
+    assert all(packer.is_record(s) for s in batch.states)
+    assert ag._upamd_server_stats['requests'] == 20 and ag._upamd_server_stats['rows'] == 20
+    env = StubCityEnv()
+    rows = []
+    for worker in range(2):                                 # every worker starts from its own fork of the same env
+        e = StubCityEnv()
+        for ep in range(2):
+            s = e.reset()
+            for t in range(5):
+                a = ag.policy_net.select_action(ref.tensorfy([s]), True).numpy().squeeze(0)
+                rows.append((s, a))
+                s, r, done, info = e.step(a)
+    for (want_s, want_a), rec, got_a in zip(rows, batch.states, batch.actions):
+        for x, y in zip(packer.expand_state(rec, padded=True), want_s):
+            assert np.array_equal(x, y)
+        assert np.array_equal(got_a, want_a)
+    assert batch.masks.tolist() == [1, 1, 1, 1, 0] * 4 and set(batch.exps.tolist()) == {0.0}     # exp = 1 - use_mean_action (:73)
+    assert batch.rewards[4] == pytest.approx(1.0 + 0.01 * float(batch.actions[:5].sum()))
+    assert log.avg_episode_reward == pytest.approx(float(batch.rewards.sum()) / 4)
+    # stochastic sampling: valid actions, exps = 1 (noise_rate = 1), a different draw on the next call (the learner's streams advance)
+    b1, _ = ag.sample(20)
+    a1 = b1.actions.copy()
+    b2, _ = ag.sample(20)
+    assert set(b1.exps.tolist()) == {1.0} and not np.array_equal(a1, b2.actions)
+    for rec, a in zip(b2.states, b2.actions):
+        st = packer.expand_state(rec, padded=True)
+        stage = int(np.argmax(st[8]))
+        assert (st[6] if stage == 0 else st[7])[int(a[stage])] and a[1 - stage] == 0
+    # the records pack exactly like the padded tuples the reference's queue would have carried
+    padded = [packer.expand_state(r, padded=True) for r in b2.states]
+    pk_a = packer.pack_replay(b2.states, b2.actions, 23, 52, pin=False)
+    pk_b = packer.pack_replay(padded, b2.actions, 23, 52, pin=False)
+    from test_packer import _sections
+    sa, sb = _sections(pk_a, 52), _sections(pk_b, 52)
+    assert all(np.array_equal(sa[k], sb[k]) for k in sa if k != 'meta')
+    # switched off: the reference's own sample() (CPU forwards in the workers, Memory + queue) and its TrajBatchDisc
+    monkeypatch.setenv('UPAMD_ROLLOUT', 'reference')
+    b3, log3 = ag.sample(20, mean_action=True)
+    assert type(b3).__name__ == 'TrajBatchDisc' and len(b3.states) == 20
+    assert np.array_equal(np.stack(b3.actions), batch.actions)
+    ag._upamd_release_arenas()
+    request_finalizer()
+
+
+@needs_reference
+def test_server_evaluation_serial_and_overlapped(tmp_path, monkeypatch):
+    """``eval_agent`` (:402-467) behind a client gives the reference's own evaluation (same greedy episode, same reward);
+    UPAMD_EVAL=overlap runs that episode as one more client of the sampling phase and hands its log to the ``eval_agent``
+    call ``optimize_policy`` (:225-246) makes after the update, with the evaluated weights kept for ``best.p``."""
+    ag, ref = _rollout_agent(tmp_path)
+    want = ag._upamd_eval_reference(1, True)                # the reference's body in this process (CPU modules)
+    assert ag.env.mode == 'train' and want.num_episodes == 1 and len(want.plans) == 1
+    monkeypatch.setenv('UPAMD_ROLLOUT', 'server')
+    ag.env.episode = -1                                     # the same first episode again
+    got = ag.eval_agent(num_samples=1, mean_action=True)
+    assert got.avg_episode_reward == want.avg_episode_reward and got.plans == want.plans and got.sample_time > 0
+    assert ag._upamd_server_stats['requests'] == 5
+    monkeypatch.setenv('UPAMD_EVAL', 'overlap')
+    ag.env.episode = -1
+    sd0 = {k: v.clone() for k, v in ag.actor_critic_net.state_dict().items()}
+    batch, log = ag.sample(20)
+    assert ag._upamd_server_stats['requests'] == 25         # 20 sampling steps + the 5 of the evaluation episode, one serving phase
+    with torch.no_grad():                                   # "update_params": the weights move on
+        for p in ag.actor_critic_net.parameters():
+            p.add_(0.01)
+    ahead = ag.eval_agent(num_samples=1, mean_action=True)  # no second serving phase: the log of the overlapped episode
+    assert ag._upamd_server_stats['requests'] == 25 and ahead.avg_episode_reward == want.avg_episode_reward
+    assert all(torch.equal(ag._upamd_eval_sd[k], v) for k, v in sd0.items())
+    # best.p is written from the EVALUATED weights, the periodic file from the current ones
+    ag.save_best_flag, ag.best_rewards = True, 1.25
+    ag.save_checkpoint(0)
+    best = pickle.load(open(os.path.join(ag.cfg.model_dir, 'best.p'), 'rb'))
+    periodic = pickle.load(open(os.path.join(ag.cfg.model_dir, 'iteration_0001.p'), 'rb'))
+    k = 'actor_net.shared_net.node_encoder.weight'
+    assert torch.equal(best['actor_critic_dict'][k], sd0[k]) and torch.equal(periodic['actor_critic_dict'][k], sd0[k] + 0.01)
+    assert torch.equal(ag.actor_critic_net.state_dict()[k], sd0[k] + 0.01)
+    ag._upamd_release_arenas()
+
+
+@needs_reference
+def test_checkpoints_carry_the_optimizer_state_through_the_real_save_and_load(tmp_path):
+    """``save_checkpoint`` (:172-194) of the bound class adds 'hip_optimizer' to the files the reference's code wrote;
+    a FRESH agent's ``load_checkpoint`` (:153-170, called from __init__ before AgentPPO.__init__ has run) parks it and the
+    updater created later picks it up; an untouched reference agent still loads the same file; a load in the middle of a
+    run leaves Adam alone (the reference keeps its optimizer object across freeze_land_use, :215-222)."""
+    ref = ref_import.load_reference()
+    mod = patched_module(tmp_path)
+    ag, _ = _rollout_agent(tmp_path, cls=mod.UrbanPlanningAgent, ref=ref)
+    up = ag._hip_updater()
+    state = {'group_steps': [7, 7, 0], 'loss_iter': 21, 'clip_pending': False, 'group_seen': [True, True, False],
+             'exp_avg': {'x': torch.arange(3.0)}, 'exp_avg_sq': {'x': torch.ones(3)}}
+    up.m, up.state_dict = object(), lambda: state           # (the real buffers live on a GPU: tests/test_gpu_parity.py)
+    ag.loss_iter = 21
+    ag.save_checkpoint(0)
+    cp = pickle.load(open(os.path.join(ag.cfg.model_dir, 'iteration_0001.p'), 'rb'))
+    assert cp['hip_optimizer']['group_steps'] == [7, 7, 0] and torch.equal(cp['hip_optimizer']['exp_avg']['x'], torch.arange(3.0))
+    fresh, _ = _rollout_agent(tmp_path, cls=mod.UrbanPlanningAgent, ref=ref, seed=9)
+    assert getattr(fresh, '_upamd_updater', None) is None
+    assert fresh.load_checkpoint(1, True) == 1 and fresh.loss_iter == 21
+    assert fresh._upamd_pending_opt['group_steps'] == [7, 7, 0]
+    up2 = fresh._hip_updater()
+    assert up2.pending_state['loss_iter'] == 21 and fresh._upamd_pending_opt is None
+    theirs = build_like_the_reference(ref.UrbanPlanningAgent, ref, reference_cfg(tmp_path))
+    assert theirs.load_checkpoint(1, True) == 1             # the extra key does not disturb the reference's loader
+    up.pending_state = None
+    ag.load_checkpoint(1, True)                             # mid-run (the updater has stepped): Adam is left alone
+    assert up.pending_state is None
