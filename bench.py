@@ -192,9 +192,12 @@ def main():
                          'global minibatch; local: per-rank shards shuffled locally')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--minibatch', type=int, default=0, help='override the per-GPU PPO minibatch of the workload (exploration)')
-    ap.add_argument('--inclusive-unique', action='store_true',
-                    help='time the update_params_inclusive leg on T DISTINCT host states (default: the replay tiles a pool '
-                         'of `unique` states, so the host packer reads a small working set)')
+    ap.add_argument('--inclusive-unique', action='store_true', default=True,
+                    help='(default) time the update_params_inclusive leg on T DISTINCT host states: the host packer reads the '
+                         'full ~150 KB x T working set, as it does behind real rollouts')
+    ap.add_argument('--inclusive-pool', dest='inclusive_unique', action='store_false',
+                    help='update_params_inclusive on the timed region\'s own replay (a tiled pool of `unique` states: the '
+                         'packer re-reads a small host working set -- an upper bound)')
     ap.add_argument('--strong-proxy', default='auto', choices=['auto', 'on', 'off'],
                     help='N = 1: also time the step on 1/8 of the minibatch (the per-GPU share of an 8-GPU strong-scaling run) and '
                          'report strong_proxy = ms(full) / (ms(share) + exposed all-reduce); auto = for the default workload only')
@@ -327,6 +330,12 @@ def main():
     if ctx.world == 1 and want_proxy and w['B'] % 8 == 0:
         engine.profile(False)
         full_B = up.mini_batch_size
+        n_full = max(4, min(args.steps, 12))            # both legs WITHOUT the per-kernel HIP events of the timed region above
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        run(n_full, True)
+        torch.cuda.synchronize(dev)
+        ms_full = 1e3 * (time.perf_counter() - t1) / n_full
         up.mini_batch_size = w['B'] // 8
         run(24, False)
         torch.cuda.synchronize(dev)
@@ -344,8 +353,7 @@ def main():
         ALPHA_US, LINK_GBPS, NR = 2.5, 50.0, 8
         model = lambda nbytes: 1e-3 * (2 * (NR - 1) * ALPHA_US + 2.0 * (NR - 1) / NR * nbytes / (LINK_GBPS * 1e3))
         exposed = model(tail_bytes)
-        ms_full = 1e3 * dt / args.steps
-        proxy = {'ms_full': ms_full, 'rows_full': w['B'], 'ms_share': ms_share, 'rows_share': w['B'] // 8, 'steps_share': n_share,
+        proxy = {'ms_full': ms_full, 'steps_full': n_full, 'rows_full': w['B'], 'ms_share': ms_share, 'rows_share': w['B'] // 8, 'steps_share': n_share,
                  'grad_buckets': [[int(b), int(e)] for b, e in bk], 'exposed_allreduce_bytes': int(tail_bytes),
                  'exposed_allreduce_ms': exposed, 'single_collective_ms': model(4 * (nfl + 4)),
                  'allreduce_source': 'MODEL, not measured (one GPU): 8-rank ring, %.1f us per hop, %.0f GB/s per link direction; '
@@ -401,10 +409,11 @@ def main():
                                     'optimizer_steps': incl['steps'], 'rows_per_step': incl['rows_per_step'],
                                     'replay_states': T, 'unique_host_states': unique_incl,
                                     'host_working_set_bytes': host_bytes, 'prepare_s': incl['prepare'], 'loop_s': incl['loop'],
-                                    'note': 'one update_params(batch) call from host numpy states: pack + H2D + pre-pass + '
-                                            'GAE + all epochs + write-back; with unique_host_states < replay_states the packer '
-                                            're-reads a small host working set, so the figure is an upper bound '
-                                            '(--inclusive-unique times T distinct states)'},
+                                    'fraction_of_step_rate': (incl['steps'] * incl['rows_per_step'] / t_incl) / value,
+                                    'prepare_pipeline_chunks': up.pipeline_chunks,
+                                    'note': 'one update_params(batch) call from host numpy states: pack | H2D | pre-pass (pipelined '
+                                            'over chunks of the replay) + GAE + all epochs + write-back; T distinct host states unless '
+                                            '--inclusive-pool (then the packer re-reads a small working set: an upper bound)'},
         'dp_mode': incl.get('dp_mode'),
     }
     if proxy is not None:

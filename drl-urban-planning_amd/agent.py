@@ -108,6 +108,9 @@ class PPOUpdater:
         # layers below is still running (engine.grad_buckets); False = ONE collective behind the whole backward.  Same bits.
         self.bucketed_allreduce = os.environ.get('UPAMD_GRAD_BUCKETS', '1') != '0'
         self.last_buckets = None              # [(begin, end)] of the last bucketed step (tests, bench.py)
+        # prepare(): the replay is packed / uploaded / swept in about this many chunks (1 = no pipeline)
+        self.pipeline_chunks = int(os.environ.get('UPAMD_PREPARE_CHUNKS', '8'))
+        self._copy_stream = None
         self.pending_state = None             # a checkpoint's optimizer state waiting for the GPU buffers (load_state_dict at the next update_params)
         self._comm = None
 
@@ -206,40 +209,65 @@ class PPOUpdater:
 
     # ------------------------------------------------------------------ iteration set-up
     def prepare(self, batch):
-        """Pack + upload the replay, value / old-log-prob pre-pass (:256-264, :283-292), GAE (:267)."""
+        """Pack + upload the replay, value / old-log-prob pre-pass (:256-264, :283-292), GAE (:267) -- as a three-stage
+        pipeline over chunks of the replay: the host threads pack chunk k + 1 (``PackedReplay.fill``) while chunk k travels
+        to HBM on a copy stream (page-locked source, one contiguous range per section) and the no-grad forward of chunk
+        k - 1 runs on the caller's stream; GAE follows the last chunk.  ``pipeline_chunks = 1`` is the unpipelined form (pack
+        everything, one upload, then the sweep): the same bytes in HBM, the same launches in the same order, so values, log-probs
+        and advantages are bit-identical either way (tests/test_gpu_update_branches.py)."""
         engine, dev = self.engine, self.engine.device
         agent = self.policy_net.agent
         T = len(batch.states)
         if not hasattr(self, '_pack_cache'):
             self._pack_cache = {}
-        packed = packer.pack_replay(batch.states, np.asarray(batch.actions), agent.node_dim,
+        packed = packer.plan_replay(batch.states, np.asarray(batch.actions), agent.node_dim,
                                     agent.numerical_feature_size, n_threads=self.pack_threads,
                                     reuse=self._pack_cache)
-        self._mode = self._resolve_mode(batch, packed)       # (the fingerprint reads the packed host buffer)
-        packed.to(dev)
+        # the small per-row arrays first, through the recycled page-locked ring: a pageable upload later on would make the host
+        # wait for every kernel queued before it
+        exps_np = np.asarray(batch.exps, dtype=np.float32)
+        rewards, _ = packer.upload_pinned(np.asarray(batch.rewards, dtype=np.float32), dev)
+        masks, _ = packer.upload_pinned(np.asarray(batch.masks, dtype=np.float32), dev)
+        exps, _ = packer.upload_pinned(exps_np, dev)
+        if self.dist.active and self.dist.world > 1 and self.dp_mode != 'local':
+            packed.fill(0, T)        # 'auto' / 'global' compare a fingerprint of the PACKED replay across the ranks first
+        self._mode = self._resolve_mode(batch, packed)
         R = self.local_rows()
         self._ensure_rowbufs(R)
-        torch.cuda.current_stream(dev).synchronize()      # the pinned staging buffer may be refilled next iteration
-        rewards = self._to_f32(batch.rewards, dev)
-        masks = self._to_f32(batch.masks, dev)
-        exps_np = np.asarray(batch.exps, dtype=np.float32)
-        exps = torch.from_numpy(exps_np).to(dev)
         shared = self._mode == 'global'
         # 'global': every rank holds all T rows, so the no-grad sweep is shared out chunk by chunk and the two
         # T-float results are summed over the ranks (rows a rank did not compute are zero)
         values = torch.zeros(T, device=dev) if shared else torch.empty(T, device=dev)
         logp = torch.zeros(T, device=dev) if shared else torch.empty(T, device=dev)
         ent = torch.empty(T, device=dev)
-        chunk = R
-        row_lists = [np.arange(i, min(i + chunk, T)) for i in range(0, T, chunk)]
-        sched = packer.Schedule(packed, row_lists, dev)
-        for k, rows in enumerate(row_lists):
-            if shared and k % self.dist.world != self.dist.rank:
-                continue
-            mb, _ = sched.minibatch(k)
-            lo, hi = int(rows[0]), int(rows[-1]) + 1
-            # no backward is pending on slot 0 here: the pre-pass shares the training arena (no second multi-GB slot)
-            engine.forward(packed, mb, self.flat, values[lo:hi], logp[lo:hi], ent[lo:hi], keep=False, slot=0)
+        row_lists = [np.arange(i, min(i + R, T)) for i in range(0, T, R)]
+        sched = packer.Schedule(packed, row_lists, dev)       # (needs the meta table only: known since the plan)
+        # pack-chunks: whole pre-pass minibatches, about `pipeline_chunks` of them over the replay
+        per = max(1, -(-len(row_lists) // max(1, int(self.pipeline_chunks))))
+        main = torch.cuda.current_stream(dev)
+        if self._copy_stream is None or self._copy_stream.device != dev:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        packed.alloc_device(dev)
+        self._copy_stream.wait_stream(main)     # the device buffer may be the previous iteration's: its last readers are on `main`
+        for first in range(0, len(row_lists), per):
+            last = min(first + per, len(row_lists))
+            t0, t1 = int(row_lists[first][0]), int(row_lists[last - 1][-1]) + 1
+            if packed.filled < t1:
+                packed.fill(t0, t1)
+            with torch.cuda.stream(self._copy_stream):
+                packed.upload(t0, t1)
+                landed = torch.cuda.Event()
+                landed.record(self._copy_stream)
+            main.wait_event(landed)
+            for k in range(first, last):
+                if shared and k % self.dist.world != self.dist.rank:
+                    continue
+                rows = row_lists[k]
+                mb, _ = sched.minibatch(k)
+                lo, hi = int(rows[0]), int(rows[-1]) + 1
+                # no backward is pending on slot 0 here: the pre-pass shares the training arena (no second multi-GB slot)
+                engine.forward(packed, mb, self.flat, values[lo:hi], logp[lo:hi], ent[lo:hi], keep=False, slot=0)
+        self._copy_stream.synchronize()           # the pinned staging buffer may be refilled next iteration
         if shared:
             self.dist.all_reduce_sum(values)
             self.dist.all_reduce_sum(logp)

@@ -203,11 +203,17 @@ extern "C" int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *p
 
 extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *meta, const upamd_pack_layout *layout,
                                int32_t n_threads, void *out) {
-    if (T <= 0 || !ptrs || !meta || !layout || !out || layout->T != T)
+    return upamd_pack_fill_range(T, ptrs, meta, layout, 0, T, n_threads, out);
+}
+
+extern "C" int upamd_pack_fill_range(int64_t T, const uint64_t *ptrs, const int32_t *meta, const upamd_pack_layout *layout,
+                                     int64_t t_begin, int64_t t_end, int32_t n_threads, void *out) {
+    if (T <= 0 || !ptrs || !meta || !layout || !out || layout->T != T || t_begin < 0 || t_end > T || t_begin > t_end)
         return upamd::fail(UPAMD_E_INVALID, "upamd_pack_fill: bad argument");
     const upamd_pack_layout &L = *layout;
     char *base = static_cast<char *>(out);
-    std::memcpy(base + L.off_meta, meta, sizeof(int32_t) * UPAMD_META_STRIDE * T);
+    std::memcpy(base + L.off_meta + sizeof(int32_t) * UPAMD_META_STRIDE * t_begin, meta + UPAMD_META_STRIDE * t_begin,
+                sizeof(int32_t) * UPAMD_META_STRIDE * (t_end - t_begin));
     float *X = reinterpret_cast<float *>(base + L.off_x);
     uint8_t *nmask = reinterpret_cast<uint8_t *>(base + L.off_nmask);
     int32_t *rowptr = reinterpret_cast<int32_t *>(base + L.off_rowptr);
@@ -227,7 +233,8 @@ extern "C" int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *m
     float *xbar = reinterpret_cast<float *>(base + L.off_xbar);
     const int F = L.node_dim, Fn = L.numerical_dim;
 
-    int rc = parallel_for(T, n_threads, [&](int64_t t) -> int {
+    int rc = parallel_for(t_end - t_begin, n_threads, [&](int64_t tt) -> int {
+        const int64_t t = t_begin + tt;
         StateView s = view(ptrs, T, t);
         const int32_t *m = meta + t * UPAMD_META_STRIDE;
         const int n = m[0], e = m[1], nh = m[2], nr = m[3], stage = m[4], N = m[7], E = m[8];

@@ -7,6 +7,7 @@ urban_planning/models/state_encoder.py:163-177).  Input format = the wire format
 ``ObservationExtractor.get_obs`` (urban_planning/envs/observation_extractor.py:207-228).
 """
 import ctypes as C
+import threading
 import importlib.util
 import os
 
@@ -22,18 +23,63 @@ M_N, M_E, M_NH, M_NR, M_STAGE, M_ACT, M_NMASK, M_PADN, M_PADE, M_NODE_OFF, M_EDG
 
 
 class PackedReplay:
-    """Host + device form of one PPO iteration's replay."""
+    """Host + device form of one PPO iteration's replay.
 
-    def __init__(self, meta, layout, host_buf):
+    Every section of the packed buffer is state-major (include/upamd.h: upamd_pack_layout), so the states [t0, t1) are ONE
+    contiguous byte range per section: ``fill(t0, t1)`` packs them on the host threads, ``upload(t0, t1)`` moves exactly
+    those ranges to HBM asynchronously.  ``pack_replay`` fills everything at once; the PPO updater streams the replay chunk
+    by chunk (fill k + 1 | H2D k | pre-pass forward k - 1, agent.PPOUpdater.prepare)."""
+
+    def __init__(self, meta, layout, host_buf, ptrs=None, keep=None, n_threads=0):
         self.meta = meta                 # np.int32 [T, 16]
         self.layout = layout             # native.PackLayout
         self.host_buf = host_buf         # torch.uint8 [total_bytes] (pinned when CUDA is available)
         self.dev_buf = None
         self.T = int(meta.shape[0])
+        self._ptrs, self._keep, self._threads = ptrs, keep, n_threads      # alive until the last state has been filled
+        self.filled = 0 if ptrs is not None else self.T
 
     def to(self, device):
         self.dev_buf = self.host_buf.to(device, non_blocking=True)
         return self
+
+    def fill(self, t0, t1):
+        """Pack the states [t0, t1) into the host buffer (host threads; the GIL is released for the duration)."""
+        if self._ptrs is None:
+            raise RuntimeError('this replay is already packed')
+        native.check(native.lib().upamd_pack_fill_range(self.T, self._ptrs.ctypes.data, self.meta.ctypes.data,
+                                                        C.byref(self.layout), int(t0), int(t1), int(self._threads),
+                                                        self.host_buf.data_ptr()), 'upamd_pack_fill_range')
+        self.filled = max(self.filled, int(t1)) if int(t0) <= self.filled else self.filled
+        if self.filled >= self.T:
+            self._ptrs = self._keep = None
+
+    def byte_ranges(self, t0, t1):
+        """[(begin, end)] byte ranges of the packed buffer that hold the states [t0, t1): one per section."""
+        L, m = self.layout, self.meta
+        a, b = m[t0], m[t1 - 1]
+        n0, n1 = int(a[M_NODE_OFF]), int(b[M_NODE_OFF]) + int(b[M_N])
+        e0, e1 = int(a[M_EDGE_OFF]), int(b[M_EDGE_OFF]) + int(b[M_E])
+        h0, h1 = int(a[M_HE_OFF]), int(b[M_HE_OFF]) + int(b[M_NH])
+        r0, r1 = int(a[M_RN_OFF]), int(b[M_RN_OFF]) + int(b[M_NR])
+        p0, p1 = int(a[13]), int(b[13]) + int(b[M_N]) + 1
+        Fn, NP, MS = int(L.numerical_dim), native.NODE_PAD, native.META_STRIDE
+        spec = [(L.off_meta, 4 * MS, t0, t1), (L.off_x, 4 * NP, n0, n1), (L.off_nmask, 1, n0, n1), (L.off_rowptr, 4, p0, p1),
+                (L.off_inc_nbr, 4, e0, e1), (L.off_he_src, 2, h0, h1), (L.off_he_dst, 2, h0, h1), (L.off_he_live, 1, h0, h1),
+                (L.off_he_slot, 4, h0, h1), (L.off_rn_node, 2, r0, r1), (L.off_numerical, 4 * Fn, t0, t1),
+                (L.off_cur, 4 * NP, t0, t1), (L.off_order, 2, n0, n1), (L.off_hinc_ptr, 4, p0, p1), (L.off_hinc_nbr, 4, h0, h1),
+                (L.off_hinc_he, 4, h0, h1), (L.off_he_sel, 2, h0, h1), (L.off_xbar, 4 * NP, t0, t1)]
+        return [(int(off) + w * lo, int(off) + w * hi) for off, w, lo, hi in spec if hi > lo]
+
+    def alloc_device(self, device):
+        if self.dev_buf is None or self.dev_buf.numel() != self.host_buf.numel() or self.dev_buf.device != torch.device(device):
+            self.dev_buf = torch.empty(self.host_buf.numel(), dtype=torch.uint8, device=device)
+        return self.dev_buf
+
+    def upload(self, t0, t1):
+        """Enqueue the H2D copies of the states [t0, t1) on the CURRENT stream (page-locked source: asynchronous)."""
+        for lo, hi in self.byte_ranges(t0, t1):
+            self.dev_buf[lo:hi].copy_(self.host_buf[lo:hi], non_blocking=True)
 
     def section(self, name, dtype, count):
         """numpy view of a section of the host buffer (tests / debugging)."""
@@ -253,6 +299,14 @@ def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     """states: list[T] of list[9] arrays (or tensors); actions: f32[T,2] (padded-slot indices).
     ``reuse``: optional dict owned by the caller; its pinned staging buffer is recycled across iterations
     (pinning ~1 GB per PPO iteration is otherwise a measurable part of the set-up time)."""
+    pk = plan_replay(states, actions, node_dim, numerical_dim, n_threads, pin, reuse)
+    pk.fill(0, pk.T)
+    return pk
+
+
+def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None, reuse=None):
+    """The first half of ``pack_replay``: address tables, the counting pass (``upamd_pack_plan``: meta table + layout) and the
+    host buffer -- NOT yet filled: ``PackedReplay.fill(t0, t1)`` packs a range of states."""
     T = len(states)
     if T == 0:
         raise ValueError('empty replay')
@@ -313,10 +367,8 @@ def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
         if reuse is not None:
             reuse['host'] = host
         host = host[:need]
-    native.check(L.upamd_pack_fill(T, ptrs.ctypes.data, meta.ctypes.data, C.byref(layout), int(n_threads),
-                                   host.data_ptr()), 'upamd_pack_fill')
-    del keep
-    return PackedReplay(meta, layout, host)
+    # (`states` holds the arrays the address table points at; `keep` the converted copies: both stay alive with the plan)
+    return PackedReplay(meta, layout, host, ptrs=ptrs, keep=(keep, states), n_threads=n_threads)
 
 
 class _PinnedRing:
@@ -326,12 +378,20 @@ class _PinnedRing:
 
     def __init__(self, slots=3):
         self.slots, self.bufs, self.events, self.next = slots, {}, {}, {}
+        # one ring per process, several host threads (a rollout.ActionServer thread next to the learner): slot choice, the
+        # wait for the slot's previous copy, the memcpy into it and the recording of the new copy's event are ONE critical
+        # section -- two threads can neither take the same slot nor lap the ring past a buffer whose copy is still in flight
+        self.lock = threading.Lock()
 
     def upload(self, array, device):
         device = torch.device(device)
         t = torch.from_numpy(np.ascontiguousarray(array))
         if device.type != 'cuda':
             return t.to(device), t
+        with self.lock:
+            return self._upload_locked(t, device)
+
+    def _upload_locked(self, t, device):
         key = (device.index, t.dtype)
         k = self.next.get(key, 0)
         self.next[key] = (k + 1) % self.slots
@@ -343,11 +403,11 @@ class _PinnedRing:
             for q in range(self.slots):
                 self.bufs[key + (q,)] = torch.empty(max(int(t.numel() * 1.25), 1024), dtype=t.dtype).pin_memory()
             buf = self.bufs[slot]
-        elif buf.numel() < t.numel():
+        if slot in self.events:
+            self.events[slot].synchronize()       # the slot's previous copy has read its buffer (also before replacing it)
+        if buf.numel() < t.numel():
             buf = torch.empty(int(t.numel() * 1.25), dtype=t.dtype).pin_memory()
             self.bufs[slot] = buf
-        elif slot in self.events:
-            self.events[slot].synchronize()
         host = buf[:t.numel()]
         host.numpy()[...] = t.numpy()             # (a plain memcpy: torch's copy_ is an OpenMP region above 32 K elements)
         dev = host.to(device, non_blocking=True)

@@ -146,6 +146,12 @@ int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const
                     int32_t *meta, upamd_pack_layout *layout);
 int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *meta, const upamd_pack_layout *layout,
                     int32_t n_threads, void *out);
+/* The same for the states [t_begin, t_end) only: every section of the packed buffer is state-major, so a range of states is ONE
+ * contiguous byte range per section -- the host wrapper packs chunk k + 1 while chunk k is on its way to HBM and chunk k - 1 is
+ * in the value / old-log-prob pre-pass (urban_planning_agent.py:256-264, :283-292).  Filling [0, T) range by range gives the bytes
+ * upamd_pack_fill writes. */
+int upamd_pack_fill_range(int64_t T, const uint64_t *ptrs, const int32_t *meta, const upamd_pack_layout *layout,
+                          int64_t t_begin, int64_t t_end, int32_t n_threads, void *out);
 
 /* ------------------------------------------------------------------------------------------
  * Engine: forward / backward of the whole policy+value network over one minibatch of graphs.

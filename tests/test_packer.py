@@ -1,6 +1,7 @@
 """Host packer (csrc/packer.cpp) against the python packer spec (tests/csr_model.pack_state). CPU only."""
 import numpy as np
 import pytest
+import torch
 
 import cases
 import csr_model
@@ -227,3 +228,35 @@ def test_compact_record_straight_from_the_unpadded_arrays():
         packer.compact_from_arrays(s[0], s[1], s[2][:5], s[3], s[6][:5], s[7], s[8], N - 1, E)
     with pytest.raises(ValueError, match='number of edges exceeds'):
         packer.compact_from_arrays(s[0], s[1][:10], s[2], s[3], s[6], s[7][:10], s[8], N, E - 1)
+
+
+def test_range_fill_and_byte_ranges_reproduce_the_whole_pack():
+    """The streamed form of the packer (PPOUpdater.prepare packs / uploads / sweeps the replay chunk by chunk): filling the
+    states range by range gives the sections ``pack_replay`` writes, and the per-section byte ranges of a chunk
+    (``byte_ranges``: what one chunk's H2D copies move) are disjoint and, over all chunks, carry every section entirely."""
+    rep = synth.make_replay(37, 'mixed', max_nodes=120, max_edges=400, seed=12, road_fraction=0.35, n_range=(20, 60))
+    Fn = rep.states[0][0].shape[-1]
+    whole = packer.pack_replay(rep.states, rep.actions, 23, Fn, pin=False)
+    pk = packer.plan_replay(rep.states, rep.actions, 23, Fn, pin=False)
+    assert pk.filled == 0 and np.array_equal(pk.meta, whole.meta)
+    pk.host_buf.zero_()
+    image = np.zeros(pk.host_buf.numel(), dtype=np.uint8)          # what HBM would hold after the chunks' copies
+    cuts = [0, 5, 6, 20, 37]
+    seen = []
+    for t0, t1 in zip(cuts[:-1], cuts[1:]):
+        pk.fill(t0, t1)
+        for lo, hi in pk.byte_ranges(t0, t1):
+            assert all(hi <= a or lo >= b for a, b in seen), 'chunks must not share bytes'
+            seen.append((lo, hi))
+            image[lo:hi] = pk.host_buf.numpy()[lo:hi]
+    assert pk.filled == 37 and pk._ptrs is None
+    with pytest.raises(RuntimeError):
+        pk.fill(0, 1)
+    assert _same_pack(pk, whole, Fn)
+    staged = packer.PackedReplay(pk.meta, pk.layout, torch.from_numpy(image))
+    assert _same_pack(staged, whole, Fn)
+    he_sel = lambda p: p.section('he_sel', np.uint16, int(p.layout.total_he))
+    xbar = lambda p: p.section('xbar', np.float32, 37 * native.NODE_PAD)
+    he_slot = lambda p: p.section('he_slot', np.int32, int(p.layout.total_he))
+    for sec in (he_sel, xbar, he_slot):
+        assert np.array_equal(sec(staged), sec(whole))
