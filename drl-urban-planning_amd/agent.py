@@ -208,21 +208,28 @@ class PPOUpdater:
         return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device)
 
     # ------------------------------------------------------------------ iteration set-up
-    def prepare(self, batch):
+    def prepare(self, batch, exact_plan=False):
         """Pack + upload the replay, value / old-log-prob pre-pass (:256-264, :283-292), GAE (:267) -- as a three-stage
         pipeline over chunks of the replay: the host threads pack chunk k + 1 (``PackedReplay.fill``) while chunk k travels
         to HBM on a copy stream (page-locked source, one contiguous range per section) and the no-grad forward of chunk
         k - 1 runs on the caller's stream; GAE follows the last chunk.  ``pipeline_chunks = 1`` is the unpipelined form (pack
         everything, one upload, then the sweep): the same bytes in HBM, the same launches in the same order, so values, log-probs
         and advantages are bit-identical either way (tests/test_gpu_update_branches.py)."""
+        if not hasattr(self, '_pack_cache'):
+            self._pack_cache = {}
+        try:
+            return self._prepare(batch, exact_plan)
+        except packer.NeedsExactPlan:           # (states no extractor emits: a live edge on a node outside the masks)
+            torch.cuda.synchronize(self.engine.device)
+            return self._prepare(batch, True)
+
+    def _prepare(self, batch, exact_plan):
         engine, dev = self.engine, self.engine.device
         agent = self.policy_net.agent
         T = len(batch.states)
-        if not hasattr(self, '_pack_cache'):
-            self._pack_cache = {}
         packed = packer.plan_replay(batch.states, np.asarray(batch.actions), agent.node_dim,
                                     agent.numerical_feature_size, n_threads=self.pack_threads,
-                                    reuse=self._pack_cache)
+                                    reuse=self._pack_cache, exact=exact_plan)
         # the small per-row arrays first, through the recycled page-locked ring: a pageable upload later on would make the host
         # wait for every kernel queued before it
         exps_np = np.asarray(batch.exps, dtype=np.float32)

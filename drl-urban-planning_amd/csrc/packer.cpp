@@ -16,8 +16,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <pthread.h>
 #include <sched.h>
 #include <thread>
 #include <vector>
@@ -57,11 +62,42 @@ inline int argmax3(const float *s) {
 // Default packer thread count: this process's share of the host -- the CPUs it may run on (affinity mask), divided by
 // the ranks torchrun started on this node (LOCAL_WORLD_SIZE, else WORLD_SIZE), capped at 64 (the fill is memory-bound:
 // more threads than that only contend).  Eight ranks on a 256-CPU host get 32 threads each instead of 8 x 256.
+// CPUs the container may actually burn: the cgroup's CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  A box that
+// shows 128 CPUs but grants 16 cores' worth of time per period throttles a process that runs 64 busy threads: the whole process is
+// frozen for the rest of the period once the quota is spent (profiles/r04_lab_host_stalls.log saw it with OpenMP; the packer's own
+// threads did the same to the packing phase).
+int cgroup_cpu_quota() {
+    auto read2 = [](const char *path, long long *a, long long *b) -> int {
+        FILE *f = fopen(path, "r");
+        if (!f) return 0;
+        char w1[64] = "", w2[64] = "";
+        const int n = fscanf(f, "%63s %63s", w1, w2);
+        fclose(f);
+        if (n >= 1) *a = strcmp(w1, "max") == 0 ? -1 : atoll(w1);
+        if (n >= 2 && b) *b = atoll(w2);
+        return n;
+    };
+    long long quota = -1, period = 100000;
+    if (read2("/sys/fs/cgroup/cpu.max", &quota, &period) >= 1) {
+        if (quota > 0 && period > 0) return (int)std::max<long long>(1, (quota + period - 1) / period);
+        return 0;
+    }
+    long long q1 = -1, p1 = 100000;
+    if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &q1, nullptr) >= 1 && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &p1, nullptr) >= 1 &&
+        q1 > 0 && p1 > 0)
+        return (int)std::max<long long>(1, (q1 + p1 - 1) / p1);
+    return 0;       // no quota
+}
+
 int default_pack_threads() {
+    const char *ev = getenv("UPAMD_PACK_THREADS");
+    if (ev && atoi(ev) > 0) return std::min(256, atoi(ev));
     int cpus = (int)std::max(1u, std::thread::hardware_concurrency());
     cpu_set_t set;
     CPU_ZERO(&set);
     if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) cpus = std::min(cpus, (int)CPU_COUNT(&set));
+    const int quota = cgroup_cpu_quota();
+    if (quota > 0) cpus = std::min(cpus, quota);
     int ranks = 1;
     const char *lw = getenv("LOCAL_WORLD_SIZE");
     if (!lw || !*lw) lw = getenv("WORLD_SIZE");
@@ -69,10 +105,71 @@ int default_pack_threads() {
     return std::max(1, std::min(64, cpus / ranks));
 }
 
+// Persistent worker pool: the streamed pack calls the fill once per chunk of the replay, and spawning 16-64 threads per call cost
+// more than packing a small chunk.  Workers sleep on a condition variable between jobs.  fork(): the child owns none of the
+// threads -- the atfork handler drops the pool object there (leaked on purpose: its threads do not exist in the child) and the
+// next call builds a new one.
+class Pool {
+public:
+    explicit Pool(int n) : stop_(false), gen_(0), pending_(0) {
+        for (int w = 0; w < n; ++w) threads_.emplace_back([this]() { loop(); });
+    }
+    int size() const { return (int)threads_.size(); }
+    // runs job() on `use` workers (<= size()) and returns when all of them are done
+    void run(int use, const std::function<void()> &job) {
+        std::unique_lock<std::mutex> lk(mu_);
+        job_ = &job;
+        want_ = use;
+        pending_ = use;
+        ++gen_;
+        cv_.notify_all();
+        done_.wait(lk, [this]() { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void()> *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&]() { return stop_ || (gen_ != seen && want_ > 0); });
+                if (stop_) return;
+                seen = gen_;
+                --want_;
+                job = job_;
+            }
+            (*job)();
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    bool stop_;
+    uint64_t gen_;
+    int want_ = 0, pending_;
+    const std::function<void()> *job_ = nullptr;
+};
+
+std::mutex g_pool_mu;             // one parallel_for at a time per process (the packer is called from one host thread)
+Pool *g_pool = nullptr;
+bool g_atfork = false;
+void pool_after_fork_child() {
+    g_pool = nullptr;             // (its threads do not exist here)
+    new (&g_pool_mu) std::mutex();
+}
+
+constexpr int64_t GRAIN = 16;     // states a worker takes at a time
+
 template <typename F>
 int parallel_for(int64_t T, int n_threads, F &&fn) {
     if (n_threads <= 0) n_threads = default_pack_threads();
-    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, T / 64));
+    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, T / GRAIN));
     std::atomic<int> status{0};
     if (n_threads <= 1) {
         for (int64_t t = 0; t < T; ++t) {
@@ -82,24 +179,27 @@ int parallel_for(int64_t T, int n_threads, F &&fn) {
         return 0;
     }
     std::atomic<int64_t> next{0};
-    std::vector<std::thread> pool;
-    for (int w = 0; w < n_threads; ++w) {
-        pool.emplace_back([&]() {
-            for (;;) {
-                int64_t t0 = next.fetch_add(64);
-                if (t0 >= T || status.load() != 0) return;
-                int64_t t1 = std::min(T, t0 + 64);
-                for (int64_t t = t0; t < t1; ++t) {
-                    int rc = fn(t);
-                    if (rc != 0) {
-                        status.store(rc);
-                        return;
-                    }
+    const std::function<void()> job = [&]() {
+        for (;;) {
+            int64_t t0 = next.fetch_add(GRAIN);
+            if (t0 >= T || status.load() != 0) return;
+            int64_t t1 = std::min(T, t0 + GRAIN);
+            for (int64_t t = t0; t < t1; ++t) {
+                int rc = fn(t);
+                if (rc != 0) {
+                    status.store(rc);
+                    return;
                 }
             }
-        });
+        }
+    };
+    std::lock_guard<std::mutex> guard(g_pool_mu);
+    if (!g_atfork) {
+        pthread_atfork(nullptr, nullptr, pool_after_fork_child);
+        g_atfork = true;
     }
-    for (auto &th : pool) th.join();
+    if (!g_pool || g_pool->size() < n_threads) g_pool = new Pool(std::max(n_threads, g_pool ? g_pool->size() : 0));      // (an outgrown pool is leaked: rare, small)
+    g_pool->run(n_threads, job);
     return status.load();
 }
 
@@ -110,6 +210,12 @@ inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 extern "C" int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const int32_t *pad_e,
                                const float *actions, int32_t node_dim, int32_t numerical_dim, int32_t n_threads,
                                int32_t *meta, upamd_pack_layout *layout) {
+    return upamd_pack_plan_ex(T, ptrs, pad_n, pad_e, actions, node_dim, numerical_dim, n_threads, 1, meta, layout);
+}
+
+extern "C" int upamd_pack_plan_ex(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const int32_t *pad_e,
+                                  const float *actions, int32_t node_dim, int32_t numerical_dim, int32_t n_threads,
+                                  int32_t exact, int32_t *meta, upamd_pack_layout *layout) {
     if (T <= 0 || !ptrs || !pad_n || !pad_e || !actions || !meta || !layout)
         return upamd::fail(UPAMD_E_INVALID, "upamd_pack_plan: null argument or T <= 0");
     if (node_dim <= 0 || node_dim > UPAMD_NODE_PAD)
@@ -127,14 +233,24 @@ extern "C" int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *p
                 ++n_mask;
             }
         int e = 0, nh = 0, nr = 0;
-        for (int k = 0; k < E; ++k) {
-            if (s.edge_mask[k]) {
-                const int64_t i = s.edge_index[2 * k], j = s.edge_index[2 * k + 1];
-                if (i < 0 || j < 0 || i >= N || j >= N) return -1000;
-                n = std::max(n, (int)std::max(i, j) + 1);
-                ++e;
+        if (exact) {
+            for (int k = 0; k < E; ++k) {
+                if (s.edge_mask[k]) {
+                    const int64_t i = s.edge_index[2 * k], j = s.edge_index[2 * k + 1];
+                    if (i < 0 || j < 0 || i >= N || j >= N) return -1000;
+                    n = std::max(n, (int)std::max(i, j) + 1);
+                    ++e;
+                }
+                if (stage == 0 && s.land_mask[k]) ++nh;
             }
-            if (stage == 0 && s.land_mask[k]) ++nh;
+        } else {
+            // masks only (a 16th of the bytes: the int64 edge list is not touched): the extent of the graph is taken from the node /
+            // road masks, which is what it is for every state the extractor emits (an edge's endpoints are live nodes,
+            // observation_extractor.py:84-132); the fill checks every live endpoint against it and asks for the exact pass if not
+            for (int k = 0; k < E; ++k) {
+                e += s.edge_mask[k] ? 1 : 0;
+                if (stage == 0 && s.land_mask[k]) ++nh;
+            }
         }
         if (stage == 1)
             for (int v = 0; v < N; ++v)
@@ -239,6 +355,13 @@ extern "C" int upamd_pack_fill_range(int64_t T, const uint64_t *ptrs, const int3
         const int32_t *m = meta + t * UPAMD_META_STRIDE;
         const int n = m[0], e = m[1], nh = m[2], nr = m[3], stage = m[4], N = m[7], E = m[8];
         const int64_t o_node = m[9], o_edge = m[10], o_he = m[11], o_rn = m[12], o_rp = m[13];
+        // every live endpoint inside the planned extent?  (always true behind the exact plan; the masks-only plan relies on it --
+        // checked before anything indexes with an endpoint)
+        for (int k = 0; k < E; ++k)
+            if (s.edge_mask[k]) {
+                const int64_t i = s.edge_index[2 * k], j = s.edge_index[2 * k + 1];
+                if (i < 0 || j < 0 || i >= n || j >= n) return -5;
+            }
         // node features + mask
         for (int v = 0; v < n; ++v) {
             float *dst = X + (o_node + v) * UPAMD_NODE_PAD;
@@ -344,6 +467,9 @@ extern "C" int upamd_pack_fill_range(int64_t T, const uint64_t *ptrs, const int3
         for (int c = F; c < UPAMD_NODE_PAD; ++c) cdst[c] = 0.f;
         return 0;
     });
+    if (rc == -5)
+        return upamd::fail(UPAMD_E_REPLAN, "upamd_pack_fill: a live edge touches a node beyond the extent the node / road masks give "
+                                           "(masks-only plan): plan again with exact = 1");
     if (rc != 0) return upamd::fail(UPAMD_E_INVALID, "upamd_pack_fill: meta table inconsistent with the states");
     return UPAMD_OK;
 }

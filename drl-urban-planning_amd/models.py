@@ -274,8 +274,9 @@ class _HipBackend:
             pieces.append(torch.zeros(engine.n_floats - cursor, device=engine.device))
         return torch.cat(pieces)
 
-    def run(self, x, action, private_ws=False):
-        """x: list[B] of list[9] tensors on any device.  Returns (value, logp, ent) f32[B] on the GPU."""
+    def run(self, x, action, private_ws=False, reuse=None):
+        """x: list[B] of list[9] tensors on any device.  Returns (value, logp, ent) f32[B] on the GPU.  ``reuse``: a dict whose
+        page-locked staging buffer is recycled (only for callers that synchronise with the device before their next call)."""
         device = next(self.shared_net.parameters()).device
         engine = self.engine(device)
         states = [s if packer.is_record(s) else
@@ -286,7 +287,7 @@ class _HipBackend:
         else:
             act = action.detach().cpu().numpy().astype(np.float32).reshape(B, 2)
         pk = packer.pack_replay(states, act, self.shared_net.agent.node_dim,
-                                self.shared_net.agent.numerical_feature_size).to(device)
+                                self.shared_net.agent.numerical_feature_size, reuse=reuse).to(device)
         sched = packer.Schedule(pk, [np.arange(B)], device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.named_params().values())
         runner = _Runner(engine, pk, sched, need_grad, private_ws)
@@ -301,7 +302,12 @@ class _HipBackend:
         stage f32[B, 3]) on the networks' device."""
         device = next(self.shared_net.parameters()).device
         with torch.no_grad():
-            _, _, _, runner = self.run(x, None, private_ws=True)
+            # (forward-only and the caller reads the result back before it calls again -- select_action, the action server --
+            # so the pinned staging buffer of the pack can be recycled instead of page-locking a fresh one per call)
+            if not hasattr(self, '_serve_cache'):
+                self._serve_cache = {}
+            torch.cuda.current_stream(device).synchronize()
+            _, _, _, runner = self.run(x, None, private_ws=True, reuse=self._serve_cache)
             pk, mb, meta = runner.packed, runner.mb, runner.packed.meta
             B = mb.B
             stage_id = meta[:B, packer.M_STAGE]

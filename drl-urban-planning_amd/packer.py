@@ -22,6 +22,10 @@ _FIELD_DTYPES = [np.float32, np.float32, np.int64, np.float32, np.bool_, np.bool
 M_N, M_E, M_NH, M_NR, M_STAGE, M_ACT, M_NMASK, M_PADN, M_PADE, M_NODE_OFF, M_EDGE_OFF, M_HE_OFF, M_RN_OFF = range(13)
 
 
+class NeedsExactPlan(RuntimeError):
+    """``fill`` found a live edge beyond the extent a masks-only plan assumed: plan again with ``exact=True``."""
+
+
 class PackedReplay:
     """Host + device form of one PPO iteration's replay.
 
@@ -47,9 +51,11 @@ class PackedReplay:
         """Pack the states [t0, t1) into the host buffer (host threads; the GIL is released for the duration)."""
         if self._ptrs is None:
             raise RuntimeError('this replay is already packed')
-        native.check(native.lib().upamd_pack_fill_range(self.T, self._ptrs.ctypes.data, self.meta.ctypes.data,
-                                                        C.byref(self.layout), int(t0), int(t1), int(self._threads),
-                                                        self.host_buf.data_ptr()), 'upamd_pack_fill_range')
+        rc = native.lib().upamd_pack_fill_range(self.T, self._ptrs.ctypes.data, self.meta.ctypes.data, C.byref(self.layout),
+                                                int(t0), int(t1), int(self._threads), self.host_buf.data_ptr())
+        if rc == native.E_REPLAN:
+            raise NeedsExactPlan(native.lib().upamd_last_error().decode())
+        native.check(rc, 'upamd_pack_fill_range')
         self.filled = max(self.filled, int(t1)) if int(t0) <= self.filled else self.filled
         if self.filled >= self.T:
             self._ptrs = self._keep = None
@@ -299,14 +305,20 @@ def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     """states: list[T] of list[9] arrays (or tensors); actions: f32[T,2] (padded-slot indices).
     ``reuse``: optional dict owned by the caller; its pinned staging buffer is recycled across iterations
     (pinning ~1 GB per PPO iteration is otherwise a measurable part of the set-up time)."""
-    pk = plan_replay(states, actions, node_dim, numerical_dim, n_threads, pin, reuse)
-    pk.fill(0, pk.T)
+    try:
+        pk = plan_replay(states, actions, node_dim, numerical_dim, n_threads, pin, reuse, exact=False)
+        pk.fill(0, pk.T)
+    except NeedsExactPlan:
+        pk = plan_replay(states, actions, node_dim, numerical_dim, n_threads, pin, reuse, exact=True)
+        pk.fill(0, pk.T)
     return pk
 
 
-def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None, reuse=None):
-    """The first half of ``pack_replay``: address tables, the counting pass (``upamd_pack_plan``: meta table + layout) and the
-    host buffer -- NOT yet filled: ``PackedReplay.fill(t0, t1)`` packs a range of states."""
+def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None, reuse=None, exact=True):
+    """The first half of ``pack_replay``: address tables, the counting pass (``upamd_pack_plan_ex``: meta table + layout) and
+    the host buffer -- NOT yet filled: ``PackedReplay.fill(t0, t1)`` packs a range of states.  ``exact=False``: the counting
+    pass reads the masks only and ``fill`` raises ``NeedsExactPlan`` if a live edge lies beyond the extent they give (never
+    for states of the reference's extractor) -- the caller then plans again with ``exact=True``."""
     T = len(states)
     if T == 0:
         raise ValueError('empty replay')
@@ -351,9 +363,9 @@ def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     actions = _as_array(np.asarray(actions).reshape(T, 2), np.float32)
     meta = np.zeros((T, native.META_STRIDE), dtype=np.int32)
     layout = native.PackLayout()
-    native.check(L.upamd_pack_plan(T, ptrs.ctypes.data, pad_n.ctypes.data, pad_e.ctypes.data, actions.ctypes.data,
-                                   int(node_dim), int(numerical_dim), int(n_threads), meta.ctypes.data,
-                                   C.byref(layout)), 'upamd_pack_plan')
+    native.check(L.upamd_pack_plan_ex(T, ptrs.ctypes.data, pad_n.ctypes.data, pad_e.ctypes.data, actions.ctypes.data,
+                                      int(node_dim), int(numerical_dim), int(n_threads), 1 if exact else 0, meta.ctypes.data,
+                                      C.byref(layout)), 'upamd_pack_plan_ex')
     if pin is None:
         pin = torch.cuda.is_available()
     need = int(layout.total_bytes)

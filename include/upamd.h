@@ -41,6 +41,7 @@ extern "C" {
 #define UPAMD_E_HIP (-2)       /* a HIP runtime call failed                            */
 #define UPAMD_E_LIMIT (-3)     /* a size limit of the packed format was exceeded       */
 #define UPAMD_E_WORKSPACE (-4) /* caller's workspace is too small                      */
+#define UPAMD_E_REPLAN (-5)    /* upamd_pack_fill*: the masks-only plan does not hold for these states; plan with exact = 1 */
 
 #define UPAMD_MAX_MLP 4        /* max depth of each small MLP (hidden-size lists)      */
 #define UPAMD_META_STRIDE 16   /* int32 words per state in the meta table              */
@@ -144,6 +145,13 @@ typedef struct upamd_pack_layout {
 int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const int32_t *pad_e,
                     const float *actions, int32_t node_dim, int32_t numerical_dim, int32_t n_threads,
                     int32_t *meta, upamd_pack_layout *layout);
+/* exact = 1: upamd_pack_plan.  exact = 0: the counting pass reads the masks only (not the int64 edge list: a 16th of the host bytes)
+ * and takes every graph's extent n from its node / road masks -- true for every state the extractor emits, whose edges join live
+ * nodes (observation_extractor.py:84-132).  upamd_pack_fill* verifies each live endpoint against that extent and returns
+ * UPAMD_E_REPLAN if one lies beyond it; the caller then plans again with exact = 1 (the host wrapper does). */
+int upamd_pack_plan_ex(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const int32_t *pad_e, const float *actions,
+                       int32_t node_dim, int32_t numerical_dim, int32_t n_threads, int32_t exact, int32_t *meta,
+                       upamd_pack_layout *layout);
 int upamd_pack_fill(int64_t T, const uint64_t *ptrs, const int32_t *meta, const upamd_pack_layout *layout,
                     int32_t n_threads, void *out);
 /* The same for the states [t_begin, t_end) only: every section of the packed buffer is state-major, so a range of states is ONE

@@ -263,8 +263,17 @@ def test_bound_agent_samples_through_the_server_and_updates_on_the_records(tmp_p
     losses = ag._hip_updater().last_losses
     assert losses.shape[0] > 0 and np.isfinite(losses).all()
     # evaluation behind a client == the same greedy episode computed in this process on the GPU modules
+    class _HostActions:                     # (the reference evaluates on CPU modules, :406; here the GPU modules answer in-process)
+        def __init__(self, net):
+            self.net = net
+
+        def select_action(self, x, mean_action):
+            return self.net.select_action(x, mean_action).cpu()
+    real = ag.policy_net
     ag.env.episode = -1
+    ag.policy_net = _HostActions(real)
     want = _ReferenceLikeAgent.eval_agent(ag, 1, True)
+    ag.policy_net = real
     ag.env.episode = -1
     got = ag.eval_agent(num_samples=1, mean_action=True)
     assert got.total_reward == want.total_reward and ag._upamd_server_stats['requests'] == 6

@@ -73,10 +73,11 @@ def _hlg_case(T, seed, road_fraction, D=16, L=2, heads=1, community='hlg'):
     return cfg, sd, rep
 
 
-@pytest.mark.parametrize('community,road_fraction', [('hlg', 0.0), ('dhm', 0.3), ('mixed', 0.5)])
+@pytest.mark.parametrize('community,road_fraction', [('hlg', 0.0), ('dhm', 0.3), ('mixed', 0.5), ('grid', 0.5)])
 def test_reference_dims_on_full_size_graphs_match_the_oracle(community, road_fraction):
     """hlg.yaml / dhm.yaml dims (D = 16, L = 2) on HLG- and DHM-sized graphs (up to 397 nodes / 2216 edges: the largest LDS
-    plan the path takes): rows, loss and every gradient against the oracle's autograd."""
+    plan the path takes) and on BASELINE cfg-1's grid-shaped graphs (grid.yaml:16-33: 120-250 nodes, land-use and road rows
+    mixed): rows, loss and every gradient against the oracle's autograd."""
     T = 12
     cfg, sd, rep = _hlg_case(T, 30, road_fraction, community=community)
     _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, rep.states, rep.actions)

@@ -260,3 +260,36 @@ def test_range_fill_and_byte_ranges_reproduce_the_whole_pack():
     he_slot = lambda p: p.section('he_slot', np.int32, int(p.layout.total_he))
     for sec in (he_sel, xbar, he_slot):
         assert np.array_equal(sec(staged), sec(whole))
+
+
+def test_masks_only_plan_equals_the_exact_plan_and_falls_back_when_it_must():
+    """The counting pass of the streamed pack reads the masks only (``exact=False``: the int64 edge lists are not touched):
+    same meta table, same pack as the exact pass for states whose edges join masked nodes -- every state the extractor emits
+    (observation_extractor.py:84-132) -- and ``fill`` asks for the exact pass (``NeedsExactPlan``; ``pack_replay`` and
+    ``PPOUpdater.prepare`` then re-plan) when a live edge touches a node beyond the extent the masks give."""
+    rep = cases.quirky_replay(12, 30, 70, seed=6, road_fraction=0.4)
+    Fn = rep.states[0][0].shape[-1]
+    exact = packer.plan_replay(rep.states, rep.actions, 23, Fn, pin=False, exact=True)
+    light = packer.plan_replay(rep.states, rep.actions, 23, Fn, pin=False, exact=False)
+    assert np.array_equal(exact.meta, light.meta) and bytes(exact.layout) == bytes(light.layout)
+    exact.fill(0, exact.T)
+    light.fill(0, 5)
+    light.fill(5, light.T)
+    assert _same_pack(exact, light, Fn)
+    # a live edge onto node n (one past the last masked node): only the exact pass sees that the graph has n + 1 nodes
+    states = [[np.array(f, copy=True) for f in s] for s in rep.states]
+    s = states[4]
+    n = int(np.flatnonzero(s[4])[-1]) + 1
+    if int(np.argmax(s[8])) == 1:
+        n = max(n, int(np.flatnonzero(s[7])[-1]) + 1)
+    assert n < s[1].shape[0]
+    k = int(np.flatnonzero(s[5])[0])
+    s[2][k, 1] = n
+    light = packer.plan_replay(states, rep.actions, 23, Fn, pin=False, exact=False)
+    light.fill(0, 4)
+    with pytest.raises(packer.NeedsExactPlan):
+        light.fill(4, 8)
+    want = packer.plan_replay(states, rep.actions, 23, Fn, pin=False, exact=True)
+    want.fill(0, want.T)
+    assert want.meta[4, packer.M_N] == n + 1
+    assert _same_pack(packer.pack_replay(states, rep.actions, 23, Fn, pin=False), want, Fn)
