@@ -643,6 +643,11 @@ extern "C" int upamd_ws_tensor(upamd_engine *eng, const upamd_minibatch *mb, con
     int k = 0;
     const int slot = slot_of_name(eng->d, x, *mb, name, &r, &c, &k);
     if (slot < 0 || pl.off[slot] < 0) return fail(UPAMD_E_INVALID, "unknown workspace tensor '%s'", name);
+    // the fused small-model path keeps every intermediate in LDS: only the pointer-head logits reach the workspace, and a name
+    // that resolves to a slot the general path would have written must not hand back stale memory
+    if (tiny_supported(eng->d, mb->max_n, mb->max_inc, mb->max_cand) && slot != S_Z_HE && slot != S_Z_RN)
+        return fail(UPAMD_E_INVALID, "workspace tensor '%s' is not materialised by the fused small-model path (this minibatch takes "
+                                     "it: only z_he / z_rn are); tune knob tiny_fused = 0 selects the general kernels", name);
     if (byte_offset) *byte_offset = pl.off[slot] * 4;
     if (rows) *rows = r;
     if (cols) *cols = c;

@@ -96,8 +96,12 @@ int default_pack_threads() {
     cpu_set_t set;
     CPU_ZERO(&set);
     if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) cpus = std::min(cpus, (int)CPU_COUNT(&set));
+    // A CPU quota limits CPU-TIME per period, not threads: the packer runs in bursts of 10-40 ms, and measured on a 256-CPU box
+    // with a 16-core quota (profiles/r05_lab_prepare.md) the fill of 8192 HLG states takes 73 / 39 / 21 / 13 ms on 8 / 16 / 32 / 64
+    // threads -- the burst is over before the period's budget is spent.  Only a burst far beyond the budget gets throttled:
+    // cap at four times the quota.
     const int quota = cgroup_cpu_quota();
-    if (quota > 0) cpus = std::min(cpus, quota);
+    if (quota > 0) cpus = std::min(cpus, 4 * quota);
     int ranks = 1;
     const char *lw = getenv("LOCAL_WORLD_SIZE");
     if (!lw || !*lw) lw = getenv("WORLD_SIZE");
@@ -206,6 +210,34 @@ int parallel_for(int64_t T, int n_threads, F &&fn) {
 inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 }  // namespace
+
+// Compact wire records (drl-urban-planning_amd/packer.py: _REC_HEADER / _record_sections) -> the packer's address table, without
+// a Python object per field: header = 10 little-endian 32-bit words (magic 'UPS1', node_dim, numerical_len, cur_len, stage_len,
+// pad_n, pad_e, n_rows, e_rows, edge_fill), then the nine arrays, each 8-byte aligned, trimmed to n_rows / e_rows.
+extern "C" int upamd_record_table(int64_t T, const uint64_t *rec_ptrs, const int64_t *rec_sizes, int32_t node_dim,
+                                  int32_t numerical_dim, uint64_t *ptrs, int32_t *pad_n, int32_t *pad_e) {
+    if (T <= 0 || !rec_ptrs || !rec_sizes || !ptrs || !pad_n || !pad_e) return upamd::fail(UPAMD_E_INVALID, "upamd_record_table: bad argument");
+    auto a8 = [](int64_t x) { return (x + 7) & ~int64_t(7); };
+    for (int64_t t = 0; t < T; ++t) {
+        const uint32_t *h = reinterpret_cast<const uint32_t *>(rec_ptrs[t]);
+        if (!h || rec_sizes[t] < 40 || h[0] != 0x31535055u) return upamd::fail(UPAMD_E_INVALID, "upamd_record_table: state %lld is not a compact record", (long long)t);
+        const int64_t F = h[1], Fn = h[2], cur = h[3], st = h[4], nr = h[7], er = h[8];
+        if (F != node_dim || Fn != numerical_dim || cur != node_dim || st != 3)
+            return upamd::fail(UPAMD_E_INVALID, "upamd_record_table: state %lld has node_dim %lld / numerical %lld / current-node %lld / stage %lld entries, "
+                                                "expected %d / %d / %d / 3", (long long)t, (long long)F, (long long)Fn, (long long)cur, (long long)st, node_dim, numerical_dim, node_dim);
+        const int64_t bytes[9] = {Fn * 4, nr * F * 4, er * 16, cur * 4, nr, er, er, nr, st * 4};
+        int64_t off = a8(40);
+        for (int f = 0; f < 9; ++f) {
+            ptrs[f * T + t] = rec_ptrs[t] + (uint64_t)off;
+            off = a8(off + bytes[f]);
+        }
+        if (off > rec_sizes[t]) return upamd::fail(UPAMD_E_INVALID, "upamd_record_table: state %lld: truncated record (%lld < %lld bytes)", (long long)t, (long long)rec_sizes[t], (long long)off);
+        if (nr > INT32_MAX || er > INT32_MAX) return upamd::fail(UPAMD_E_LIMIT, "upamd_record_table: record too large");
+        pad_n[t] = (int32_t)nr;
+        pad_e[t] = (int32_t)er;
+    }
+    return UPAMD_OK;
+}
 
 extern "C" int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const int32_t *pad_e,
                                const float *actions, int32_t node_dim, int32_t numerical_dim, int32_t n_threads,

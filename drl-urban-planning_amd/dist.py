@@ -77,7 +77,11 @@ class DistContext:
             store, rank, world = next(iter(dist.rendezvous('env://', rank=rank, world_size=world)))
             if backend == 'nccl':
                 assert_one_rank_per_device(exchange_idents(store, rank, world, device_ident(device)), rank)
-            kwargs = {}
+            # ranks > 0 sit inside a collective (broadcast_batch / broadcast_object) for the whole of rank 0's env sampling and
+            # evaluation under UPAMD_DP_SAMPLING=rank0: the process group's default watchdog (10 min under RCCL) would abort a
+            # long sampling phase.  UPAMD_DIST_TIMEOUT_S (default 4 h) bounds a genuinely hung job instead.
+            import datetime
+            kwargs = {'timeout': datetime.timedelta(seconds=float(os.environ.get('UPAMD_DIST_TIMEOUT_S', '14400')))}
             if device is not None and backend == 'nccl':
                 kwargs['device_id'] = device
             dist.init_process_group(backend=backend, store=store, rank=rank, world_size=world, **kwargs)

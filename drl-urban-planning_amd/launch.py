@@ -31,6 +31,11 @@ def visible_devices(environ):
         v = environ.get(key)
         if v is not None and v.strip() != '':
             return [x.strip() for x in v.split(',') if x.strip() != '']
+    # ROCR_VISIBLE_DEVICES (the ROCr-level mask schedulers and cgroup set-ups use) filters FIRST and the HIP-level indices are
+    # relative to what it leaves: with N entries there, this process has HIP devices 0 .. N-1
+    v = environ.get('ROCR_VISIBLE_DEVICES')
+    if v is not None and v.strip() != '':
+        return [str(i) for i, x in enumerate(v.split(',')) if x.strip() != '']
     try:                                            # KFD topology: GPU nodes have a non-zero simd_count
         root = '/sys/class/kfd/kfd/topology/nodes'
         n = 0

@@ -339,7 +339,7 @@ class _HipBackend:
                 out.append(logits)
             stage = np.zeros((B, 3), dtype=np.float32)
             for b, s in enumerate(x):
-                st = packer.expand_state(s)[8] if packer.is_record(s) else s[8]
+                st = packer.record_stage(s) if packer.is_record(s) else s[8]
                 stage[b] = st.detach().cpu().numpy() if isinstance(st, torch.Tensor) else np.asarray(st)
         return out[0], out[1], torch.from_numpy(stage).to(device)
 

@@ -58,6 +58,7 @@ SYMBOLS = {
     'upamd_param_groups': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'upamd_pack_plan': (C.c_int, [C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(PackLayout)]),
     'upamd_pack_fill': (C.c_int, [C.c_int64, _P, _P, C.POINTER(PackLayout), C.c_int32, _P]),
+    'upamd_record_table': (C.c_int, [C.c_int64, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     'upamd_pack_plan_ex': (C.c_int, [C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(PackLayout)]),
     'upamd_pack_fill_range': (C.c_int, [C.c_int64, _P, _P, C.POINTER(PackLayout), C.c_int64, C.c_int64, C.c_int32, _P]),
     'upamd_engine_create': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_P)]),

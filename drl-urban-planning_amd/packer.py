@@ -264,9 +264,28 @@ def record_bytes_bound(pad_n, pad_e, node_dim, numerical_len, stage_len=3):
     return _record_sections(h)[1]
 
 
+class RecordList(list):
+    """A list of compact records that also carries their addresses and byte sizes as arrays (``addr`` uint64[T], ``size``
+    int64[T]): ``plan_replay`` hands those to the C packer instead of touching the T record objects."""
+
+    def __init__(self, records, addr=None, size=None):
+        super().__init__(records)
+        self.addr, self.size = addr, size
+
+
 def is_record(obj):
     return isinstance(obj, np.ndarray) and obj.dtype == np.uint8 and obj.ndim == 1 and obj.size >= _REC_HEADER.itemsize \
         and int(obj[:4].view('<u4')[0]) == _REC_MAGIC
+
+
+def record_stage(record):
+    """The stage one-hot (field 8, f32[stage_len]) of a record, without building views of the other eight fields."""
+    w = record[:_REC_HEADER.itemsize].view('<u4')
+    F, Fn, cur, st, nr, er = int(w[1]), int(w[2]), int(w[3]), int(w[4]), int(w[7]), int(w[8])
+    off = _align8(_REC_HEADER.itemsize)
+    for nbytes in (Fn * 4, nr * F * 4, er * 16, cur * 4, nr, er, er, nr):
+        off = _align8(off + nbytes)
+    return record[off:off + 4 * st].view(np.float32)
 
 
 def record_pads(record):
@@ -322,15 +341,31 @@ def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     T = len(states)
     if T == 0:
         raise ValueError('empty replay')
-    if any(is_record(s) for s in states):           # compact wire records: zero-copy views, trimmed pads
-        states = [expand_state(s) if is_record(s) else s for s in states]
     L = native.lib()
     ptrs = np.empty((9, T), dtype=np.uint64)
     pad_n = np.empty(T, dtype=np.int32)
     pad_e = np.empty(T, dtype=np.int32)
     keep = []
     first_slow = 0
-    helper = _host_helper()
+    # compact wire records: the address table straight from the record headers in C.  A ``RecordList`` (rollout.RecordBatch
+    # over shared-memory arenas) brings every record's address and size as arrays; any other all-record list costs one
+    # address look-up per record here.  (Nine numpy views per record in Python took 90 us a state -- 0.7 s for an 8192-row replay.)
+    addr = getattr(states, 'addr', None)
+    size = getattr(states, 'size', None)
+    if addr is None and all(is_record(s) for s in states):
+        addr = np.fromiter((s.ctypes.data for s in states), dtype=np.uint64, count=T)
+        size = np.fromiter((s.size for s in states), dtype=np.int64, count=T)
+    if addr is not None:
+        addr = np.ascontiguousarray(addr, dtype=np.uint64)
+        size = np.ascontiguousarray(size, dtype=np.int64)
+        if addr.size != T or size.size != T:
+            raise ValueError('RecordList: %d addresses / %d sizes for %d states' % (addr.size, size.size, T))
+        native.check(L.upamd_record_table(T, addr.ctypes.data, size.ctypes.data, int(node_dim), int(numerical_dim),
+                                          ptrs.ctypes.data, pad_n.ctypes.data, pad_e.ctypes.data), 'upamd_record_table')
+        first_slow = T
+    elif any(is_record(s) for s in states):         # records and padded tuples mixed: zero-copy views of the records
+        states = [expand_state(s) if is_record(s) else s for s in states]
+    helper = _host_helper() if addr is None else None
     if helper is not None:
         # fast path: every state whose fields already are C-contiguous arrays of the wire dtypes is handled in C
         try:

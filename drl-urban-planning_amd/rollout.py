@@ -333,6 +333,12 @@ class SharedArena:
         states = [data[int(o):int(o) + int(s)] for o, s in zip(t[:, 0], t[:, 1])]
         return states, t[:, 2:4].astype(np.float32), t[:, 4].copy(), t[:, 5].copy(), t[:, 6].copy()
 
+    def record_addresses(self):
+        """(addresses uint64[n], sizes int64[n]) of the appended records in this process's mapping of the arena"""
+        t = self.table[:len(self)]
+        base = np.frombuffer(self.shm.buf, dtype=np.uint8).ctypes.data + self._data_off
+        return (np.uint64(base) + t[:, 0].astype(np.uint64)), t[:, 1].astype(np.int64)
+
     def close(self, unlink=None):
         self._unpin()
         self.shm.close()
@@ -362,11 +368,14 @@ class RecordBatch:
     worker order: ``states`` hold compact records (views into the arenas), the per-row arrays are stacked."""
 
     def __init__(self, memory_list):
-        states, actions, masks, rewards, exps = [], [], [], [], []
+        states, actions, masks, rewards, exps, addrs, sizes = [], [], [], [], [], [], []
         for m in memory_list:
             arena = getattr(m, 'arena', m if isinstance(m, SharedArena) else None)
             if arena is not None:
                 s, a, mk, rw, ex = arena.rows()
+                ad, sz = arena.record_addresses()
+                addrs.append(ad)
+                sizes.append(sz)
             else:                                    # a khrylib Memory: rows of [state, action, mask, next_state, reward, exp]
                 rows = m.sample()
                 s = [_to_record(r[0]) for r in rows]
@@ -374,12 +383,15 @@ class RecordBatch:
                 mk = np.array([r[2] for r in rows], dtype=np.float64)
                 rw = np.array([r[4] for r in rows], dtype=np.float64)
                 ex = np.array([r[5] for r in rows], dtype=np.float64)
+                addrs.append(np.array([r.ctypes.data for r in s], dtype=np.uint64))
+                sizes.append(np.array([r.size for r in s], dtype=np.int64))
             states += s
             actions.append(a)
             masks.append(mk)
             rewards.append(rw)
             exps.append(ex)
-        self.states = states
+        # (a list of record views that also carries the records' addresses: the packer never touches the T view objects)
+        self.states = packer.RecordList(states, np.concatenate(addrs) if addrs else None, np.concatenate(sizes) if sizes else None)
         self.actions = np.concatenate(actions) if actions else np.zeros((0, 2), np.float32)
         self.masks = np.concatenate(masks) if masks else np.zeros(0)
         self.rewards = np.concatenate(rewards) if rewards else np.zeros(0)

@@ -145,6 +145,12 @@ typedef struct upamd_pack_layout {
 int upamd_pack_plan(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const int32_t *pad_e,
                     const float *actions, int32_t node_dim, int32_t numerical_dim, int32_t n_threads,
                     int32_t *meta, upamd_pack_layout *layout);
+/* States given as COMPACT WIRE RECORDS (the lossless trimmed form of the same nine arrays that the
+ * rollout workers write into shared memory instead of pickling padded tuples through a queue, khrylib/rl/agents/agent.py:92-97):
+ * rec_ptrs[t] / rec_sizes[t] = address and byte size of record t.  Fills the [9][T] field-address table and the per-state
+ * array extents (the record's trimmed row counts) that upamd_pack_plan* / upamd_pack_fill* take -- no per-field host objects. */
+int upamd_record_table(int64_t T, const uint64_t *rec_ptrs, const int64_t *rec_sizes, int32_t node_dim, int32_t numerical_dim,
+                       uint64_t *ptrs, int32_t *pad_n, int32_t *pad_e);
 /* exact = 1: upamd_pack_plan.  exact = 0: the counting pass reads the masks only (not the int64 edge list: a 16th of the host bytes)
  * and takes every graph's extent n from its node / road masks -- true for every state the extractor emits, whose edges join live
  * nodes (observation_extractor.py:84-132).  upamd_pack_fill* verifies each live endpoint against that extent and returns

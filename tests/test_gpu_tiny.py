@@ -237,6 +237,14 @@ def test_action_heads_read_the_fused_forwards_logits():
         elif st == 1:
             assert int(act[b, 1]) == int(road.logits[ir].argmax())
             ir += 1
+    # the fused path materialises nothing else: a stage tensor of the general path must be refused, not read from stale memory
+    _, _, _, eng, flat, pk, sched, mb = _engine_setup(cfg, sd, rep.states, rep.actions)
+    assert eng.step_fused_ok(mb)
+    _forward(eng, pk, mb, flat)
+    assert eng.ws_tensor(mb, 'z_he').numel() + eng.ws_tensor(mb, 'z_rn').numel() > 0
+    for name in ('H1', 'hbarV', 'SV', 'att'):
+        with pytest.raises(RuntimeError, match='fused small-model path'):
+            eng.ws_tensor(mb, name)
 
 
 @pytest.mark.parametrize('gain,bias', [(40.0, 0.0), (1.0, 3.0), (12.0, 0.0)])

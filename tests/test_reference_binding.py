@@ -226,6 +226,11 @@ def test_local_rank_is_mapped_to_one_visible_device():
     assert configure_rank(env) is None
     with pytest.raises(RuntimeError, match='one device per rank'):                           # 2 ranks, 1 GPU, RCCL
         configure_rank({'LOCAL_RANK': '1', 'LOCAL_WORLD_SIZE': '2', 'HIP_VISIBLE_DEVICES': '0'})
+    # a ROCr-level mask (scheduler / cgroup): HIP indices are relative to what it leaves
+    env = {'LOCAL_RANK': '1', 'LOCAL_WORLD_SIZE': '2', 'ROCR_VISIBLE_DEVICES': '4,6'}
+    assert configure_rank(env) == '1' and env['HIP_VISIBLE_DEVICES'] == '1' and env['ROCR_VISIBLE_DEVICES'] == '4,6'
+    with pytest.raises(RuntimeError, match='one device per rank'):
+        configure_rank({'LOCAL_RANK': '2', 'LOCAL_WORLD_SIZE': '3', 'ROCR_VISIBLE_DEVICES': 'GPU-abc,GPU-def'})
     env = {'LOCAL_RANK': '1', 'LOCAL_WORLD_SIZE': '2', 'HIP_VISIBLE_DEVICES': '0', 'UPAMD_DIST_BACKEND': 'gloo'}
     assert configure_rank(env) == '0'                                                        # test ranks may share
 

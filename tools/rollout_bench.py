@@ -53,6 +53,7 @@ def main():
     ap.add_argument('--tuples', action='store_true', help='clients hold padded 9-field tuples (compacted per request) instead of records')
     ap.add_argument('--cpu-procs', type=int, nargs='+', default=[1, 8, 16])
     ap.add_argument('--cpu-requests', type=int, default=40)
+    ap.add_argument('--profile', type=int, default=0, help='cProfile N in-process batched select_action calls of 64 records (stderr)')
     args = ap.parse_args()
     torch.set_num_threads(1)
     from drl_urban_planning_amd import packer, rollout, synth
@@ -85,6 +86,19 @@ def main():
     ac.to('cuda:0')
     with torch.no_grad():
         policy_net.select_action(pool_t[:4], True)              # HIP initialised before the first fork
+    if args.profile:
+        import cProfile, pstats
+        batch = pool_r[:64]
+        for _ in range(5):
+            policy_net.select_action(batch, False)
+        t0 = time.perf_counter()
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(args.profile):
+            policy_net.select_action(batch, False).cpu()
+        pr.disable()
+        out['inprocess_ms_per_64_row_batch'] = 1e3 * (time.perf_counter() - t0) / args.profile
+        pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(28)
     for n in args.clients:
         server = rollout.ActionServer(policy_net, n, slot_bytes=1 << 18, mp_context=ctx)
         q = ctx.Queue()
