@@ -295,6 +295,73 @@ class _HipBackend:
         value, logp, ent = _HipNetwork.apply(flat, runner)
         return value, logp, ent, runner
 
+    def serve_actions(self, x, mean_rows):
+        """``select_action`` (policy.py:67-85) for the batched action server: one no-grad HIP forward for all rows, then per
+        row the arg-max (``mean_rows[b]``) or a ``Categorical.sample`` over its OWN candidates -- the masked slots of the
+        reference's padded logits have probability exactly 0 (pad constant -2^32 + 1), so a Categorical over the candidates
+        alone is the same distribution and the same arg-max (first maximum in slot order).  Returns f32 [B, 2] on the host.
+        Lean on purpose (the server calls it once per serving round): cached flat parameters (re-flattened when a parameter
+        changed), recycled page-locked staging, no autograd graph, no [B, pad] logit tensors."""
+        device = next(self.shared_net.parameters()).device
+        engine = self.engine(device)
+        named = self.named_params()
+        version = tuple(p._version for p in named.values()) + tuple(p.data_ptr() for p in named.values())
+        cache = self.__dict__.setdefault('_serve', {})
+        if cache.get('version') != version or cache.get('device') != device:
+            cache['flat'] = engine.flatten(named, out=cache.get('flat') if cache.get('device') == device else None)
+            cache['version'], cache['device'] = version, device
+        B = len(x)
+        states = [s if packer.is_record(s) else
+                  [f.detach().cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in s] for s in x]
+        torch.cuda.current_stream(device).synchronize()      # (the previous round's copies have left the recycled staging buffer)
+        pk = packer.pack_replay(states, np.zeros((B, 2), dtype=np.float32), self.shared_net.agent.node_dim,
+                                self.shared_net.agent.numerical_feature_size, reuse=cache.setdefault('pack', {})).to(device)
+        sched = packer.Schedule(pk, [np.arange(B)], device)
+        mb, _ = sched.minibatch(0)
+        out = cache.get('rows')
+        if out is None or out.shape[1] < B:
+            out = cache['rows'] = torch.empty(3, max(B, 64), device=device)
+        with torch.no_grad():
+            engine.forward(pk, mb, cache['flat'], out[0, :B], out[1, :B], out[2, :B], keep=False, slot='serve')
+            meta = pk.meta
+            stage = meta[:B, packer.M_STAGE]
+            cnt = np.where(stage == 0, meta[:B, packer.M_NH], np.where(stage == 1, meta[:B, packer.M_NR], 0)).astype(np.int64)
+            action = np.zeros((B, 2), dtype=np.float32)
+            width = int(cnt.max()) if B else 0
+            if width > 0:
+                # candidates of the land-use rows / road rows are consecutive in pack order in z_he / z_rn
+                start = np.zeros(B, dtype=np.int64)
+                for sid, col in ((0, packer.M_NH), (1, packer.M_NR)):
+                    sel = stage == sid
+                    c = np.where(sel, meta[:B, col], 0).astype(np.int64)
+                    start[sel] = (np.cumsum(c) - c)[sel]
+                z_he = engine.ws_tensor(mb, 'z_he', slot='serve').reshape(-1) if int(pk.layout.total_he) else None
+                z_rn = engine.ws_tensor(mb, 'z_rn', slot='serve').reshape(-1) if int(pk.layout.total_rn) else None
+                col = np.arange(width)[None, :]
+                valid = col < cnt[:, None]
+                src = np.where(valid, start[:, None] + col, 0)
+                idx, _ = packer.upload_pinned(np.stack([src, valid.astype(np.int64), (stage == 1).astype(np.int64)[:, None] * np.ones_like(src)]), device)
+                zl = z_he[idx[0].clamp(max=max(z_he.numel() - 1, 0))] if z_he is not None else torch.zeros_like(idx[0], dtype=torch.float32)
+                zr = z_rn[idx[0].clamp(max=max(z_rn.numel() - 1, 0))] if z_rn is not None else torch.zeros_like(idx[0], dtype=torch.float32)
+                dense = torch.where(idx[1].bool(), torch.where(idx[2].bool(), zr, zl), torch.full_like(zl, _PAD_LOGIT))
+                dist = torch.distributions.Categorical(logits=dense)
+                pick = torch.where(torch.from_numpy(np.asarray(mean_rows, dtype=bool)).to(device), dist.probs.argmax(dim=1),
+                                   dist.sample()).cpu().numpy()
+                he_slot = pk.section('he_slot', np.int32, max(int(pk.layout.total_he), 1))
+                rn_node = pk.section('rn_node', np.uint16, max(int(pk.layout.total_rn), 1))
+                for b in range(B):
+                    if stage[b] not in (0, 1):
+                        continue
+                    if cnt[b] == 0:
+                        # no candidate at all: the reference's logits are the pad constant everywhere -- a uniform Categorical over
+                        # the padded slots (arg-max: slot 0)
+                        pad = packer.record_pads(x[b])[1 - int(stage[b])] if packer.is_record(x[b]) else int(meta[b, packer.M_PADE if stage[b] == 0 else packer.M_PADN])
+                        action[b, int(stage[b])] = 0.0 if mean_rows[b] else float(torch.randint(max(pad, 1), (1,)).item())      # (torch's stream, as the reference's sample; never numpy's global one: the update's permutations live there)
+                        continue
+                    k = int(start[b] + min(int(pick[b]), int(cnt[b]) - 1))
+                    action[b, int(stage[b])] = float(he_slot[k] if stage[b] == 0 else rn_node[k])
+        return action
+
     def pointer_logits(self, x):
         """The two pointer heads of a batch as the reference lays them out (policy.py:45-65): logits over the PADDED
         edge / node slots of the rows in that stage, masked slots = the pad constant.  Forward only (the differentiable

@@ -113,6 +113,7 @@ class ActionServer:
         self._server_ends = [p[0] for p in self.pipes]
         self._index_of = {id(c): i for i, c in enumerate(self._server_ends)}
         self.stats = dict(batches=0, requests=0, rows=0, max_rows=0, busy_s=0.0)
+        self.fast = True                # GPU modules: models._HipBackend.serve_actions instead of policy_net.forward + Categorical over pads
         self.last_error = None
         self._thread = None
         self._stop = threading.Event()
@@ -182,6 +183,9 @@ class ActionServer:
 
     def _actions(self, states, mean_rows):
         """One forward for all rows; per row arg-max (mean_action) or a sample (policy.py:67-85)."""
+        backend = getattr(self.policy_net, '_backend', [None])[0]
+        if self.fast and backend is not None and next(self.policy_net.parameters()).device.type == 'cuda':
+            return backend.serve_actions(states, mean_rows)         # the lean HIP route (models._HipBackend.serve_actions)
         with torch.no_grad():
             land_dist, road_dist, stage = self.policy_net.forward(states)
             action = torch.zeros(stage.shape[0], 2, dtype=torch.float32, device=stage.device)
