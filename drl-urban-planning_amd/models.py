@@ -323,43 +323,9 @@ class _HipBackend:
             out = cache['rows'] = torch.empty(3, max(B, 64), device=device)
         with torch.no_grad():
             engine.forward(pk, mb, cache['flat'], out[0, :B], out[1, :B], out[2, :B], keep=False, slot='serve')
-            meta = pk.meta
-            stage = meta[:B, packer.M_STAGE]
-            cnt = np.where(stage == 0, meta[:B, packer.M_NH], np.where(stage == 1, meta[:B, packer.M_NR], 0)).astype(np.int64)
-            action = np.zeros((B, 2), dtype=np.float32)
-            width = int(cnt.max()) if B else 0
-            if width > 0:
-                # candidates of the land-use rows / road rows are consecutive in pack order in z_he / z_rn
-                start = np.zeros(B, dtype=np.int64)
-                for sid, col in ((0, packer.M_NH), (1, packer.M_NR)):
-                    sel = stage == sid
-                    c = np.where(sel, meta[:B, col], 0).astype(np.int64)
-                    start[sel] = (np.cumsum(c) - c)[sel]
-                z_he = engine.ws_tensor(mb, 'z_he', slot='serve').reshape(-1) if int(pk.layout.total_he) else None
-                z_rn = engine.ws_tensor(mb, 'z_rn', slot='serve').reshape(-1) if int(pk.layout.total_rn) else None
-                col = np.arange(width)[None, :]
-                valid = col < cnt[:, None]
-                src = np.where(valid, start[:, None] + col, 0)
-                idx, _ = packer.upload_pinned(np.stack([src, valid.astype(np.int64), (stage == 1).astype(np.int64)[:, None] * np.ones_like(src)]), device)
-                zl = z_he[idx[0].clamp(max=max(z_he.numel() - 1, 0))] if z_he is not None else torch.zeros_like(idx[0], dtype=torch.float32)
-                zr = z_rn[idx[0].clamp(max=max(z_rn.numel() - 1, 0))] if z_rn is not None else torch.zeros_like(idx[0], dtype=torch.float32)
-                dense = torch.where(idx[1].bool(), torch.where(idx[2].bool(), zr, zl), torch.full_like(zl, _PAD_LOGIT))
-                dist = torch.distributions.Categorical(logits=dense)
-                pick = torch.where(torch.from_numpy(np.asarray(mean_rows, dtype=bool)).to(device), dist.probs.argmax(dim=1),
-                                   dist.sample()).cpu().numpy()
-                he_slot = pk.section('he_slot', np.int32, max(int(pk.layout.total_he), 1))
-                rn_node = pk.section('rn_node', np.uint16, max(int(pk.layout.total_rn), 1))
-                for b in range(B):
-                    if stage[b] not in (0, 1):
-                        continue
-                    if cnt[b] == 0:
-                        # no candidate at all: the reference's logits are the pad constant everywhere -- a uniform Categorical over
-                        # the padded slots (arg-max: slot 0)
-                        pad = packer.record_pads(x[b])[1 - int(stage[b])] if packer.is_record(x[b]) else int(meta[b, packer.M_PADE if stage[b] == 0 else packer.M_PADN])
-                        action[b, int(stage[b])] = 0.0 if mean_rows[b] else float(torch.randint(max(pad, 1), (1,)).item())      # (torch's stream, as the reference's sample; never numpy's global one: the update's permutations live there)
-                        continue
-                    k = int(start[b] + min(int(pick[b]), int(cnt[b]) - 1))
-                    action[b, int(stage[b])] = float(he_slot[k] if stage[b] == 0 else rn_node[k])
+            z_he = engine.ws_tensor(mb, 'z_he', slot='serve').reshape(-1) if int(pk.layout.total_he) else None
+            z_rn = engine.ws_tensor(mb, 'z_rn', slot='serve').reshape(-1) if int(pk.layout.total_rn) else None
+            action = ragged_actions(pk, x, z_he, z_rn, mean_rows, device)
         return action
 
     def pointer_logits(self, x):
@@ -409,6 +375,53 @@ class _HipBackend:
                 st = packer.record_stage(s) if packer.is_record(s) else s[8]
                 stage[b] = st.detach().cpu().numpy() if isinstance(st, torch.Tensor) else np.asarray(st)
         return out[0], out[1], torch.from_numpy(stage).to(device)
+
+
+def ragged_actions(pk, x, z_he, z_rn, mean_rows, device):
+    """Per-row action of a packed batch from the RAGGED pointer-head logits (``z_he``: the land-use rows' candidates, ``z_rn``:
+    the road rows', both in pack order): arg-max where ``mean_rows[b]``, else one ``Categorical.sample`` -- over the row's own
+    candidates, padded to the widest row with the reference's pad constant (probability exactly 0, policy.py:50-52), then
+    mapped back to the PADDED edge / node slot the reference's action indexes (policy.py:70-83).  f32 [B, 2] on the host."""
+    meta = pk.meta
+    B = len(x)
+    stage = meta[:B, packer.M_STAGE]
+    cnt = np.where(stage == 0, meta[:B, packer.M_NH], np.where(stage == 1, meta[:B, packer.M_NR], 0)).astype(np.int64)
+    action = np.zeros((B, 2), dtype=np.float32)
+    width = int(cnt.max()) if B else 0
+    pick = np.zeros(B, dtype=np.int64)
+    start = np.zeros(B, dtype=np.int64)
+    if width > 0:
+        # candidates of the land-use rows / road rows are consecutive in pack order in z_he / z_rn
+        for sid, col in ((0, packer.M_NH), (1, packer.M_NR)):
+            sel = stage == sid
+            c = np.where(sel, meta[:B, col], 0).astype(np.int64)
+            start[sel] = (np.cumsum(c) - c)[sel]
+        col = np.arange(width)[None, :]
+        valid = col < cnt[:, None]
+        src = np.where(valid, start[:, None] + col, 0)
+        idx, _ = packer.upload_pinned(np.stack([src, valid.astype(np.int64), np.broadcast_to((stage == 1).astype(np.int64)[:, None], src.shape)]), device)
+        zeros = torch.zeros(src.shape, dtype=torch.float32, device=device)
+        zl = z_he[idx[0].clamp(max=z_he.numel() - 1)] if z_he is not None and z_he.numel() else zeros
+        zr = z_rn[idx[0].clamp(max=z_rn.numel() - 1)] if z_rn is not None and z_rn.numel() else zeros
+        dense = torch.where(idx[1].bool(), torch.where(idx[2].bool(), zr, zl), torch.full_like(zeros, _PAD_LOGIT))
+        dist = torch.distributions.Categorical(logits=dense)
+        greedy = torch.from_numpy(np.ascontiguousarray(mean_rows, dtype=bool)).to(device)
+        pick = torch.where(greedy, dist.probs.argmax(dim=1), dist.sample()).cpu().numpy()
+    he_slot = pk.section('he_slot', np.int32, max(int(pk.layout.total_he), 1))
+    rn_node = pk.section('rn_node', np.uint16, max(int(pk.layout.total_rn), 1))
+    for b in range(B):
+        if stage[b] not in (0, 1):
+            continue
+        if cnt[b] == 0:
+            # no candidate at all: the reference's logits are the pad constant everywhere -- a uniform Categorical over the
+            # padded slots (arg-max: slot 0).  torch's stream, as the reference's sample; never numpy's global one (the
+            # update's permutations live there)
+            pad = packer.record_pads(x[b])[1 - int(stage[b])] if packer.is_record(x[b]) else int(meta[b, packer.M_PADE if stage[b] == 0 else packer.M_PADN])
+            action[b, int(stage[b])] = 0.0 if mean_rows[b] else float(torch.randint(max(pad, 1), (1,)).item())
+            continue
+        k = int(start[b] + min(int(pick[b]), int(cnt[b]) - 1))
+        action[b, int(stage[b])] = float(he_slot[k] if stage[b] == 0 else rn_node[k])
+    return action
 
 
 def _on_gpu(module):

@@ -435,8 +435,10 @@ class _PinnedRing:
         t = torch.from_numpy(np.ascontiguousarray(array))
         if device.type != 'cuda':
             return t.to(device), t
+        shape = t.shape
         with self.lock:
-            return self._upload_locked(t, device)
+            dev, host = self._upload_locked(t.reshape(-1), device)
+        return dev.view(shape), host.view(shape)
 
     def _upload_locked(self, t, device):
         key = (device.index, t.dtype)

@@ -179,3 +179,50 @@ def test_arena_overflow_is_loud():
     with pytest.raises(MemoryError):
         arena.append(rep.states[2], rep.actions[2], 1, 0.0, 1)
     arena.close()
+
+
+def test_ragged_actions_equal_the_padded_categorical_route():
+    """The action server's lean route picks from the RAGGED pointer-head logits (one entry per candidate, pack order); the
+    reference -- and ``policy_net.forward`` -- build a Categorical over the PADDED slots with the pad constant on the masked
+    ones (policy.py:45-65).  Fed with the CPU module's own logits, the ragged route must give the same greedy action for
+    every row (mixed stages, records and tuples mixed, a row without any candidate), and samples inside each row's mask
+    with the right frequencies."""
+    from drl_urban_planning_amd.models import ragged_actions
+    policy_net, value_net, ac = _policy(seed=5)
+    rep = _states(14, 21, road_fraction=0.5)
+    states = [[np.array(f, copy=True) for f in s] for s in rep.states]
+    states[3][6][:] = False                                   # a land-use row without a single candidate
+    states[3][8][:] = (1, 0, 0)
+    x = [packer.compact_state(s) if i % 2 else s for i, s in enumerate(states)]
+    with torch.no_grad():
+        land, road, stage = policy_net.forward([[torch.from_numpy(np.asarray(f)) for f in s] for s in states])
+    pk = packer.pack_replay(x, np.zeros((len(x), 2), np.float32), 23, 52, pin=False)
+    # the ragged logits in pack order, cut out of the padded ones
+    z_he, z_rn, il, ir = [], [], 0, 0
+    want = np.zeros((len(x), 2), dtype=np.float32)
+    for b, s in enumerate(states):
+        st = int(np.argmax(s[8]))
+        if st == 0:
+            z_he.append(land.logits[il][torch.from_numpy(s[6])] + land.logits[il].exp().sum().log() * 0)    # (log-softmaxed: a per-row shift)
+            want[b, 0] = float(land.probs[il].argmax())
+            il += 1
+        elif st == 1:
+            z_rn.append(road.logits[ir][torch.from_numpy(s[7])])
+            want[b, 1] = float(road.probs[ir].argmax())
+            ir += 1
+    z_he, z_rn = torch.cat(z_he), torch.cat(z_rn)
+    got = ragged_actions(pk, x, z_he, z_rn, np.ones(len(x), dtype=bool), 'cpu')
+    assert np.array_equal(got, want), (got, want)
+    # sampling: inside the mask, and the empirical frequencies of one row follow its probabilities
+    torch.manual_seed(0)
+    b = next(i for i, s in enumerate(states) if int(np.argmax(s[8])) == 0 and s[6].sum() >= 3)
+    draws = np.stack([ragged_actions(pk, x, z_he, z_rn, np.zeros(len(x), dtype=bool), 'cpu') for _ in range(400)])
+    for i, s in enumerate(states):
+        st = int(np.argmax(s[8]))
+        if st in (0, 1) and (s[6] if st == 0 else s[7]).any():
+            assert (s[6] if st == 0 else s[7])[draws[:, i, st].astype(int)].all() and not draws[:, i, 1 - st].any()
+    row = sum(1 for s in states[:b] if int(np.argmax(s[8])) == 0)
+    p = land.probs[row].numpy()
+    freq = np.bincount(draws[:, b, 0].astype(int), minlength=p.size) / draws.shape[0]
+    assert np.abs(freq - p).max() < 0.12
+    assert (draws[:, 3, 0] >= 0).all() and len(set(draws[:, 3, 0].tolist())) > 3       # the candidate-less row: uniform over the pads

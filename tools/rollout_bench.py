@@ -104,7 +104,7 @@ def main():
         q = ctx.Queue()
         t0 = time.perf_counter()
         procs = server.launch(_client, [(i, pool, args.requests, q) for i in range(n)], ctx)
-        lats = [q.get(timeout=600)[1] for _ in procs]
+        lats = [q.get(timeout=90)[1] for _ in procs]
         wall = time.perf_counter() - t0
         for p in procs:
             p.join()
