@@ -109,7 +109,9 @@ class PPOUpdater:
         self.bucketed_allreduce = os.environ.get('UPAMD_GRAD_BUCKETS', '1') != '0'
         self.last_buckets = None              # [(begin, end)] of the last bucketed step (tests, bench.py)
         # prepare(): the replay is packed / uploaded / swept in about this many chunks (1 = no pipeline)
-        self.pipeline_chunks = int(os.environ.get('UPAMD_PREPARE_CHUNKS', '8'))
+        # 0 = auto: 8 where the pre-pass is worth hiding (gcn_node_dim > 32), 1 for the small models, whose prepare() is bound by the
+        # host packer alone -- there the per-chunk overhead cost 8 % of the call (profiles/r05_lab_prepare.md)
+        self.pipeline_chunks = int(os.environ.get('UPAMD_PREPARE_CHUNKS', '0'))
         self._copy_stream = None
         self.pending_state = None             # a checkpoint's optimizer state waiting for the GPU buffers (load_state_dict at the next update_params)
         self._comm = None
@@ -250,7 +252,8 @@ class PPOUpdater:
         row_lists = [np.arange(i, min(i + R, T)) for i in range(0, T, R)]
         sched = packer.Schedule(packed, row_lists, dev)       # (needs the meta table only: known since the plan)
         # pack-chunks: whole pre-pass minibatches, about `pipeline_chunks` of them over the replay
-        per = max(1, -(-len(row_lists) // max(1, int(self.pipeline_chunks))))
+        chunks = int(self.pipeline_chunks) or (8 if int(engine.desc.D) > 32 else 1)
+        per = max(1, -(-len(row_lists) // max(1, chunks)))
         main = torch.cuda.current_stream(dev)
         if self._copy_stream is None or self._copy_stream.device != dev:
             self._copy_stream = torch.cuda.Stream(device=dev)
