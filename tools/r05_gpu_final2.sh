@@ -1,6 +1,9 @@
 # round 5, final evidence (2/2): the other BASELINE workloads, the 256-row step, RCCL single rank, 2-rank functional lines
 # (bucketed / single collective), rollout serving
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r05y; mkdir -p $O
+for i in 1 2 3; do timeout 200 python -m pytest tests/test_gpu_rollout.py -m gpu -q -x > $O/rollout_tests_$i.log 2>&1; tail -2 $O/rollout_tests_$i.log; done
+grep -h -B30 "^E " $O/rollout_tests_*.log | head -80
+(timeout 300 python -m pytest tests/test_gpu_rollout.py tests/test_gpu_tiny.py tests/test_gpu_mlp.py -m gpu -q 2>&1 | tail -30) > $O/rollout_after_tiny.log 2>&1; tail -3 $O/rollout_after_tiny.log
 for w in hlg_concept_d256 dhm_d256 mixed_d256; do
   timeout 300 python bench.py --workload $w --cpu-baseline off --steps 8 --warmup 3 --inclusive-pool > $O/bench_$w.json 2>/dev/null
 done
