@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libupamd.so')
+# (UPAMD_LIB_PATH: kernel-lab A/B runs load another build of the same ABI, e.g. tools/lab/libupamd_base.so)
+LIB_PATH = os.environ.get('UPAMD_LIB_PATH') or os.path.join(CSRC, 'libupamd.so')
 ABI_VERSION = 6
 MAX_MLP = 4
 MAX_EDGE_FC = 4
