@@ -375,7 +375,9 @@ def main():
     # the single upload, value / old-log-prob pre-pass, GAE, every optimizer step of every epoch, write-back
     ctx.barrier()
     replay_incl, unique_incl = replay, min(w['unique'], T)
-    if args.inclusive_unique:       # T distinct host states: the packer's host working set is the full ~150 KB x T
+    if args.inclusive_unique and ctx.world == 1:       # T distinct host states: the packer's host working set is the full ~150 KB x T
+        # (one rank only: N ranks of one host would each generate and hold T x 150 KB -- 39 GB at 8 ranks -- for a leg that is a
+        # single-GPU figure; multi-rank lines time it on the tiled pool)
         replay_incl = synth.make_replay(T, w['community'], max_nodes=w['max_nodes'], max_edges=w['max_edges'],
                                         seed=seed_replay + 50, unique=None, road_fraction=w.get('road_fraction', 0.0))
         unique_incl = T

@@ -106,7 +106,10 @@ class PPOUpdater:
         self.collective_events = None         # a list: record a HIP-event pair around every step's gradient all-reduce (bench.py)
         # data parallelism: all-reduce the gradient buffer bucket by bucket on a communication stream while the backward of the
         # layers below is still running (engine.grad_buckets); False = ONE collective behind the whole backward.  Same bits.
+        # (UPAMD_GRAD_BUCKETS: 1 default | 0 single collective | force = also with ONE rank in an initialised process group, which is
+        # how the RCCL route -- async work objects on the process group's own stream -- is exercised on a one-GPU box)
         self.bucketed_allreduce = os.environ.get('UPAMD_GRAD_BUCKETS', '1') != '0'
+        self._buckets_forced = os.environ.get('UPAMD_GRAD_BUCKETS') == 'force'
         self.last_buckets = None              # [(begin, end)] of the last bucketed step (tests, bench.py)
         # prepare(): the replay is packed / uploaded / swept in about this many chunks (1 = no pipeline)
         # 0 = auto: 8 where the pre-pass is worth hiding (gcn_node_dim > 32), 1 for the small models, whose prepare() is bound by the
@@ -379,7 +382,8 @@ class PPOUpdater:
         + node encoder and the first GCN layer, final with the backward's last launch -- is exposed.  The ranges are disjoint
         and a sum over ranks is element-wise: bucketed and single-collective steps give the same bits."""
         d, nflt = self.dist, self.engine.n_floats
-        ranges = self.engine.grad_buckets() if (buckets and self.bucketed_allreduce and d.active and d.world > 1) else []
+        ranges = self.engine.grad_buckets() if (buckets and self.bucketed_allreduce and d.active
+                                                and (d.world > 1 or self._buckets_forced)) else []
         if len(ranges) <= 1:
             self.last_buckets = None
             d.all_reduce_sum(self.grads)                  # ONE collective per optimizer step (no-op for one rank)
