@@ -308,6 +308,7 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     run(args.steps, True)
+    t_enqueued = time.perf_counter() - t0            # the host has handed every launch of the timed steps to the runtime
     torch.cuda.synchronize(dev)
     ctx.barrier()
     dt = time.perf_counter() - t0
@@ -360,7 +361,13 @@ def main():
                                      'bucketed form = only the range that is final with the last launch of the backward is exposed'
                                      % (ALPHA_US, LINK_GBPS),
                  'value': ms_full / (ms_share + exposed), 'value_without_collective': ms_full / ms_share,
-                 'value_single_collective': ms_full / (ms_share + model(4 * (nfl + 4))), 'ideal': 8.0}
+                 'value_single_collective': ms_full / (ms_share + model(4 * (nfl + 4))), 'ideal': 8.0,
+                 # what the data-parallel route itself adds to a 256-row step under a real RCCL process group, measured with ONE
+                 # rank (nothing on the wire): lab constants of round 5, not measured by this run
+                 'rccl_route_overhead_ms': {'single_collective': 0.035, 'bucketed': 0.115,
+                                            'source': 'profiles/r05_lab_bucket_overhead.md (one-rank RCCL group, round 5)'},
+                 'value_with_route_overhead': ms_full / (ms_share + 0.115 + exposed),
+                 'value_single_collective_with_route_overhead': ms_full / (ms_share + 0.035 + model(4 * (nfl + 4)))}
 
     kern = {}
     if not args.no_kernel_events:
@@ -430,6 +437,7 @@ def main():
                    'global_batch': w['B'] * ctx.world, 'parallelism': 'dp%d' % ctx.world,
                    'node_steps_per_s': value * nodes_per_sample},
         'setup_s': {'generate': t_gen, 'pack_upload_prepass_gae': t_prep},
+        'host_enqueue_ms_per_step': 1e3 * t_enqueued / args.steps,      # (close to ms_per_step = the host is the bound, not the GPU)
         'update_params_inclusive': {'samples_per_s': incl['steps'] * incl['rows_per_step'] / t_incl, 'seconds': t_incl,
                                     'optimizer_steps': incl['steps'], 'rows_per_step': incl['rows_per_step'],
                                     'replay_states': T, 'unique_host_states': unique_incl,

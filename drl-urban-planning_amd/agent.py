@@ -390,11 +390,30 @@ class PPOUpdater:
             return
         dev = self.engine.device
         if self._comm is None or self._comm.device != dev:
-            self._comm = torch.cuda.Stream(device=dev, priority=-1)
+            # NORMAL priority: the engine's side streams are high-priority, and a high-priority communication stream (which only ever
+            # holds event waits) shared their hardware queue -- its waits then stood in front of side-stream kernels: +0.16 ms per
+            # 256-row step under a one-rank RCCL group against +0.07 at normal priority (profiles/r05_lab_bucket_overhead.md)
+            self._comm = torch.cuda.Stream(device=dev, priority=int(os.environ.get('UPAMD_COMM_PRIORITY', '0')))
         ranges = [(b, e + 4 if e == nflt else e) for b, e in ranges]      # the 4 loss scalars ride behind the last parameter
         works = []
+        lab = os.environ.get('UPAMD_BUCKET_LAB', '')        # lab only: 'late' = the same collectives, all behind the backward;
+        if lab == 'two':                                    # 'two' = the first range early, everything else as one late collective
+            lo = min(b for b, e in ranges[1:])
+            hi = max(e for b, e in ranges[1:])
+            self.engine.grad_bucket_wait(0, self._comm)
+            with torch.cuda.stream(self._comm):
+                works.append(d.all_reduce_sum_async(self.grads[ranges[0][0]:ranges[0][1]]))
+            self.engine.grad_bucket_wait(len(ranges) - 1, self._comm)
+            with torch.cuda.stream(self._comm):
+                works.append(d.all_reduce_sum_async(self.grads[lo:hi]))
+            ranges = []
         for j, (b, e) in enumerate(ranges):
-            self.engine.grad_bucket_wait(j, self._comm)
+            if j == len(ranges) - 1 and lab != 'late' and os.environ.get('UPAMD_BUCKET_TAIL', 'main') == 'main':
+                # the last range becomes final with the backward's last launch on the CALLER's stream: issue its collective from
+                # there (one stream hand-over less than through the communication stream)
+                works.append(d.all_reduce_sum_async(self.grads[b:e]))
+                continue
+            self.engine.grad_bucket_wait(len(ranges) - 1 if lab == 'late' else j, self._comm)
             with torch.cuda.stream(self._comm):
                 works.append(d.all_reduce_sum_async(self.grads[b:e]))
         for w in works:
