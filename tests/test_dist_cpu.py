@@ -178,3 +178,40 @@ def test_auto_mode_fingerprint_tells_replays_with_equal_scalars_apart():
     assert fp(a.states, a.actions) == fp(a.states, a.actions)
     records = [packer.compact_state(s) for s in a.states]
     assert fp(records, a.actions) == fp(a.states, a.actions)
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    """The host side of the bucketed all-reduce on CPU tensors: ranges reduced one by one through ``all_reduce_sum_async``
+    equal ONE collective over the whole buffer bit for bit; the iteration's permutations travel in one 2-D broadcast."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from drl_urban_planning_amd.dist import DistContext
+    ctx = DistContext.from_env(backend='gloo')
+    g = torch.Generator().manual_seed(100 + rank)
+    n = 10_000
+    grads = torch.randn(n + 4, generator=g)
+    whole = grads.clone()
+    ctx.all_reduce_sum(whole)
+    ranges = [(7000, n + 4), (4000, 7000), (1500, 4000), (0, 1500)]          # readiness order: back to front, as the engine reports them
+    works = [ctx.all_reduce_sum_async(grads[b:e]) for b, e in ranges]
+    for w in works:
+        w.wait()
+    assert torch.equal(grads, whole)
+    assert ctx.all_reduce_sum_async(torch.ones(3)).wait() is not None
+    # rank 0's permutations for the whole iteration in ONE broadcast (agent.PPOUpdater.draw_permutations)
+    np.random.seed(5 + rank)                                                  # the ranks' own streams differ on purpose
+    perms = np.stack([np.random.permutation(50) for _ in range(3)])
+    got = ctx.broadcast_array(perms)
+    np.random.seed(5)
+    want = np.stack([np.random.permutation(50) for _ in range(3)])
+    assert got.shape == (3, 50) and np.array_equal(got, want)
+    ctx.barrier()
+    if rank == 1:
+        open(os.path.join(out_dir, 'ok'), 'w').close()
+    ctx.close()
+
+
+def test_bucketed_ranges_equal_one_collective_and_permutations_travel_once(tmp_path):
+    port = _free_port()
+    mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(str(tmp_path / 'ok'))

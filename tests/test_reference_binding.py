@@ -536,3 +536,28 @@ def test_checkpoints_carry_the_optimizer_state_through_the_real_save_and_load(tm
     up.pending_state = None
     ag.load_checkpoint(1, True)                             # mid-run (the updater has stepped): Adam is left alone
     assert up.pending_state is None
+
+
+@needs_reference
+def test_server_rollout_reports_a_failing_worker_instead_of_hanging(tmp_path, monkeypatch):
+    """An env worker that raises (here: the env's ``step`` in worker 1) must surface in the learner as a RuntimeError carrying the
+    worker's traceback within seconds -- not as a queue wait without end -- and leave the agent usable for the next ``sample()``."""
+    ag, ref = _rollout_agent(tmp_path)
+    monkeypatch.setenv('UPAMD_ROLLOUT', 'server')
+    good_step = ag.env.step
+    calls = {'n': 0}
+
+    def step(action, logger=None):
+        calls['n'] += 1
+        if os.getpid() != learner and calls['n'] == 3 and int(os.environ.get('UPAMD_TEST_FAIL', '0')):
+            raise ValueError('geometry blew up in the worker')
+        return good_step(action, logger)
+    learner = os.getpid()
+    ag.env.step = step
+    monkeypatch.setenv('UPAMD_TEST_FAIL', '1')
+    with pytest.raises(RuntimeError, match='geometry blew up in the worker'):
+        ag.sample(20)
+    monkeypatch.setenv('UPAMD_TEST_FAIL', '0')
+    batch, log = ag.sample(20)
+    assert len(batch) == 20 and log.num_episodes == 4
+    ag._upamd_release_arenas()
