@@ -43,6 +43,11 @@ struct upamd_engine {
     // the engine on two streams (an action server next to the learner) do not queue their
     // side chains behind each other.  The engine's entry points are not re-entrant: the host wrapper serialises them.
     std::unordered_map<hipStream_t, SideCtx> sides;
+    // workspaces whose LAST forward ran the general kernels (i.e. hold the activations the general backward reads).  The fused
+    // small-model forward writes none of them: a backward that takes the general path behind it (tune knob tiny_fused flipped in
+    // between) would differentiate through stale memory -- refused instead.  (The fused backward recomputes its forward: any order is fine.)
+    std::unordered_map<const void *, int> general_fwd;
+    bool general_fwd_complete = true;      // false once the table had to be dropped: a missing entry then proves nothing
 };
 
 namespace {
@@ -677,7 +682,14 @@ extern "C" int upamd_forward(upamd_engine *eng, const void *packed_dev, const up
     auto PR = [&](int idx) { return prm + P.off(idx); };
     Profiler *prof = &eng->prof;
     // fused small-model path (tiny.hip): the whole forward of a graph in one workgroup, one launch for the minibatch
-    if (tiny_supported(d, mbp->max_n, mbp->max_inc, mbp->max_cand)) {
+    const bool fused_fwd = tiny_supported(d, mbp->max_n, mbp->max_inc, mbp->max_cand);
+    if (fused_fwd) {
+        eng->general_fwd.erase(ws_dev);
+    } else {
+        if (eng->general_fwd.size() > 65536) { eng->general_fwd.clear(); eng->general_fwd_complete = false; }
+        eng->general_fwd[ws_dev] = 1;
+    }
+    if (fused_fwd) {
         TinyIO io;
         memset(&io, 0, sizeof(io));
         io.mode = 0;
@@ -952,6 +964,11 @@ static int backward_impl(upamd_engine *eng, const void *packed_dev, const upamd_
     auto PR = [&](int idx) { return prm + P.off(idx); };
     auto GR = [&](int idx) { return grads + P.off(idx); };
     Profiler *prof = &eng->prof;
+    if (!tiny_supported(d, mbp->max_n, mbp->max_inc, mbp->max_cand) && eng->general_fwd_complete &&
+        eng->general_fwd.find(ws_dev) == eng->general_fwd.end())
+        return fail(UPAMD_E_INVALID, "upamd_backward: the last forward on this workspace did not run the general kernels (no forward at all, or "
+                                     "the fused small-model path -- was tune knob tiny_fused changed between forward and backward?): the "
+                                     "activations this backward reads were never written");
     if (tiny_supported(d, mbp->max_n, mbp->max_inc, mbp->max_cand)) {
         // fused small-model path: forward recomputed inside the kernel, backward from the given seeds, slabs -> grads (added)
         TinyIO io;

@@ -212,6 +212,18 @@ def test_other_model_shapes_fused_and_general_agree(D, L, heads, S, value_head, 
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-4, atol=1e-5)
     scale = float(b[3].abs().max())
     assert float((a[3] - b[3]).abs().max()) <= 2e-5 * scale
+    # a forward on the fused path followed by a GENERAL backward (the knob flipped in between): the general backward would read
+    # activations nobody wrote -- refused; the other order is fine (the fused backward recomputes its forward)
+    _forward(eng, pk, mb, flat)
+    tune('tiny_fused', 0)
+    with pytest.raises(RuntimeError, match='did not run the general kernels'):
+        eng.backward(pk, mb, flat, seeds[0], seeds[1], seeds[2], torch.zeros(eng.n_floats, device=DEV))
+    _forward(eng, pk, mb, flat)
+    tune('tiny_fused', 1)
+    g2 = torch.zeros(eng.n_floats, device=DEV)
+    eng.backward(pk, mb, flat, seeds[0], seeds[1], seeds[2], g2)
+    torch.cuda.synchronize()
+    assert torch.equal(g2, a[3])
 
 
 def test_action_heads_read_the_fused_forwards_logits():
