@@ -1,6 +1,6 @@
 # round 5, final evidence (1/2) on the frozen csrc/: GPU suite + smoke, the driver-style default line, kernel traces, PMC passes
 # (stamped with the csrc hash)
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r05z; mkdir -p $O
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r05w; mkdir -p $O
 (timeout 900 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -16) > $O/gpu_tests.log 2>&1
 timeout 120 python __graft_entry__.py smoke > $O/smoke.log 2>&1
 timeout 420 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
