@@ -278,7 +278,7 @@ def main():
     if tune:
         from drl_urban_planning_amd import native
         for knob, value in tune.items():
-            native.check(native.lib().upamd_tune(knob.encode(), int(value)), 'upamd_tune')
+            native.tune(knob, int(value))
     t_prep = time.time()
     it = up.prepare(replay)
     torch.cuda.synchronize(dev)

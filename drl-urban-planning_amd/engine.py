@@ -41,9 +41,22 @@ class NativeEngine:
         # workspace read-backs, the profiler).  Only the ENQUEUE is under it; the kernels of two callers still overlap
         # on their streams.
         self.lock = threading.RLock()
+        # this engine's own kernel-lab knobs (`set_tune`): applied around every native call of THIS engine, the process defaults
+        # restored behind it (native.tuned) -- two engines in one process no longer share a setting one of them changed for itself
+        self.tune_overrides = {}
 
     def _st(self):
         return _stream(self.device)
+
+    def set_tune(self, name, value):
+        """Kernel-lab knob `name` for THIS engine only (None: back to the process default).  Names: include/upamd.h, upamd_tune."""
+        if name not in native.TUNE_DEFAULTS:
+            raise KeyError('unknown kernel-lab knob %r' % (name,))
+        with self.lock:
+            if value is None:
+                self.tune_overrides.pop(name, None)
+            else:
+                self.tune_overrides[name] = int(value)
 
     def _on_device(self):
         """Native launches go to the device that is current in the calling thread (the library never calls
@@ -119,7 +132,7 @@ class NativeEngine:
         """slot=None: slot 0 for a forward whose activations are kept, the scratch slot 'nograd' for a no-grad one, so
         that a stray no-grad forward never overwrites activations a backward on slot 0 still needs.  A caller that
         knows no backward is pending (the PPO pre-pass) names slot 0 itself and spares the second arena."""
-        with self.lock:
+        with self.lock, native.tuned(self.tune_overrides):
             if ws is None:
                 if slot is None:
                     slot = 0 if keep else 'nograd'
@@ -133,11 +146,11 @@ class NativeEngine:
 
     def release_slot(self, slot):
         """Give a slot's workspace back to the caching allocator (stream-ordered)."""
-        with self.lock:
+        with self.lock, native.tuned(self.tune_overrides):
             self.ws_slots.pop(slot, None)
 
     def backward(self, packed, mb, flat_params, dvalue, dlogp, dent, grads, slot=0, ws=None):
-        with self.lock, self._on_device():
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
             wsp, wsb, _ = self._ws_args(slot, ws)
             native.check(self.lib.upamd_backward(self.handle, _ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
                                                  _ptr(flat_params), wsp, wsb, _ptr(dvalue), _ptr(dlogp), _ptr(dent),
@@ -149,13 +162,13 @@ class NativeEngine:
         made them final (one range for the paths that finalise everything at the end)."""
         n = C.c_int32()
         b, e = (C.c_int64 * 24)(), (C.c_int64 * 24)()
-        with self.lock, self._on_device():
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
             native.check(self.lib.upamd_grad_buckets(self.handle, self._st(), 24, C.byref(n), b, e), 'upamd_grad_buckets')
         return [(int(b[i]), int(e[i])) for i in range(n.value)]
 
     def grad_bucket_wait(self, k, waiter):
         """`waiter` (a torch.cuda.Stream) waits until bucket k of the last backward on the current stream is final"""
-        with self.lock, self._on_device():
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
             native.check(self.lib.upamd_grad_bucket_wait(self.handle, self._st(), int(k), C.c_void_p(waiter.cuda_stream)),
                          'upamd_grad_bucket_wait')
 
@@ -169,7 +182,7 @@ class NativeEngine:
                    logp, ent, grads, losses, slot=0):
         """forward + loss seeds + backward; `grads` (flat, n_floats) is overwritten, `losses` (4) gets the loss scalars"""
         assert rows is None or (rows.dtype == torch.int64 and rows.is_contiguous())
-        with self.lock:
+        with self.lock, native.tuned(self.tune_overrides):
             self.ensure_workspace(mb, slot)
             wsp, wsb, _ = self._ws_args(slot, None)
             with self._on_device():
@@ -182,7 +195,7 @@ class NativeEngine:
     def ws_tensor(self, mb, name, slot=0, ws=None):
         """Row-major copy of a named intermediate of the last forward on that workspace (parity tests, action heads)."""
         off, rows, cols, kind = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
-        with self.lock:
+        with self.lock, native.tuned(self.tune_overrides):
             native.check(self.lib.upamd_ws_tensor(self.handle, C.byref(mb), name.encode(), C.byref(off), C.byref(rows),
                                                   C.byref(cols), C.byref(kind)), 'upamd_ws_tensor')
             _, _, shift = self._ws_args(slot, ws)
@@ -196,7 +209,7 @@ class NativeEngine:
     # ---- PPO math
     def ppo_loss(self, B, value, logp, ent, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind, dvalue,
                  dlogp, dent, losses):
-        with self.lock, self._on_device():
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
             native.check(self.lib.upamd_ppo_loss(B, _ptr(value), _ptr(logp), _ptr(ent), _ptr(adv), _ptr(ret),
                                                  _ptr(old_logp), _ptr(exps), clip_eps, cv, ce, inv_rows, inv_ind,
                                                  _ptr(dvalue), _ptr(dlogp), _ptr(dent), _ptr(losses), self._st()),
@@ -206,7 +219,7 @@ class NativeEngine:
                       dvalue, dlogp, dent, losses, zero=None):
         """loss of the minibatch whose replay rows are `rows` (int64, device) + zeroing of `zero` in the same launch"""
         assert rows.dtype == torch.int64 and rows.is_contiguous()
-        with self.lock, self._on_device():
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
             native.check(self.lib.upamd_ppo_loss_rows(B, _ptr(value), _ptr(logp), _ptr(ent), _ptr(rows), _ptr(adv),
                                                       _ptr(ret), _ptr(old_logp), _ptr(exps), clip_eps, cv, ce, inv_rows,
                                                       inv_ind, _ptr(dvalue), _ptr(dlogp), _ptr(dent), _ptr(losses),
@@ -215,18 +228,18 @@ class NativeEngine:
                          'upamd_ppo_loss_rows')
 
     def gae(self, rewards, masks, values, gamma, tau, adv, ret):
-        with self.lock, self._on_device():
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
             native.check(self.lib.upamd_gae(rewards.numel(), _ptr(rewards), _ptr(masks), _ptr(values), float(gamma),
                                             float(tau), _ptr(adv), _ptr(ret), self._st()), 'upamd_gae')
 
     def clip_first_step(self, grads, max_norm, scratch):
-        with self.lock, self._on_device():
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
             native.check(self.lib.upamd_clip_first_step(C.byref(self.desc), _ptr(grads), float(max_norm), _ptr(scratch),
                                                         self._st()), 'upamd_clip_first_step')
 
     def adam_step(self, group, params, grads, m, v, step, lr, beta1, beta2, eps, weight_decay):
         b, e = self.groups[group]
-        with self.lock, self._on_device():
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
             native.check(self.lib.upamd_adam_step(b, e, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), int(step),
                                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                                   self._st()), 'upamd_adam_step')
@@ -237,7 +250,7 @@ class NativeEngine:
         b = (C.c_int64 * n)(*[g[0] for g in self.groups])
         e = (C.c_int64 * n)(*[g[1] for g in self.groups])
         st = (C.c_int32 * n)(*[int(x) for x in steps])
-        with self.lock, self._on_device():
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
             native.check(self.lib.upamd_adam_groups(n, b, e, st, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), float(lr),
                                                     float(beta1), float(beta2), float(eps), float(weight_decay),
                                                     _ptr(loss_src) if loss_src is not None else None,
@@ -246,16 +259,16 @@ class NativeEngine:
 
     # ---- profiling
     def profile(self, on):
-        with self.lock:
+        with self.lock, native.tuned(self.tune_overrides):
             native.check(self.lib.upamd_profile_enable(self.handle, 1 if on else 0), 'upamd_profile_enable')
 
     def profile_reset(self):
-        with self.lock:
+        with self.lock, native.tuned(self.tune_overrides):
             native.check(self.lib.upamd_profile_reset(self.handle), 'upamd_profile_reset')
 
     def profile_read(self, name):
         n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-        with self.lock:
+        with self.lock, native.tuned(self.tune_overrides):
             native.check(self.lib.upamd_profile_read(self.handle, name.encode(), C.byref(n), C.byref(ms), C.byref(fl),
                                                      C.byref(by)), 'upamd_profile_read')
         return dict(launches=n.value, total_ms=ms.value, flops=fl.value, bytes=by.value)

@@ -7,6 +7,7 @@ declares; ``build()`` compiles it in-tree with hipcc for gfx950.
 import ctypes as C
 import os
 import subprocess
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
@@ -150,6 +151,55 @@ def check(rc, what=''):
     if rc != 0:
         msg = lib().upamd_last_error()
         raise RuntimeError('%s failed (%d): %s' % (what or 'native call', rc, msg.decode() if msg else ''))
+
+
+# ---- kernel-lab knobs: process-wide in the library (upamd_tune), per ENGINE here.
+# The library reads its knobs when a call is ENQUEUED (launch configuration, which kernel, which stream), so an engine that wants
+# its own settings -- a learner next to an action server on another model in one process -- gets them by having its overrides
+# applied around its own native calls and the process defaults put back behind them, under one process-wide lock (only the enqueue
+# is serialised; the kernels of two engines still overlap on their streams).  `tune()` sets a process default (what engines
+# without an override of that knob see); `tuned(overrides)` is the bracket NativeEngine puts around its calls.
+TUNE_DEFAULTS = {'gemm_nt_dma': 1, 'gemm_split': 0, 'fold_layer1': 1, 'he_fused': 1, 'side_stream': 1, 'fwd_h_hbm': 1, 'fe_half': 1,
+                 'pq_exp': 1, 'bwd_nb_global': 1, 'nt_min_wgs': 128, 'tiny_fused': 1, 'tiny_threads': 1024, 'side_heads': 1,
+                 'side_wgrad': 1, 'side_priority': 1, 'grad_buckets': 1, 'gemm_lds_pad': 12 * 1024, 'gemm_stagger_mode': 1,
+                 'gemm_stagger_cycles': 37000}      # the library's built-in defaults (include/upamd.h, the block above upamd_tune)
+_tune_lock = threading.RLock()
+_tune_process = {}            # knob -> process default set through tune()
+
+
+def tune(name, value):
+    """Set a PROCESS default of a kernel-lab knob (engines created before or after see it unless they override that knob)."""
+    if name not in TUNE_DEFAULTS:
+        raise KeyError('unknown kernel-lab knob %r' % (name,))
+    with _tune_lock:
+        check(lib().upamd_tune(name.encode(), int(value)), 'upamd_tune')
+        _tune_process[name] = int(value)
+
+
+class tuned:
+    """``with native.tuned({'knob': value, ...}):`` -- the overrides hold for the native calls made inside the block (by this
+    thread; other threads' brackets wait at the lock), the process defaults are restored on the way out.  Empty overrides cost nothing."""
+
+    def __init__(self, overrides):
+        self.overrides = overrides
+
+    def __enter__(self):
+        if self.overrides:
+            _tune_lock.acquire()
+            L = lib()
+            for name, value in self.overrides.items():
+                check(L.upamd_tune(name.encode(), int(value)), 'upamd_tune')
+        return self
+
+    def __exit__(self, *exc):
+        if self.overrides:
+            try:
+                L = lib()
+                for name in self.overrides:
+                    L.upamd_tune(name.encode(), int(_tune_process.get(name, TUNE_DEFAULTS[name])))
+            finally:
+                _tune_lock.release()
+        return False
 
 
 ENCODER_SGNN, ENCODER_MLP = 0, 1

@@ -272,3 +272,37 @@ def test_saturating_edge_mlp_on_the_fused_path(gain, bias):
         if 'edge_fc_layers' in k:
             sd[k] = sd[k] * gain if k.endswith('weight') else sd[k] + bias
     _check_against_oracle(cfg, sd, replay, heads, T, tol=3e-4 if gain > 1 else 1e-4)
+
+
+def test_two_engines_in_one_process_keep_their_own_knobs():
+    """``engine.set_tune``: engine A runs the general kernels (tiny_fused = 0 for itself), engine B -- same model, same process -- stays
+    on the fused path, call by call interleaved; both match each other to the usual tolerance and the process default is untouched."""
+    from drl_urban_planning_amd import native
+    from drl_urban_planning_amd.engine import NativeEngine
+    T = 10
+    cfg, sd, rep = _hlg_case(T, 70, 0.3)
+    _, _, _, engB, flat, pk, sched, mb = _engine_setup(cfg, sd, rep.states, rep.actions)
+    engA = NativeEngine(engB.desc, torch.device(DEV))
+    engA.set_tune('tiny_fused', 0)
+    assert engB.step_fused_ok(mb) and not engA.step_fused_ok(mb) and engB.step_fused_ok(mb)
+    g = torch.Generator().manual_seed(4)
+    seeds = [torch.randn(T, generator=g).to(DEV) for _ in range(3)]
+    outs = {}
+    for name, eng in (('A', engA), ('B', engB), ('A2', engA), ('B2', engB)):
+        v, l, e = _forward(eng, pk, mb, flat)
+        grads = torch.zeros(eng.n_floats, device=DEV)
+        eng.backward(pk, mb, flat, seeds[0], seeds[1], seeds[2], grads)
+        torch.cuda.synchronize()
+        outs[name] = [t.clone() for t in (v, l, e, grads)]
+    assert engA.ws_tensor(mb, 'H1').numel() > 0                 # A's workspace holds the general path's tensors ...
+    with pytest.raises(RuntimeError, match='fused small-model path'):
+        engB.ws_tensor(mb, 'H1')                                # ... B's does not
+    for a, b in zip(outs['A'], outs['A2']):
+        assert torch.equal(a, b)
+    for a, b in zip(outs['B'], outs['B2']):
+        assert torch.equal(a, b)
+    for a, b in zip(outs['A'][:3], outs['B'][:3]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    scale = float(outs['A'][3].abs().max())
+    assert float((outs['A'][3] - outs['B'][3]).abs().max()) <= 2e-5 * scale
+    assert native.lib().upamd_step_fused_ok(engB.handle, __import__('ctypes').byref(mb)) == 1      # the process default is back

@@ -153,3 +153,50 @@ def test_workspace_plan_of_a_deep_edge_mlp_model():
     assert two[0] > plan(1, 400)[0] and two[1:] == [0, 400, 32, 1]
     assert plan(2, 4000)[0] - two[0] >= 3600 * 32 * 4 * (2 * 2 + 2)      # A_k of both layers + the backward ping-pong
     assert plan(2, 400, 'EA2_3')[1] != 0 and plan(3, 400, 'EA2_3')[1] == 0
+
+
+def test_kernel_lab_knobs_per_engine_bracket():
+    """The library's kernel-lab knobs are process-wide (upamd_tune); ``native.tuned(overrides)`` -- the bracket NativeEngine puts
+    around ITS native calls (``engine.set_tune``) -- makes them per engine: inside the block the overrides hold, behind it the process
+    defaults are back, and two threads with different overrides each see their own (only the enqueue is serialised).  Checked on
+    the one decision that needs no GPU: whether a minibatch takes the fused small-model path (tiny_fused)."""
+    import ctypes as C
+    import threading
+    L = native.lib()
+    cfg = helpers.make_cfg(D=16, L=2)
+    d = native.make_desc(cfg.state_encoder_specs, cfg.policy_specs, cfg.value_specs, 23, 52)
+    h = C.c_void_p()
+    native.check(L.upamd_engine_create(C.byref(d), C.byref(h)), 'upamd_engine_create')
+    mb = native.Minibatch()
+    mb.B, mb.n_nodes, mb.n_he, mb.n_rn, mb.max_n, mb.max_inc, mb.max_cand = 4, 100, 50, 0, 30, 120, 20
+    fused = lambda: L.upamd_step_fused_ok(h, C.byref(mb))
+    assert fused() == 1
+    with native.tuned({'tiny_fused': 0}):
+        assert fused() == 0
+        with native.tuned({}):                      # an engine without overrides inside: nothing changes, nothing is restored
+            assert fused() == 0
+    assert fused() == 1
+    native.tune('tiny_fused', 0)                    # a PROCESS default: what engines without their own setting see ...
+    try:
+        assert fused() == 0
+        with native.tuned({'tiny_fused': 1}):       # ... and what the bracket of an engine WITH one restores behind itself
+            assert fused() == 1
+        assert fused() == 0
+    finally:
+        native.tune('tiny_fused', 1)
+    assert fused() == 1
+    with pytest.raises(KeyError):
+        native.tune('no_such_knob', 1)
+    seen = {0: set(), 1: set()}
+
+    def worker(v):
+        for _ in range(300):
+            with native.tuned({'tiny_fused': v}):
+                seen[v].add(fused())
+    ts = [threading.Thread(target=worker, args=(v,)) for v in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert seen == {0: {0}, 1: {1}} and fused() == 1
+    L.upamd_engine_destroy(h)
