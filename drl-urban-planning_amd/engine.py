@@ -105,7 +105,8 @@ class NativeEngine:
 
     def workspace_bytes(self, mb):
         need = C.c_int64()
-        native.check(self.lib.upamd_workspace_bytes(self.handle, C.byref(mb), 1, C.byref(need)), 'upamd_workspace_bytes')
+        with self.lock, native.tuned(self.tune_overrides):
+            native.check(self.lib.upamd_workspace_bytes(self.handle, C.byref(mb), 1, C.byref(need)), 'upamd_workspace_bytes')
         return int(need.value)
 
     def alloc_workspace(self, mb):
@@ -176,7 +177,8 @@ class NativeEngine:
     def step_fused_ok(self, mb):
         """True when forward + PPO loss + backward of this minibatch run as ONE launch (gcn_node_dim <= 32, graphs that fit
         a workgroup's LDS): `step_fused` then replaces forward / ppo_loss_rows / backward."""
-        return bool(self.lib.upamd_step_fused_ok(self.handle, C.byref(mb)))
+        with self.lock, native.tuned(self.tune_overrides):
+            return bool(self.lib.upamd_step_fused_ok(self.handle, C.byref(mb)))
 
     def step_fused(self, packed, mb, flat_params, rows, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind, value,
                    logp, ent, grads, losses, slot=0):
