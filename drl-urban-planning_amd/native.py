@@ -164,6 +164,7 @@ TUNE_DEFAULTS = {'gemm_nt_dma': 1, 'gemm_split': 0, 'fold_layer1': 1, 'he_fused'
                  'side_wgrad': 1, 'side_priority': 1, 'grad_buckets': 1, 'gemm_lds_pad': 12 * 1024, 'gemm_stagger_mode': 1,
                  'gemm_stagger_cycles': 37000}      # the library's built-in defaults (include/upamd.h, the block above upamd_tune)
 _tune_lock = threading.RLock()
+_tune_depth = threading.local()
 _tune_process = {}            # knob -> process default set through tune()
 
 
@@ -186,17 +187,21 @@ class tuned:
     def __enter__(self):
         if self.overrides:
             _tune_lock.acquire()
-            L = lib()
-            for name, value in self.overrides.items():
-                check(L.upamd_tune(name.encode(), int(value)), 'upamd_tune')
+            _tune_depth.n = getattr(_tune_depth, 'n', 0) + 1
+            if _tune_depth.n == 1:              # (an engine's methods call each other: only the outermost bracket applies / restores)
+                L = lib()
+                for name, value in self.overrides.items():
+                    check(L.upamd_tune(name.encode(), int(value)), 'upamd_tune')
         return self
 
     def __exit__(self, *exc):
         if self.overrides:
             try:
-                L = lib()
-                for name in self.overrides:
-                    L.upamd_tune(name.encode(), int(_tune_process.get(name, TUNE_DEFAULTS[name])))
+                _tune_depth.n -= 1
+                if _tune_depth.n == 0:
+                    L = lib()
+                    for name in self.overrides:
+                        L.upamd_tune(name.encode(), int(_tune_process.get(name, TUNE_DEFAULTS[name])))
             finally:
                 _tune_lock.release()
         return False

@@ -175,6 +175,9 @@ def test_kernel_lab_knobs_per_engine_bracket():
         assert fused() == 0
         with native.tuned({}):                      # an engine without overrides inside: nothing changes, nothing is restored
             assert fused() == 0
+        with native.tuned({'tiny_fused': 0}):       # the same engine's nested call: the INNER bracket must not restore anything
+            assert fused() == 0
+        assert fused() == 0
     assert fused() == 1
     native.tune('tiny_fused', 0)                    # a PROCESS default: what engines without their own setting see ...
     try:
