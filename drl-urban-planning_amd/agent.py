@@ -382,8 +382,12 @@ class PPOUpdater:
         + node encoder and the first GCN layer, final with the backward's last launch -- is exposed.  The ranges are disjoint
         and a sum over ranks is element-wise: bucketed and single-collective steps give the same bits."""
         d, nflt = self.dist, self.engine.n_floats
-        ranges = self.engine.grad_buckets() if (buckets and self.bucketed_allreduce and d.active
-                                                and (d.world > 1 or self._buckets_forced)) else []
+        # Bucketed by default under RCCL only.  gloo moves HOST memory: every bucket is a blocking D2H + host reduce + H2D of the calling
+        # thread, nothing overlaps on the wire, and with several test ranks time-slicing ONE GPU the four blocking hand-overs per step
+        # cost whole scheduling rounds (4 ranks: 18.6 ms per step with one collective, 243 ms bucketed -- profiles/r05_lab_bucket_overhead.md);
+        # UPAMD_GRAD_BUCKETS=force keeps the route testable there (and with one rank).
+        on = buckets and self.bucketed_allreduce and d.active and ((d.world > 1 and d.backend == 'nccl') or self._buckets_forced)
+        ranges = self.engine.grad_buckets() if on else []
         if len(ranges) <= 1:
             self.last_buckets = None
             d.all_reduce_sum(self.grads)                  # ONE collective per optimizer step (no-op for one rank)

@@ -12,7 +12,7 @@ timeout 300 python bench.py --workload grid_ref --steps 100 --warmup 200 > $O/be
 timeout 200 python bench.py --minibatch 256 --cpu-baseline off --steps 64 --warmup 16 --inclusive-pool > $O/bench_hlg_d256_minibatch256.json 2>/dev/null
 UPAMD_DIST_FORCE_INIT=1 RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29531 timeout 300 python bench.py --steps 20 --warmup 5 --cpu-baseline off --inclusive-pool > $O/bench_rccl_single_rank.json 2> $O/rccl_single_rank.log
 R="python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 12 --warmup 4 --minibatch 512 --inclusive-pool"
-UPAMD_DIST_BACKEND=gloo timeout 300 $R > $O/bench_2ranks_1gpu_gloo_bucketed.json 2> $O/r2b.err
+UPAMD_DIST_BACKEND=gloo UPAMD_GRAD_BUCKETS=force timeout 300 $R > $O/bench_2ranks_1gpu_gloo_bucketed.json 2> $O/r2b.err
 UPAMD_DIST_BACKEND=gloo UPAMD_GRAD_BUCKETS=0 timeout 300 $R > $O/bench_2ranks_1gpu_gloo_single.json 2> $O/r2s.err
 timeout 200 python tools/rollout_bench.py --D 16 --L 2 > $O/rollout_d16.json 2> $O/rollout_d16.err
 timeout 200 python tools/rollout_bench.py --D 256 --L 3 --clients 8 16 32 64 --cpu-procs 1 16 --cpu-requests 10 > $O/rollout_d256.json 2> $O/rollout_d256.err
