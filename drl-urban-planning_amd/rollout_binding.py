@@ -71,6 +71,14 @@ def _rollout_child(client, agent, kind, pid, arena_spec, n, mean_action, seeds, 
                 arena.close(unlink=False)
         except Exception:
             pass
+        # Leave WITHOUT the interpreter's teardown: this is a fork of a process that holds an initialised GPU runtime, its allocator
+        # and their threads' state -- exit handlers and destructors running against that copy can crash or hang the child after its
+        # work is done (and a non-zero exit code of a worker that has long reported must not be read as a failure: see _upamd_serve).
+        try:
+            out_q.close()
+            out_q.join_thread()         # the report is in the pipe
+        finally:
+            os._exit(0)
 
 
 class RolloutMixin:
@@ -126,9 +134,11 @@ class RolloutMixin:
                 try:
                     kind, pid, rows, logger, err = out_q.get(timeout=1.0)
                 except Exception:               # queue.Empty: is everyone still alive, is the server still serving?
-                    dead = [p for p in procs if p.exitcode not in (None, 0)]
-                    if dead:
-                        failed = 'an env worker died with exit code %s' % dead[0].exitcode
+                    # (only a worker that has NOT reported counts: how a child that has delivered its rows leaves is its own business)
+                    dead = [p for p, (kind, pid, _, _) in zip(procs, jobs)
+                            if p.exitcode is not None and (kind, pid) not in reports]
+                    if dead and out_q.empty():
+                        failed = 'an env worker died (exit code %s) without reporting' % dead[0].exitcode
                     elif server.last_error and server._thread is not None and not server._thread.is_alive():
                         failed = 'the action server stopped: %s' % server.last_error
                     elif deadline is not None and time.time() > deadline:
