@@ -276,12 +276,12 @@ def test_bound_agent_samples_through_the_server_and_updates_on_the_records(tmp_p
     losses = ag._hip_updater().last_losses
     assert losses.shape[0] > 0 and np.isfinite(losses).all()
     # evaluation behind a client == the same greedy episode computed in this process on the GPU modules
-    class _HostActions:                     # (the reference evaluates on CPU modules, :406; here the GPU modules answer in-process)
-        def __init__(self, net):
-            self.net = net
+    class _HostActions:                     # (the reference evaluates on CPU modules, :406; here the GPU modules answer in-process,
+        def __init__(self, net):            # through the SAME route the server uses: the weights were just moved by an update on
+            self.net = net                  # SAMPLED rows, and two routes' soft-maxes may break a near-tie differently)
 
         def select_action(self, x, mean_action):
-            return self.net.select_action(x, mean_action).cpu()
+            return torch.from_numpy(self.net._backend[0].serve_actions(x, np.full(len(x), bool(mean_action))))
     real = ag.policy_net
     ag.env.episode = -1
     ag.policy_net = _HostActions(real)
