@@ -137,14 +137,17 @@ def cpu_baseline(w, mode='quick'):
     if not full:                                    # quick: 16 and 32 threads only (where the optimum sits), fewer steps
         sweep = sorted({min(16, ncpu), min(32, ncpu)})
     B_small = 8 if wide else 64
-    rows = [_cpu_row(P, orc, synth, w, B_small, 1, False, 5 if full else 2, 12.0)]
-    for t in sweep:         # small steps: the fastest per sample on a CPU (the working set of a bigger batch falls out of cache)
-        rows.append(_cpu_row(P, orc, synth, w, B_small, t, False, 5, 10.0 if full else 6.0))
-    best_t = max(rows[1:], key=lambda r: r['samples_per_s'])['threads']
-    rows.append(_cpu_row(P, orc, synth, w, B_std, best_t, False, 5, 15.0 if full else 6.0))      # and a 32-row step
+    if mode == 'brief':     # the ref_dims child runs: the line the quick sweep has picked on every box so far (16 threads, small steps)
+        rows = [_cpu_row(P, orc, synth, w, B_small, min(16, ncpu), False, 5, 5.0)]
+    else:
+        rows = [_cpu_row(P, orc, synth, w, B_small, 1, False, 5 if full else 2, 12.0)]
+        for t in sweep:     # small steps: the fastest per sample on a CPU (the working set of a bigger batch falls out of cache)
+            rows.append(_cpu_row(P, orc, synth, w, B_small, t, False, 5, 10.0 if full else 6.0))
+        best_t = max(rows[1:], key=lambda r: r['samples_per_s'])['threads']
+        rows.append(_cpu_row(P, orc, synth, w, B_std, best_t, False, 5, 15.0 if full else 6.0))      # and a 32-row step
     padded = [r for r in rows if r['threads'] > 1] or rows
     best = max(padded, key=lambda r: r['samples_per_s'])
-    tight = _cpu_row(P, orc, synth, w, best['rows_per_step'], best['threads'], True, 5, 15.0 if full else 6.0)
+    tight = _cpu_row(P, orc, synth, w, best['rows_per_step'], best['threads'], True, 5, 15.0 if full else (4.0 if mode == 'brief' else 6.0))
     rows.append(tight)
     torch.set_num_threads(min(ncpu, 32))
     return dict(value=best['samples_per_s'], unit='samples/s', cores=best['threads'], kind='port',
@@ -152,7 +155,7 @@ def cpu_baseline(w, mode='quick'):
                        'path: /root/reference is absent on the GPU box), best of the (threads, rows) lines %s'
                        % (best['steps'], best['rows_per_step'], w['max_nodes'], w['max_edges'], w['D'], w['L'],
                           [(r['threads'], r['rows_per_step']) for r in padded]),
-                ms_per_step=best['ms_per_step'], host_cpus=ncpu, one_thread=rows[0]['samples_per_s'],
+                ms_per_step=best['ms_per_step'], host_cpus=ncpu, one_thread=rows[0]['samples_per_s'] if rows[0]['threads'] == 1 else None,
                 tight_pad=tight['samples_per_s'], rows=rows)
 
 
@@ -178,6 +181,60 @@ def pmc_figure(fname, args, pick):
     return v, (None if v is not None else 'kernel not in profiles/%s' % fname)
 
 
+def spawn_ranks(args, argv):
+    """``python bench.py --gpus N`` with no launcher around it: re-exec this script under ``torch.distributed.run`` (one rank
+    per GPU, rendezvous on 127.0.0.1, a free port) -- rank 0 of that run prints the JSON line on the inherited stdout.  With
+    fewer visible GPUs than ranks the ranks share devices over gloo (UPAMD_DIST_BACKEND=gloo: a functional check of the rank
+    logic on a one-GPU box, labelled as such in the line -- RCCL refuses two ranks on one device)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus and 'UPAMD_DIST_BACKEND' not in env:
+        sys.stderr.write('bench.py: %d ranks on %d visible GPU(s): ranks share devices over gloo (functional check, not a '
+                         'scaling number)\n' % (args.gpus, ndev))
+        env['UPAMD_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+REF_DIMS_KEYS = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'node_steps_per_s', 'host_enqueue_ms_per_step', 'kernel_ms_per_step')
+
+
+def ref_dims_line(workload, steps=400, warmup=256, timeout_s=240):
+    """One of the reference-YAML-dims workloads (hlg_ref: hlg.yaml:21-44; grid_ref = BASELINE configs[0]: grid.yaml:16-33) measured by a
+    child run of this script (its own process: another model, replay and engine) and reduced to the fields SURVEY 8(d) asks for
+    next to every configuration: samples/s, ms/step, the fused kernel's roofline fraction, the CPU port's row, the inclusive fractions."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--workload', workload, '--steps', str(steps), '--warmup', str(warmup),
+           '--cpu-baseline', 'brief', '--strong-proxy', 'off', '--no-ref-dims']
+    t0 = time.time()
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        line = [l for l in res.stdout.splitlines() if l.startswith('{')]
+        if res.returncode != 0 or not line:
+            return {'error': 'rc=%d: %s' % (res.returncode, res.stderr[-400:])}
+        d = json.loads(line[-1])
+    except Exception as exc:                       # a failed side measurement must not cost the headline its line
+        return {'error': '%s: %s' % (type(exc).__name__, exc)}
+    out = {k: d.get(k) for k in REF_DIMS_KEYS}
+    out['workload'] = d['config']['workload']
+    rl = d.get('roofline') or {}
+    out['roofline'] = {k: rl.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'traffic')}
+    cb = d.get('cpu_baseline') or {}
+    out['cpu_baseline'] = {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample', 'ms_per_step', 'tight_pad')}
+    for k in ('update_params_inclusive', 'update_params_inclusive_records'):
+        if d.get(k):
+            out[k] = {q: d[k].get(q) for q in ('samples_per_s', 'seconds', 'fraction_of_step_rate', 'prepare_s', 'loop_s')}
+    out['wall_s'] = time.time() - t0
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -185,8 +242,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--workload', default='hlg_d256', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline', default='quick', choices=['quick', 'full', 'off'],
-                    help='quick: ~1 min of CPU work (default); full: the whole thread sweep, >= 5 steps per line')
+    ap.add_argument('--cpu-baseline', default='quick', choices=['quick', 'full', 'brief', 'off'],
+                    help='quick: ~1 min of CPU work (default); full: the whole thread sweep, >= 5 steps per line; brief: one '
+                         '16-thread line + its tight-pad twin (~15 s; what the ref_dims child runs use)')
+    ap.add_argument('--no-ref-dims', action='store_true',
+                    help='skip the ref_dims object (default run at N = 1: hlg_ref and grid_ref measured by child runs)')
     ap.add_argument('--dp-mode', default='global', choices=['global', 'local'],
                     help='global (default): every rank holds the replay, one global permutation, rank slices of each '
                          'global minibatch; local: per-rank shards shuffled locally')
@@ -204,6 +264,8 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak (default): the minibatch per GPU is fixed; strong: the GLOBAL minibatch is fixed and split')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args, sys.argv[1:])             # does not return: this process becomes the launcher
     # The learner process of the reference runs with OMP_NUM_THREADS=1 (khrylib/rl/agents/agent.py:12).  It matters here: torch's
     # default is one OpenMP thread per core (128 on the GPU boxes), whose workers spin after every parallel region (a 64 KB host copy
     # is enough) -- inside a container with a CPU quota (16 cores on this pool) that burns the quota and the whole process is
@@ -320,6 +382,10 @@ def main():
     cmean = torch.tensor([sum(coll) / max(len(coll), 1)], dtype=torch.float64, device=dev)
     ctx.all_reduce_max(cmean)
     grad_bytes = int(up.grads.numel()) * 4
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    if ctx.world > 1:
+        ctx.all_reduce_sum(ones)                       # every rank that takes part in the collectives adds 1
+    ranks_seen, backend = int(round(float(ones.item()))), ctx.backend()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     ctx.all_reduce_max(tmax)
     dt = float(tmax.item())
@@ -461,6 +527,10 @@ def main():
     if ctx.world > 1:
         # how long the backward's stream WAITS for the step's gradient all-reduce (HIP events on that stream): all of a single
         # collective, the exposed tail of the bucketed form (UPAMD_GRAD_BUCKETS=0 switches the buckets off)
+        out['rccl_ranks_seen'] = ranks_seen      # the sum of an all-reduce of ones over the gradient's process group
+        out['collective_backend'] = backend + ('' if backend == 'nccl' else ' (ranks share a GPU through host memory: a functional check of '
+                                                                            'the rank logic, not a scaling number)')
+        out['visible_gpus'] = torch.cuda.device_count()
         out['allreduce_buckets'] = [[int(b), int(e)] for b, e in (up.last_buckets or [])]
         out['allreduce_ms'] = float(cmean.item())
         out['allreduce_share_of_step'] = float(cmean.item()) / out['ms_per_step']
@@ -536,6 +606,10 @@ def main():
         out['message_passing'] = mp
     if ctx.world == 1 and not args.no_cpu_baseline and args.cpu_baseline != 'off':
         out['cpu_baseline'] = cpu_baseline(w, args.cpu_baseline)
+    if ctx.world == 1 and args.workload == 'hlg_d256' and not args.minibatch and not args.no_ref_dims:
+        # "for every cfg additionally report the reference-YAML dims" -- the two small-model workloads in the same line
+        # (child runs, long warm-up: sub-millisecond steps need the clock ramp)
+        out['ref_dims'] = {name: ref_dims_line(name) for name in ('hlg_ref', 'grid_ref')}
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + '\n').encode())
     os.close(json_fd)

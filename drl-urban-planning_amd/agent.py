@@ -110,6 +110,19 @@ class PPOUpdater:
         # how the RCCL route -- async work objects on the process group's own stream -- is exercised on a one-GPU box)
         self.bucketed_allreduce = os.environ.get('UPAMD_GRAD_BUCKETS', '1') != '0'
         self._buckets_forced = os.environ.get('UPAMD_GRAD_BUCKETS') == 'force'
+        # UPAMD_GRAD_BUCKETS=check (any world size, also without a process group): a FINALITY check of the engine's bucket events -- the
+        # communication stream snapshots every range the moment its event has fired, and behind the whole backward the snapshots
+        # are compared with the final gradient bit for bit (bucket_check_mismatches counts differing floats; tests assert 0).  A range
+        # the backward marks final too early is invisible to a one-rank RCCL group (its sum is the identity) and caught under gloo
+        # only by chance of timing; this sees it on one GPU.
+        self._buckets_check = os.environ.get('UPAMD_GRAD_BUCKETS') == 'check'
+        self._bucket_check_shift = 0          # tests only (negative control): snapshot range j + shift behind event j -- must mismatch
+        self.bucket_check_mismatches = None   # device int64 scalar (check mode)
+        self.bucket_checks = 0                # ranges compared so far (check mode)
+        # lab knobs of the bucketed route, read once (profiles/r05_lab_bucket_overhead.md)
+        self._bucket_lab = os.environ.get('UPAMD_BUCKET_LAB', '')
+        self._bucket_tail_main = os.environ.get('UPAMD_BUCKET_TAIL', 'main') == 'main'
+        self._comm_priority = int(os.environ.get('UPAMD_COMM_PRIORITY', '0'))
         self.last_buckets = None              # [(begin, end)] of the last bucketed step (tests, bench.py)
         # prepare(): the replay is packed / uploaded / swept in about this many chunks (1 = no pipeline)
         # 0 = auto: 8 where the pre-pass is worth hiding (gcn_node_dim > 32), 1 for the small models, whose prepare() is bound by the
@@ -386,6 +399,8 @@ class PPOUpdater:
         # thread, nothing overlaps on the wire, and with several test ranks time-slicing ONE GPU the four blocking hand-overs per step
         # cost whole scheduling rounds (4 ranks: 18.6 ms per step with one collective, 243 ms bucketed -- profiles/r05_lab_bucket_overhead.md);
         # UPAMD_GRAD_BUCKETS=force keeps the route testable there (and with one rank).
+        if buckets and self._buckets_check:
+            self._check_bucket_finality()
         on = buckets and self.bucketed_allreduce and d.active and ((d.world > 1 and d.backend == 'nccl') or self._buckets_forced)
         ranges = self.engine.grad_buckets() if on else []
         if len(ranges) <= 1:
@@ -397,10 +412,10 @@ class PPOUpdater:
             # NORMAL priority: the engine's side streams are high-priority, and a high-priority communication stream (which only ever
             # holds event waits) shared their hardware queue -- its waits then stood in front of side-stream kernels: +0.16 ms per
             # 256-row step under a one-rank RCCL group against +0.07 at normal priority (profiles/r05_lab_bucket_overhead.md)
-            self._comm = torch.cuda.Stream(device=dev, priority=int(os.environ.get('UPAMD_COMM_PRIORITY', '0')))
+            self._comm = torch.cuda.Stream(device=dev, priority=self._comm_priority)
         ranges = [(b, e + 4 if e == nflt else e) for b, e in ranges]      # the 4 loss scalars ride behind the last parameter
         works = []
-        lab = os.environ.get('UPAMD_BUCKET_LAB', '')        # lab only: 'late' = the same collectives, all behind the backward;
+        lab = self._bucket_lab                              # lab only: 'late' = the same collectives, all behind the backward;
         if lab == 'two':                                    # 'two' = the first range early, everything else as one late collective
             lo = min(b for b, e in ranges[1:])
             hi = max(e for b, e in ranges[1:])
@@ -412,7 +427,7 @@ class PPOUpdater:
                 works.append(d.all_reduce_sum_async(self.grads[lo:hi]))
             ranges = []
         for j, (b, e) in enumerate(ranges):
-            if j == len(ranges) - 1 and lab != 'late' and os.environ.get('UPAMD_BUCKET_TAIL', 'main') == 'main':
+            if j == len(ranges) - 1 and lab != 'late' and self._bucket_tail_main:
                 # the last range becomes final with the backward's last launch on the CALLER's stream: issue its collective from
                 # there (one stream hand-over less than through the communication stream)
                 works.append(d.all_reduce_sum_async(self.grads[b:e]))
@@ -423,6 +438,32 @@ class PPOUpdater:
         for w in works:
             w.wait()                                      # the caller's stream continues behind every bucket
         self.last_buckets = ranges
+
+    def _check_bucket_finality(self):
+        """UPAMD_GRAD_BUCKETS=check: snapshot every range behind ITS event on the communication stream, compare with the gradient
+        buffer behind the whole backward (the caller's stream).  Called right behind engine.backward, i.e. where the collectives of
+        the bucketed route are issued."""
+        ranges = self.engine.grad_buckets()
+        if len(ranges) <= 1:
+            return
+        dev = self.engine.device
+        if self._comm is None or self._comm.device != dev:
+            self._comm = torch.cuda.Stream(device=dev, priority=self._comm_priority)
+        if self.bucket_check_mismatches is None:
+            self.bucket_check_mismatches = torch.zeros((), dtype=torch.int64, device=dev)
+        snaps = []
+        for j in range(len(ranges) - 1 - self._bucket_check_shift):      # (the last range is final with the backward's last launch by definition)
+            b, e = ranges[j + self._bucket_check_shift]
+            self.engine.grad_bucket_wait(j, self._comm)
+            with torch.cuda.stream(self._comm):
+                snaps.append((b, e, self.grads[b:e].clone()))
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(self._comm)
+        for b, e, snap in snaps:
+            snap.record_stream(cur)                       # allocated on the communication stream, read on the caller's
+            # bit comparison (NaNs included): a float that changed after its range's event is a finality violation
+            self.bucket_check_mismatches += (snap.view(torch.int32) != self.grads[b:e].view(torch.int32)).sum()
+            self.bucket_checks += 1
 
     def _finish_step(self, ep, k, loss_out, buckets=True):
         """all-reduce, first-step clip, Adam -- everything behind the backward of a step"""

@@ -115,6 +115,7 @@ class ActionServer:
         self.stats = dict(batches=0, requests=0, rows=0, max_rows=0, busy_s=0.0)
         self.fast = True                # GPU modules: models._HipBackend.serve_actions instead of policy_net.forward + Categorical over pads
         self.last_error = None
+        self.last_traceback = None
         self._thread = None
         self._stop = threading.Event()
 
@@ -161,8 +162,10 @@ class ActionServer:
             actions = self._actions(states, np.asarray(owner, dtype=bool))
             status = 'ok'
         except Exception as exc:                    # report to the workers instead of dying silently
+            import traceback
             actions, status = None, '%s: %s' % (type(exc).__name__, exc)
             self.last_error = status
+            self.last_traceback = traceback.format_exc()
         row = 0
         for i, conn, sizes, mean in reqs:
             if actions is not None:
@@ -226,8 +229,10 @@ class ActionServer:
             try:
                 self.serve_once(timeout=0.02)
             except Exception as exc:                # a broken pipe, an OSError from wait(): tell whoever is waiting, keep serving
+                import traceback
                 self.stats['errors'] = self.stats.get('errors', 0) + 1
                 self.last_error = '%s: %s' % (type(exc).__name__, exc)
+                self.last_traceback = traceback.format_exc()
                 for conn in self._server_ends:
                     try:
                         if not conn.closed and conn.poll(0):
@@ -276,6 +281,7 @@ class SharedArena:
             self.shm = shared_memory.SharedMemory(name=name)
             self.owner = False
         self._pinned = False
+        self._closed = self._unlinked = False
 
     @property
     def name(self):
@@ -344,13 +350,25 @@ class SharedArena:
         return (np.uint64(base) + t[:, 0].astype(np.uint64)), t[:, 1].astype(np.int64)
 
     def close(self, unlink=None):
+        """Unmap (and, for the owner, unlink) the arena.  Record views taken from ``data`` / ``rows()`` export the mapping's
+        buffer: while one is alive the mapping is NOT torn down (``BufferError`` from the memoryview) -- the name is unlinked
+        all the same, and the pages go when the last view does.  Returns True when the mapping is gone."""
+        if self._closed:
+            return True
         self._unpin()
-        self.shm.close()
-        if self.owner if unlink is None else unlink:
+        gone = True
+        try:
+            self.shm.close()
+            self._closed = True
+        except BufferError:                 # exported views are alive: leave the mapping to the garbage collector
+            gone = False
+        if (self.owner if unlink is None else unlink) and not self._unlinked:
             try:
                 self.shm.unlink()
             except FileNotFoundError:
                 pass
+            self._unlinked = True
+        return gone
 
 
 class ArenaMemory:
@@ -371,8 +389,17 @@ class RecordBatch:
     """``TrajBatchDisc`` (urban_planning/utils/tools.py:4-16) over worker arenas and / or plain ``Memory`` objects, in
     worker order: ``states`` hold compact records (views into the arenas), the per-row arrays are stacked."""
 
-    def __init__(self, memory_list):
+    def __init__(self, memory_list, owns=()):
+        """``owns``: arenas whose lifetime is THIS batch's -- the zero-copy record views in ``states`` and the raw addresses in
+        ``states.addr`` point into their mappings, so they are closed (and unlinked) by ``close()`` or when the batch is
+        collected, never while it can still be handed to ``update_params`` (a second ``sample()`` before the update, a batch
+        kept for debugging or replay reuse must not read unmapped memory)."""
+        import weakref
         states, actions, masks, rewards, exps, addrs, sizes = [], [], [], [], [], [], []
+        self._arenas = list(owns)
+        self._held = {'states': None}        # shared with the finalizer: the views must go BEFORE the mappings they point into
+        self._finalizer = weakref.finalize(self, _release_batch, self._held, self._arenas) if self._arenas else None
+        self.closed = False
         for m in memory_list:
             arena = getattr(m, 'arena', m if isinstance(m, SharedArena) else None)
             if arena is not None:
@@ -395,12 +422,34 @@ class RecordBatch:
             rewards.append(rw)
             exps.append(ex)
         # (a list of record views that also carries the records' addresses: the packer never touches the T view objects)
-        self.states = packer.RecordList(states, np.concatenate(addrs) if addrs else None, np.concatenate(sizes) if sizes else None)
+        self._held['states'] = packer.RecordList(states, np.concatenate(addrs) if addrs else None, np.concatenate(sizes) if sizes else None)
+        del states
         self.actions = np.concatenate(actions) if actions else np.zeros((0, 2), np.float32)
         self.masks = np.concatenate(masks) if masks else np.zeros(0)
         self.rewards = np.concatenate(rewards) if rewards else np.zeros(0)
         self.exps = np.concatenate(exps) if exps else np.zeros(0)
         self.next_states = None
 
+    def close(self):
+        """Drop the record views and addresses, then unmap / unlink the arenas this batch owns.  A closed batch is empty: handing
+        it to ``update_params`` raises ('empty replay') instead of reading freed memory."""
+        self.closed = True
+        if self._finalizer is not None:
+            self._finalizer()              # runs _release_batch once; a later collection does nothing
+        self._held['states'] = packer.RecordList([], None, None)
+
+    @property
+    def states(self):
+        return self._held['states']
+
     def __len__(self):
-        return len(self.states)
+        return len(self._held['states'])
+
+
+def _release_batch(held, arenas):
+    held['states'] = None                  # the zero-copy record views (and the raw address table) first ...
+    for a in arenas:                       # ... then the mappings they pointed into
+        try:
+            a.close()
+        except Exception:
+            pass

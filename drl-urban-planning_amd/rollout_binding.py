@@ -44,10 +44,28 @@ import torch
 from . import packer
 
 
-def _rollout_child(client, agent, kind, pid, arena_spec, n, mean_action, seeds, out_q):
+def _child_log_path(diag_dir, kind, pid):
+    return os.path.join(diag_dir, '%s%d.log' % (kind, pid))
+
+
+def _rollout_child(client, agent, kind, pid, arena_spec, n, mean_action, seeds, out_q, diag_dir=None):
     """Body of one forked env worker.  The child never touches the (GPU) modules or the HIP runtime."""
     from . import rollout
     arena = None
+    if diag_dir:
+        # whatever ends this child, the learner can say why: stderr and faulthandler (fatal signals, and a stack dump of every
+        # thread if the worker is still here after UPAMD_ROLLOUT_STUCK_S seconds) go to a per-worker file the parent quotes on failure
+        try:
+            import faulthandler
+            fh = open(_child_log_path(diag_dir, kind, pid), 'w', buffering=1)
+            os.dup2(fh.fileno(), 2)
+            faulthandler.enable(file=fh, all_threads=True)
+            faulthandler.dump_traceback_later(float(os.environ.get('UPAMD_ROLLOUT_STUCK_S', '90')), repeat=True, file=fh)
+        except Exception:
+            pass
+    # One OpenMP thread, like the reference's workers (khrylib/rl/agents/agent.py:12 sets OMP_NUM_THREADS=1 before anything forks):
+    # the learner's OpenMP pool does not exist in a forked child, and a parallel region entered there waits for its threads for ever
+    torch.set_num_threads(1)
     try:
         agent.policy_net = client               # what sample_worker / eval_agent call select_action on
         agent.sample_modules = []               # to_test / to_cpu (agent.py:79-80, urban_planning_agent.py:404-406) see nothing
@@ -118,16 +136,21 @@ class RolloutMixin:
         order: (kind, pid, rows, logger)."""
         from . import rollout
         import multiprocessing
+        import shutil
+        import tempfile
         ctx = multiprocessing.get_context('fork')
         out_q = ctx.Queue()
+        diag_dir = tempfile.mkdtemp(prefix='upamd_rollout_')       # per-worker stderr / faulthandler files (quoted on failure)
         server = rollout.ActionServer(self.policy_net, len(jobs), slot_bytes=int(os.environ.get('UPAMD_ROLLOUT_SLOT', 1 << 20)),
                                       mp_context=ctx)
         args = []
         for j, (kind, pid, n, mean) in enumerate(jobs):
             a = arenas.get(j)
-            args.append((self, kind, pid, (a.name, a.cap_rows, a.cap_bytes) if a is not None else None, n, mean, seeds, out_q))
+            args.append((self, kind, pid, (a.name, a.cap_rows, a.cap_bytes) if a is not None else None, n, mean, seeds, out_q, diag_dir))
         procs = server.launch(_rollout_child, args, ctx)       # forks FIRST, then starts the serving thread
         reports, failed = {}, None
+        if timeout_s is None:
+            timeout_s = float(os.environ.get('UPAMD_ROLLOUT_TIMEOUT_S', '0')) or None
         deadline = None if timeout_s is None else time.time() + timeout_s
         try:
             while len(reports) < len(jobs) and failed is None:
@@ -149,23 +172,56 @@ class RolloutMixin:
                     break
                 reports[(kind, pid)] = (kind, pid, rows, logger)
         finally:
+            if failed is not None and any(p.is_alive() for p in procs):
+                for p in procs:                 # a stuck worker: have faulthandler write every thread's stack before it is ended
+                    if p.is_alive():
+                        try:
+                            os.kill(p.pid, 6)   # SIGABRT -> faulthandler dump into the worker's file
+                        except OSError:
+                            pass
             for p in procs:
-                p.join(timeout=5.0 if failed is None else 0.5)
+                p.join(timeout=5.0 if failed is None else 1.0)
                 if p.is_alive():
                     p.terminate()
             self._upamd_server_stats = dict(server.stats)
+            server_error, server_tb = server.last_error, server.last_traceback
             server.close()
+            if failed is not None:
+                failed += self._upamd_failure_report(jobs, procs, reports, diag_dir, server_error, server_tb)
+            if os.environ.get('UPAMD_ROLLOUT_KEEP_DIAG') != '1':
+                shutil.rmtree(diag_dir, ignore_errors=True)
         if failed is not None:
             raise RuntimeError('UPAMD_ROLLOUT=server: %s' % failed)
         return [reports[(kind, pid)] for kind, pid, _, _ in jobs]
 
-    def _upamd_release_arenas(self):
-        for a in getattr(self, '_upamd_arenas', None) or []:
+    @staticmethod
+    def _upamd_failure_report(jobs, procs, reports, diag_dir, server_error, server_tb):
+        """Everything known about a failed serving phase, for the exception message: per worker whether it reported, its exit code
+        (negative = the signal that killed it) and the tail of its stderr / faulthandler file; the serving thread's last error."""
+        lines = ['', '---- serving phase post-mortem ----']
+        for p, (kind, pid, _, _) in zip(procs, jobs):
+            lines.append('worker %s %d: reported=%s exitcode=%s' % (kind, pid, (kind, pid) in reports, p.exitcode))
             try:
-                a.close()
-            except Exception:
+                with open(_child_log_path(diag_dir, kind, pid)) as fh:
+                    text = '\n'.join(l for l in fh.read().splitlines() if not l.startswith('Extension modules:'))
+                if text.strip():
+                    # faulthandler writes the innermost frames first: keep the head, and the tail for whatever came last
+                    if len(text) > 3200:
+                        text = text[:2600] + '\n[...]\n' + text[-500:]
+                    lines.append('  stderr / faulthandler:\n    ' + text.replace('\n', '\n    '))
+            except OSError:
                 pass
-        self._upamd_arenas = []
+        lines.append('action server: last_error=%s' % server_error)
+        if server_tb:
+            lines.append(server_tb)
+        return '\n'.join(lines)
+
+    def _upamd_release_arenas(self):
+        """Close every batch ``sample()`` has handed out that is still alive (end of training, tests).  NOT called by ``sample()``:
+        a batch owns its arenas -- they are unmapped when the batch is closed or collected, never underneath a batch the caller
+        still holds (a second ``sample()`` before ``update_params``, a batch kept for debugging or replay reuse)."""
+        for b in list(getattr(self, '_upamd_batches', None) or []):
+            b.close()
 
     # ---- Agent.sample (khrylib/rl/agents/agent.py:75-100)
     def sample(self, num_samples, mean_action=False, nthreads=None):
@@ -178,10 +234,8 @@ class RolloutMixin:
         for m in self.sample_modules:           # to_test (:79); the modules stay where they are (no to_cpu, :80)
             m.train(False)
         thread_num_samples = int(math.floor(num_samples / nthreads))
-        self._upamd_release_arenas()            # the previous iteration's batch has been consumed by update_params
         cap_rows, cap_bytes = self._upamd_arena_caps(thread_num_samples)
         arenas = [rollout.SharedArena(cap_rows, cap_bytes) for _ in range(nthreads)]
-        self._upamd_arenas = arenas
         if os.environ.get('UPAMD_ROLLOUT_PIN') == '1':
             for a in arenas:
                 a.pin()
@@ -193,15 +247,25 @@ class RolloutMixin:
         if overlap:
             jobs.append(('eval', nthreads, 1, True))
             self._upamd_eval_sd = {k: v.detach().to('cpu', copy=True) for k, v in self.actor_critic_net.state_dict().items()}
-        with torch.no_grad():
-            reports = self._upamd_serve(jobs, {i: arenas[i] for i in range(nthreads)}, seeds)
+        try:
+            with torch.no_grad():
+                reports = self._upamd_serve(jobs, {i: arenas[i] for i in range(nthreads)}, seeds)
+        except BaseException:
+            for a in arenas:                    # no batch will ever own them
+                a.close()
+            raise
         if overlap:
             self._upamd_eval_ahead = reports[-1][3]
         memories = [rollout.ArenaMemory(a) for a in arenas]
         for (kind, pid, rows, _), m in zip(reports[:nthreads], memories):
             if rows != len(m):
                 raise RuntimeError('env worker %d reported %d rows, its arena holds %d' % (pid, rows, len(m)))
-        traj_batch = rollout.RecordBatch(memories)
+        traj_batch = rollout.RecordBatch(memories, owns=arenas)      # the arenas live exactly as long as the batch does
+        del memories
+        if getattr(self, '_upamd_batches', None) is None:
+            import weakref
+            self._upamd_batches = weakref.WeakSet()
+        self._upamd_batches.add(traj_batch)
         logger = self.logger_cls.merge([r[3] for r in reports[:nthreads]], **self.logger_kwargs)
         logger.sample_time = time.time() - t_start
         return traj_batch, logger

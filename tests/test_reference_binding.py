@@ -561,3 +561,63 @@ def test_server_rollout_reports_a_failing_worker_instead_of_hanging(tmp_path, mo
     batch, log = ag.sample(20)
     assert len(batch) == 20 and log.num_episodes == 4
     ag._upamd_release_arenas()
+
+
+@needs_reference
+def test_server_rollout_post_mortem_names_the_signal_and_quotes_the_workers_stderr(tmp_path, monkeypatch):
+    """A worker that DIES (here: SIGSEGV inside the env's ``step``) cannot report.  The learner's RuntimeError must carry what is
+    needed to find the cause: which workers reported, every exit code (-11 = killed by SIGSEGV), the tail of the dead worker's
+    stderr / faulthandler file (the Python stack at the fault), the serving thread's last error."""
+    import signal
+    ag, ref = _rollout_agent(tmp_path)
+    monkeypatch.setenv('UPAMD_ROLLOUT', 'server')
+    good_step = ag.env.step
+    learner = os.getpid()
+    calls = {'n': 0}
+
+    def step(action, logger=None):
+        calls['n'] += 1
+        if os.getpid() != learner and calls['n'] == 3 and os.environ.get('UPAMD_TEST_FAIL') == 'segv':
+            os.kill(os.getpid(), signal.SIGSEGV)
+        return good_step(action, logger)
+    ag.env.step = step
+    monkeypatch.setenv('UPAMD_TEST_FAIL', 'segv')
+    with pytest.raises(RuntimeError) as err:
+        ag.sample(20)
+    msg = str(err.value)
+    assert 'without reporting' in msg and 'post-mortem' in msg
+    assert 'exitcode=-11' in msg, msg
+    assert 'Segmentation fault' in msg and 'in step' in msg, msg           # faulthandler's dump of the worker's Python stack
+    assert 'action server: last_error=' in msg
+    monkeypatch.setenv('UPAMD_TEST_FAIL', '0')
+    batch, log = ag.sample(20)                                            # the agent is usable afterwards
+    assert len(batch) == 20
+    batch.close()
+
+
+@needs_reference
+def test_a_record_batch_owns_its_arenas(tmp_path, monkeypatch):
+    """The batch ``sample()`` returns holds zero-copy record views and raw record addresses into shared-memory arenas.  Those
+    arenas live exactly as long as the batch: another ``sample()`` does not unmap them (it used to: a batch kept across the next
+    call -- a second sample before update_params, debugging, replay reuse -- then read freed memory: SIGSEGV in the interpreter or
+    in the C packer threads); ``close()`` / garbage collection unmaps AND unlinks them; a closed batch is empty."""
+    import gc
+    from drl_urban_planning_amd import packer
+    ag, ref = _rollout_agent(tmp_path)
+    monkeypatch.setenv('UPAMD_ROLLOUT', 'server')
+    b1, _ = ag.sample(20, mean_action=True)
+    names1 = [a.name for a in b1._arenas]
+    want = [bytes(r) for r in b1.states]
+    b2, _ = ag.sample(20, mean_action=True)
+    assert [bytes(r) for r in b1.states] == want                          # still mapped, still the same bytes
+    pk = packer.pack_replay(b1.states, b1.actions, 23, 52, pin=False)     # the C packer reads b1's raw addresses
+    assert pk.T == 20
+    assert all(os.path.exists('/dev/shm/' + n.lstrip('/')) for n in names1)
+    names2 = [a.name for a in b2._arenas]
+    b2.close()
+    assert b2.closed and len(b2) == 0 and not any(os.path.exists('/dev/shm/' + n.lstrip('/')) for n in names2)
+    with pytest.raises(ValueError, match='empty replay'):
+        packer.pack_replay(b2.states, b2.actions, 23, 52, pin=False)
+    del b1, pk
+    gc.collect()
+    assert not any(os.path.exists('/dev/shm/' + n.lstrip('/')) for n in names1)      # collected -> unmapped and unlinked
