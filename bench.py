@@ -270,7 +270,7 @@ def main():
     # default is one OpenMP thread per core (128 on the GPU boxes), whose workers spin after every parallel region (a 64 KB host copy
     # is enough) -- inside a container with a CPU quota (16 cores on this pool) that burns the quota and the whole process is
     # throttled for the rest of the 100 ms period: 60-90 ms host stalls at random places, 1.1 instead of 0.4 ms per step at the
-    # reference dims (profiles/r04_lab_host_stalls.log).  cpu_baseline() sets its own thread counts for its sweep.
+    # reference dims (profiles/archive/r04_lab_host_stalls.log).  cpu_baseline() sets its own thread counts for its sweep.
     torch.set_num_threads(int(os.environ.get('UPAMD_BENCH_THREADS', '1')))      # (the variable: lab A/B only)
 
     # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1 behind Python's back (RCCL prints

@@ -691,7 +691,7 @@ void set_fwd_h_hbm(int on) { g_fwd_h_hbm = on ? 1 : 0; }
 // tune knob fold_layer1 = 2 (lab rule, not the default): fold only when the minibatch's largest graph fits HALF the LDS.  It
 // dates from when the folded kernels had no H-in-HBM / list-in-global forms and ran their large size class at one workgroup
 // per CU; they have both now (edge_fwd_kernel<.., FOLD, HLDS = false>, edge_bwd_kernel<.., FOLD, .., NBG>): DHM 115.5k ->
-// 119.0k samples/s, profiles/r03_lab_fold_two_per_cu.log
+// 119.0k samples/s, profiles/archive/r03_lab_fold_two_per_cu.log
 bool edge_fold_pays(const MbView &mb) {
     return edge_lds_bytes(mb.max_n, mb.max_inc, false, false, true, true) <= LDS_HALF &&
            edge_lds_bytes(mb.max_n, mb.max_inc, true, false, true, true) <= LDS_HALF;
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(EDGE_THREADS) __attribute__((amdgpu_num_sgpr(72), a
             // Exp form: everything NEGATED -- nr = rcp(-(1 + E)) = -r from the negated own-side factors, nr^2 + nr = -(r - r^2) is then
             // a plain FMA, the sums come out as -sum and the sign goes into the final scale.  Bit-identical to r - r^2 summed
             // with the positive sign (negation is exact), and four v_xor_b32 per incidence less: the packed FMAs take no
-            // negation modifier, and the walk is bound by its VALU instruction count (profiles/r03_lab_shared_reciprocal.log)
+            // negation modifier, and the walk is bound by its VALU instruction count (profiles/archive/r03_lab_shared_reciprocal.log)
             // The own-side factors are kept as (column ca, column ca + 1) PAIRS: the neighbour's (Q, Q) and (P, P) are register
             // pairs of its ds_read_b128, so t, nr^2 + nr and the sums are two-wide v_pk_fma_f32 each (16 VALU instructions per
             // incidence instead of 22).

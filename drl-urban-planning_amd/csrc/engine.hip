@@ -19,7 +19,7 @@ using namespace upamd;
 struct SideCtx {
     hipStream_t side = nullptr;
     // a second stream of the same (high) priority for the weight-gradient GEMMs of small minibatches (side_wgrad).  Measured at 256
-    // rows (profiles/r03_lab_rccl_side_stream.log): at NORMAL priority it is the fastest form without a process group (2.39 ms; at high
+    // rows (profiles/archive/r03_lab_rccl_side_stream.log): at NORMAL priority it is the fastest form without a process group (2.39 ms; at high
     // priority the weight gradient runs ahead of the caller's dgrad GEMM, the one on the critical path: 2.47 ms) -- but with RCCL
     // initialised a normal-priority stream shares the caller's hardware queue and the cross-stream events then stall it (3.08 ms
     // against 2.55 ms without side_wgrad).  High priority is the setting that holds in both worlds (2.46-2.47 ms).
@@ -53,7 +53,7 @@ struct upamd_engine {
 namespace {
 
 // tune knob "side_wgrad": the weight-gradient GEMM of GCN layer l on the side stream next to the same layer's dgrad GEMM (dP|dQ
-// alternates between two buffers).  Measured (profiles/r03_lab_side_streams.log): two big GEMMs sharing the matrix pipe lose 2.5 %
+// alternates between two buffers).  Measured (profiles/archive/r03_lab_side_streams.log): two big GEMMs sharing the matrix pipe lose 2.5 %
 // of the 2048-row step, but at <= 256 rows per step neither GEMM fills the chip (2.9 rounds of workgroups) and running them
 // together gains 3 % -- so the default (1) applies it to minibatches of at most SIDE_WGRAD_MAX_NODES nodes; 2 = always, with the
 // weight gradient BEHIND the dgrad, i.e. next to the next layer's message passing (-2 %: the walk and the GEMM slow each other
@@ -430,7 +430,7 @@ static bool pq_exp_layer(const GemmNT &g, int l, int K) { return g_pq_exp && K =
 static int g_fold_layer1 = 1;
 // (1 = fold whenever the slices fit the LDS at all; 2 = only where every graph fits HALF of it.  Measured, round 3: with the
 // K = 32 GEMMs instead of the fold's one-workgroup-per-CU large size class DHM minibatches gain 0.4 %, mixed ones lose 1 %
-// (profiles/r03_lab_fold_rule.log) -- the default stays 1)
+// (profiles/archive/r03_lab_fold_rule.log) -- the default stays 1)
 static bool fold_layer1(const MbView &mb, int L, int K) {
     return g_fold_layer1 && K == 1 && L >= 2 && (g_fold_layer1 == 2 ? edge_fold_pays(mb) : edge_fold_ok(mb));
 }

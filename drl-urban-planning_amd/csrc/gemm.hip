@@ -227,7 +227,7 @@ __device__ __forceinline__ void first_wave_stagger(int mode, int cycles) {
 
 // Workgroup tile (32 TM WM) x (32 TN WN), one (32 TM) x (32 TN) output block per wave.  128 x 128 with 64 x 64 per wave
 // (4 waves) is the measured optimum of the one-block-per-wave forms: 256 x 128 / 128 x 256 with EIGHT waves are 3-5 % slower,
-// 256 x 256 (16 waves on one barrier) 14 % (profiles/r02_gemm_lab.md).  TM / TN > 2 give a wave a bigger block instead (fewer
+// 256 x 256 (16 waves on one barrier) 14 % (profiles/archive/r02_gemm_lab.md).  TM / TN > 2 give a wave a bigger block instead (fewer
 // DMA and fragment-read instructions per MFMA at two waves per SIMD); PRIO raises the wave's priority over its MFMA burst.
 template <int WM, int WN, int TM = 2, int TN = 2, bool PRIO = false>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 4 ? 2 : 1)) void gemm_nt_dma2_kernel(const float *__restrict__ A, int64_t M, int K,
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN > 4 ? 2 : 1)) void gemm_nt_d
 
 // which LDS-DMA configuration a plain panel-major launch uses (0 = the register-staged kernel); set through
 // upamd_tune("gemm_nt_dma", v) by the kernel lab / tests
-// defaults = the best configuration of the kernel lab (tools/gemm_lab*.py, profiles/r02_gemm_lab.md): LDS-DMA staging,
+// defaults = the best configuration of the kernel lab (tools/gemm_lab*.py, profiles/archive/r02_gemm_lab.md): LDS-DMA staging,
 // three workgroups per CU (12 KB of LDS padding), first-residency-round stagger
 static int g_nt_dma_variant = 1, g_stagger_mode = 1, g_stagger_cycles = 37000, g_lds_pad = 12 * 1024;
 static int g_nt_split = 0;                      // 0 | 6 | 9, see launch_gemm_nt_ex

@@ -64,7 +64,7 @@ inline int argmax3(const float *s) {
 // more threads than that only contend).  Eight ranks on a 256-CPU host get 32 threads each instead of 8 x 256.
 // CPUs the container may actually burn: the cgroup's CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  A box that
 // shows 128 CPUs but grants 16 cores' worth of time per period throttles a process that runs 64 busy threads: the whole process is
-// frozen for the rest of the period once the quota is spent (profiles/r04_lab_host_stalls.log saw it with OpenMP; the packer's own
+// frozen for the rest of the period once the quota is spent (profiles/archive/r04_lab_host_stalls.log saw it with OpenMP; the packer's own
 // threads did the same to the packing phase).
 int cgroup_cpu_quota() {
     auto read2 = [](const char *path, long long *a, long long *b) -> int {

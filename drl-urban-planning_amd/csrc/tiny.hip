@@ -16,7 +16,7 @@ using namespace upamd_tiny;
 
 // threads per workgroup: tune knob "tiny_threads".  1024 (default): 4 waves per SIMD at <= 128 VGPRs each (the program needs ~100
 // since the per-phase thread id, see t_tid() in tiny_body.h); the phases are latency-bound and 4 waves hide more of it than the 2
-// of the 512-thread variant: ~12 % faster at the reference dims (profiles/r04_lab_tiny_sections.log).
+// of the 512-thread variant: ~12 % faster at the reference dims (profiles/archive/r04_lab_tiny_sections.log).
 static int g_tiny_threads = 1024;
 void set_tiny_threads(int n) { g_tiny_threads = n == 512 ? 512 : 1024; }
 constexpr int64_t TINY_LDS_LIMIT = 160 * 1024 - 512;

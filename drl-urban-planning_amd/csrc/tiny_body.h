@@ -24,7 +24,7 @@
 //     are added in a fixed order by the reduction launch.
 //
 // What bounds the kernel is the LATENCY of its ~95 dependent phases, not arithmetic (1 MFLOP per graph).  What that took is in
-// profiles/r04_lab_tiny_sections.log: weight rows in registers, every serial LDS sum with eight loads in flight, LDS rows loaded
+// profiles/archive/r04_lab_tiny_sections.log: weight rows in registers, every serial LDS sum with eight loads in flight, LDS rows loaded
 // whole before their FMAs, a per-phase thread id (no cross-phase CSE of address math), staging loads issued together.
 #pragma once
 #include <stdint.h>

@@ -415,7 +415,7 @@ def test_saturating_edge_mlp_on_the_dma_path_matches_oracle(gain, bias, tune):
             sd[k] = sd[k] * gain if k.endswith('weight') else sd[k] + bias
     # gain 400 over THREE layers leaves every tanh saturated to the last ulp: the node-encoder gradient is then the sum of a
     # few O(1) terms whose rounding differs between the exp-form and torch's tanh (rel-L2 3.6e-4 with or without the DMA
-    # path, profiles/r03_diag_saturating.log) -- the tolerance is widened for that case only
+    # path, profiles/archive/r03_diag_saturating.log) -- the tolerance is widened for that case only
     _check_against_oracle(cfg, sd, replay, heads, T, tol=1e-3 if gain >= 100 else (3e-4 if gain > 1 else 1e-4))
 
 

@@ -1,6 +1,6 @@
 """Kernel lab: the register-staged gemm_nt against the LDS-DMA kernel at every workgroup tile, on the shapes of the
 training step (needs a GPU).  Earlier lab rounds (staging variants, stagger, K sweep, occupancy x priority) are
-summarised with their raw logs in profiles/r02_gemm_lab.md."""
+summarised with their raw logs in profiles/archive/r02_gemm_lab.md."""
 import ctypes as C
 import os
 import sys

@@ -4,7 +4,7 @@
         --output-format csv -d out/util -- python bench.py --steps 4 --warmup 1 --cpu-baseline off --no-kernel-events
     python tools/pmc_util.py out/util --md profiles/rNN_pmc_utilisation.md
 
-Normalisation (profiles/r01_pmc_utilisation.md): GRBM_GUI_ACTIVE is summed over the 8 XCDs (/ 8 = kernel duration in
+Normalisation (profiles/archive/r01_pmc_utilisation.md): GRBM_GUI_ACTIVE is summed over the 8 XCDs (/ 8 = kernel duration in
 cycles); SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (/ 1024 = cycles a SIMD's matrix pipe is busy);
 SQ_ACTIVE_INST_VALU counts 4-cycle units per SIMD (/ 1024 * 4)."""
 import argparse
