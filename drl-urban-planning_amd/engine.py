@@ -57,6 +57,7 @@ class NativeEngine:
                 self.tune_overrides.pop(name, None)
             else:
                 self.tune_overrides[name] = int(value)
+                native.note_engine_overrides()
 
     def _on_device(self):
         """Native launches go to the device that is current in the calling thread (the library never calls

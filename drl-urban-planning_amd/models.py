@@ -311,8 +311,11 @@ class _HipBackend:
             cache['flat'] = engine.flatten(named, out=cache.get('flat') if cache.get('device') == device else None)
             cache['version'], cache['device'] = version, device
         B = len(x)
-        states = [s if packer.is_record(s) else
-                  [f.detach().cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in s] for s in x]
+        if isinstance(x, packer.RecordList) and x.addr is not None:
+            states = x                 # records with their address table (the action server's ring): no per-record Python below
+        else:
+            states = [s if packer.is_record(s) else
+                      [f.detach().cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in s] for s in x]
         torch.cuda.current_stream(device).synchronize()      # (the previous round's copies have left the recycled staging buffer)
         pk = packer.pack_replay(states, np.zeros((B, 2), dtype=np.float32), self.shared_net.agent.node_dim,
                                 self.shared_net.agent.numerical_feature_size, reuse=cache.setdefault('pack', {})).to(device)

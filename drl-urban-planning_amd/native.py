@@ -166,6 +166,13 @@ TUNE_DEFAULTS = {'gemm_nt_dma': 1, 'gemm_split': 0, 'fold_layer1': 1, 'he_fused'
 _tune_lock = threading.RLock()
 _tune_depth = threading.local()
 _tune_process = {}            # knob -> process default set through tune()
+_tune_isolation = False       # some engine of this process has (had) overrides: EVERY engine's native calls take the lock from then on
+                              # (an engine without overrides must not enqueue while another engine's temporary values are applied)
+
+
+def note_engine_overrides():
+    global _tune_isolation
+    _tune_isolation = True
 
 
 def tune(name, value):
@@ -179,14 +186,17 @@ def tune(name, value):
 
 class tuned:
     """``with native.tuned({'knob': value, ...}):`` -- the overrides hold for the native calls made inside the block (by this
-    thread; other threads' brackets wait at the lock), the process defaults are restored on the way out.  Empty overrides cost nothing."""
+    thread; other threads' brackets wait at the lock), the process defaults are restored on the way out.  Empty overrides cost
+    nothing until some engine of the process sets an override (``note_engine_overrides``); from then on every bracket takes the lock."""
 
     def __init__(self, overrides):
         self.overrides = overrides
 
     def __enter__(self):
-        if self.overrides:
+        self.locked = bool(self.overrides) or _tune_isolation
+        if self.locked:
             _tune_lock.acquire()
+        if self.overrides:
             _tune_depth.n = getattr(_tune_depth, 'n', 0) + 1
             if _tune_depth.n == 1:              # (an engine's methods call each other: only the outermost bracket applies / restores)
                 L = lib()
@@ -195,14 +205,15 @@ class tuned:
         return self
 
     def __exit__(self, *exc):
-        if self.overrides:
-            try:
+        try:
+            if self.overrides:
                 _tune_depth.n -= 1
                 if _tune_depth.n == 0:
                     L = lib()
                     for name in self.overrides:
                         L.upamd_tune(name.encode(), int(_tune_process.get(name, TUNE_DEFAULTS[name])))
-            finally:
+        finally:
+            if self.locked:
                 _tune_lock.release()
         return False
 

@@ -46,15 +46,50 @@ def _to_record(state):
 
 
 # ------------------------------------------------------------------------------------------------ action serving
+# Transport (round 6): a request RING in shared memory + eventfd wake-ups, no pipes and nothing pickled.  Every client owns one
+# slot: a header (request / response sequence numbers, row count, greedy flag, record sizes, status + error text), the answer
+# (f32 [MAX_ROWS, 2]) and the records.  A client writes its records and header, bumps ``req_seq`` and rings the ONE doorbell
+# eventfd all clients share; the server wakes once per serving round, finds the pending slots with one strided numpy compare
+# (req_seq != resp_seq), answers them with one forward, writes answers + ``resp_seq`` and rings each answered client's own eventfd.
+# (Round 5 moved a pickled (sizes, flag) tuple and a pickled 'ok' through a duplex pipe per request: 2 x 64 send / recv system calls
+# with pickling per 64-row round in the serving thread, which was busy 72-91 % of the time doing that.)
+_H_REQ, _H_RESP, _H_N, _H_MEAN, _H_STATUS, _H_ERRLEN, _H_SIZES = 0, 8, 16, 20, 24, 28, 32
+_ERR_CAP = 480
+
+
+def _eventfd():
+    import os
+    return os.eventfd(0, os.EFD_NONBLOCK)
+
+
+def _efd_wait(fd, timeout):
+    """True when the eventfd was signalled within `timeout` seconds (the counter is consumed)."""
+    import os
+    import select
+    r, _, _ = select.select([fd], [], [], timeout)
+    if not r:
+        return False
+    try:
+        os.eventfd_read(fd)
+    except BlockingIOError:
+        return False
+    return True
+
+
 class ActionClient:
     """Worker-side handle: ``select_action(x, mean_action)`` like ``UrbanPlanningPolicy.select_action``."""
 
     MAX_ROWS = 64
+    HDR = _align(_H_SIZES + 4 * MAX_ROWS + _ERR_CAP)     # header + record sizes + error text
+    ACT = HDR                                            # answers: f32 [MAX_ROWS, 2]
+    REC = _align(HDR + 8 * MAX_ROWS)                     # first record
 
-    def __init__(self, shm_name, index, slot_bytes, conn, timeout_s=120.0):
-        self._shm_name, self.index, self.slot_bytes, self.conn = shm_name, index, slot_bytes, conn
+    def __init__(self, shm_name, index, slot_bytes, doorbell, wake, timeout_s=120.0):
+        self._shm_name, self.index, self.slot_bytes = shm_name, index, slot_bytes
+        self.doorbell, self.wake = doorbell, wake        # eventfds: the server's (shared by all clients), this client's own
         self.timeout_s = timeout_s            # a dead server must not hang the sampling phase for ever
         self._shm = None
+        self._seq = 0
         self._dead = None                     # set after a timeout: the request is still in flight on the shared slot
         self.type = 'discrete'
 
@@ -64,13 +99,24 @@ class ActionClient:
         base = self.index * self.slot_bytes
         return np.ndarray((self.slot_bytes,), dtype=np.uint8, buffer=self._shm.buf, offset=base)
 
+    def post(self, sizes, mean_action):
+        """Publish a request whose records already sit in the slot (``select_action`` does both; tests post by hand)."""
+        import os
+        slot = self._slot()
+        slot[_H_N:_H_N + 8].view(np.uint32)[:] = (len(sizes), 1 if mean_action else 0)
+        slot[_H_SIZES:_H_SIZES + 4 * len(sizes)].view(np.uint32)[:] = sizes
+        req = slot[_H_REQ:_H_REQ + 8].view(np.uint64)
+        self._seq = int(req[0]) + 1             # (continues the SLOT's sequence: a fresh handle on a used slot is fine)
+        req[0] = self._seq                      # published last (x86: stores stay in order)
+        os.eventfd_write(self.doorbell, 1)
+
     def select_action(self, x, mean_action=False):
         if self._dead is not None:
             raise RuntimeError('action client %d is closed: %s' % (self.index, self._dead))
         if len(x) > self.MAX_ROWS:
             raise ValueError('at most %d states per request' % self.MAX_ROWS)
         slot = self._slot()
-        cursor = _align(8 * self.MAX_ROWS)
+        cursor = self.REC
         sizes = []
         for s in x:
             rec = _to_record(s)
@@ -79,20 +125,24 @@ class ActionClient:
             slot[cursor:cursor + rec.size] = rec
             sizes.append(int(rec.size))
             cursor = _align(cursor + rec.size)
-        self.conn.send((sizes, bool(mean_action)))
-        if not self.conn.poll(self.timeout_s):
-            # the request stays in flight: the server may still read or answer it on the shared slot, and its late 'ok'
-            # would be taken for the answer to the NEXT request -- this client is finished
-            self._dead = 'a request timed out after %.0f s and may still be in flight' % self.timeout_s
-            try:
-                self.conn.close()
-            except OSError:
-                pass
-            raise TimeoutError('action server did not answer within %.0f s (is its serving thread alive?)' % self.timeout_s)
-        status = self.conn.recv()
-        if status != 'ok':
-            raise RuntimeError('action server: %s' % status)
-        act = slot[:8 * len(x)].view(np.float32).reshape(len(x), 2).copy()
+        self.post(sizes, mean_action)
+        deadline = time.monotonic() + self.timeout_s
+        resp = slot[_H_RESP:_H_RESP + 8].view(np.uint64)
+        while int(resp[0]) != self._seq:
+            left = deadline - time.monotonic()
+            if left <= 0 or not _efd_wait(self.wake, left):
+                if int(resp[0]) == self._seq:
+                    break
+                if time.monotonic() < deadline:
+                    continue
+                # the request stays in flight: the server may still read or answer it on the shared slot -- this client is finished
+                self._dead = 'a request timed out after %.0f s and may still be in flight' % self.timeout_s
+                raise TimeoutError('action server did not answer within %.0f s (is its serving thread alive?)' % self.timeout_s)
+        status, err_len = (int(v) for v in slot[_H_STATUS:_H_STATUS + 8].view(np.uint32))
+        if status != 0:
+            text = bytes(slot[_H_SIZES + 4 * self.MAX_ROWS:_H_SIZES + 4 * self.MAX_ROWS + min(err_len, _ERR_CAP)]).decode('utf-8', 'replace')
+            raise RuntimeError('action server: %s' % text)
+        act = slot[self.ACT:self.ACT + 8 * len(x)].view(np.float32).reshape(len(x), 2).copy()
         return torch.from_numpy(act)
 
     def close(self):
@@ -106,12 +156,18 @@ class ActionServer:
 
     def __init__(self, policy_net, num_clients, slot_bytes=1 << 20, linger_s=0.0002, mp_context=None):
         self.policy_net = policy_net
-        self.num_clients, self.slot_bytes, self.linger_s = num_clients, _align(slot_bytes), linger_s
-        ctx = mp_context or multiprocessing.get_context('fork')
+        self.num_clients, self.slot_bytes, self.linger_s = num_clients, _align(max(slot_bytes, ActionClient.REC + 4096)), linger_s
         self.shm = shared_memory.SharedMemory(create=True, size=num_clients * self.slot_bytes)
-        self.pipes = [ctx.Pipe(duplex=True) for _ in range(num_clients)]
-        self._server_ends = [p[0] for p in self.pipes]
-        self._index_of = {id(c): i for i, c in enumerate(self._server_ends)}
+        np.ndarray((num_clients * self.slot_bytes,), dtype=np.uint8, buffer=self.shm.buf)[:] = 0
+        self.doorbell = _eventfd()                      # every client rings this one: ONE wake-up of the serving thread per round
+        self.wakes = [_eventfd() for _ in range(num_clients)]
+        n, sb, buf = num_clients, self.slot_bytes, self.shm.buf
+        # strided views over all slots at once: the pending scan and the answers are a handful of vector operations per round
+        self._seqs = np.ndarray((n, 2), dtype=np.uint64, buffer=buf, strides=(sb, 8))                  # req_seq, resp_seq
+        self._ctl = np.ndarray((n, 4), dtype=np.uint32, buffer=buf, offset=_H_N, strides=(sb, 4))      # n, mean, status, err_len
+        self._sizes = np.ndarray((n, ActionClient.MAX_ROWS), dtype=np.uint32, buffer=buf, offset=_H_SIZES, strides=(sb, 4))
+        self._acts = np.ndarray((n, ActionClient.MAX_ROWS, 2), dtype=np.float32, buffer=buf, offset=ActionClient.ACT, strides=(sb, 8, 4))
+        self._base = np.frombuffer(buf, dtype=np.uint8).ctypes.data
         self.stats = dict(batches=0, requests=0, rows=0, max_rows=0, busy_s=0.0)
         self.fast = True                # GPU modules: models._HipBackend.serve_actions instead of policy_net.forward + Categorical over pads
         self.last_error = None
@@ -120,69 +176,84 @@ class ActionServer:
         self._stop = threading.Event()
 
     def client(self, i):
-        return ActionClient(self.shm.name, i, self.slot_bytes, self.pipes[i][1])
+        return ActionClient(self.shm.name, i, self.slot_bytes, self.doorbell, self.wakes[i])
 
     def _slot(self, i):
         return np.ndarray((self.slot_bytes,), dtype=np.uint8, buffer=self.shm.buf, offset=i * self.slot_bytes)
 
+    def _answer(self, idx, error=None):
+        """publish the answers of the slots `idx` (their actions are already in place) and wake their clients"""
+        import os
+        if error is not None:
+            raw = error.encode('utf-8', 'replace')[:_ERR_CAP]
+            for i in idx:
+                s = self._slot(int(i))
+                s[_H_SIZES + 4 * ActionClient.MAX_ROWS:_H_SIZES + 4 * ActionClient.MAX_ROWS + len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+            self._ctl[idx, 2], self._ctl[idx, 3] = 1, len(raw)
+        else:
+            self._ctl[idx, 2] = 0
+        self._seqs[idx, 1] = self._seqs[idx, 0]         # published last
+        for i in idx:
+            os.eventfd_write(self.wakes[int(i)], 1)
+
     def serve_once(self, timeout=0.05):
         """Waits up to ``timeout`` for a request, lingers ``linger_s`` for the other workers' requests to arrive, then
         answers all of them with one forward.  Returns the number of requests answered."""
-        live = [c for c in self._server_ends if not c.closed]
-        ready = multiprocessing.connection.wait(live, timeout)
-        if not ready:
-            return 0
+        if not _efd_wait(self.doorbell, timeout):
+            if not (self._seqs[:, 0] != self._seqs[:, 1]).any():      # (a ring that raced with the previous round's scan)
+                return 0
         if self.linger_s > 0:
             time.sleep(self.linger_s)
-        reqs = []                                   # (client index, conn, sizes, mean)
-        for conn in live:
-            try:
-                if conn.poll(0):
-                    sizes, mean = conn.recv()
-                    reqs.append((self._index_of[id(conn)], conn, sizes, mean))
-            except (EOFError, OSError):
-                conn.close()
-        if not reqs:
+        pend = np.flatnonzero(self._seqs[:, 0] != self._seqs[:, 1])
+        if pend.size == 0:
             return 0
-        # From here on every request has been taken off its pipe: whatever happens, its worker gets an answer
+        # From here on every pending request is taken: whatever happens, its worker gets an answer
         t0 = time.perf_counter()
-        states, owner = [], []
-        try:
-            for i, conn, sizes, mean in reqs:
-                slot = self._slot(i)
-                cursor = _align(8 * ActionClient.MAX_ROWS)
-                if len(sizes) > ActionClient.MAX_ROWS:
-                    raise ValueError('request of client %d: more than %d states' % (i, ActionClient.MAX_ROWS))
-                for sz in sizes:
-                    if sz <= 0 or cursor + sz > self.slot_bytes:
-                        raise ValueError('request of client %d does not fit its slot' % i)
-                    states.append(slot[cursor:cursor + sz])
-                    owner.append(mean)
-                    cursor = _align(cursor + sz)
-            actions = self._actions(states, np.asarray(owner, dtype=bool))
-            status = 'ok'
-        except Exception as exc:                    # report to the workers instead of dying silently
-            import traceback
-            actions, status = None, '%s: %s' % (type(exc).__name__, exc)
-            self.last_error = status
-            self.last_traceback = traceback.format_exc()
-        row = 0
-        for i, conn, sizes, mean in reqs:
-            if actions is not None:
-                out = actions[row:row + len(sizes)]
-                self._slot(i)[:8 * len(sizes)] = np.ascontiguousarray(out, dtype=np.float32).view(np.uint8).reshape(-1)
-            row += len(sizes)
+        cnt = self._ctl[pend, 0].astype(np.int64)
+        mean = self._ctl[pend, 1] != 0
+        good, states, addrs, sizes_all, owner, rows_of = [], [], [], [], [], []
+        for j, i in enumerate(pend):
+            n, i = int(cnt[j]), int(i)
+            sz = self._sizes[i, :max(min(n, ActionClient.MAX_ROWS), 0)].astype(np.int64)
+            off = ActionClient.REC + np.concatenate([[0], np.cumsum((sz[:-1] + _ALIGN - 1) // _ALIGN * _ALIGN)]) if n > 0 else np.zeros(0, np.int64)
+            if n <= 0 or n > ActionClient.MAX_ROWS or (sz <= 0).any() or (off + sz > self.slot_bytes).any():
+                self.last_error = 'ValueError: request of client %d does not fit its slot (%d states)' % (i, n)
+                self._answer(np.array([i]), self.last_error)
+                continue
+            slot = self._slot(i)
+            good.append(i)
+            rows_of.append(n)
+            for o, z in zip(off, sz):
+                states.append(slot[int(o):int(o) + int(z)])
+            addrs.append(self._base + i * self.slot_bytes + off)
+            sizes_all.append(sz)
+            owner.append(np.full(n, mean[j]))
+        n_req = len(pend)
+        if good:
+            good = np.asarray(good)
             try:
-                conn.send(status)
-            except (BrokenPipeError, OSError):      # that worker is gone; the others still get their answers
-                conn.close()
+                recs = packer.RecordList(states, np.concatenate(addrs).astype(np.uint64), np.concatenate(sizes_all))
+                actions = np.ascontiguousarray(self._actions(recs, np.concatenate(owner)), dtype=np.float32)
+                row = 0
+                if all(r == 1 for r in rows_of):
+                    self._acts[good, 0, :] = actions
+                else:
+                    for i, r in zip(good, rows_of):
+                        self._acts[int(i), :r, :] = actions[row:row + r]
+                        row += r
+                self._answer(good)
+            except Exception as exc:                    # report to the workers instead of dying silently
+                import traceback
+                self.last_error = '%s: %s' % (type(exc).__name__, exc)
+                self.last_traceback = traceback.format_exc()
+                self._answer(good, self.last_error)
         st = self.stats
         st['batches'] += 1
-        st['requests'] += len(reqs)
+        st['requests'] += n_req
         st['rows'] += len(states)
         st['max_rows'] = max(st['max_rows'], len(states))
         st['busy_s'] += time.perf_counter() - t0
-        return len(reqs)
+        return n_req
 
     def _actions(self, states, mean_rows):
         """One forward for all rows; per row arg-max (mean_action) or a sample (policy.py:67-85)."""
@@ -219,6 +290,11 @@ class ActionServer:
 
     def start(self):
         if self._thread is None:
+            # a serving phase starts from the parameters as they are NOW: the lean route's flattened copy is keyed on the parameters'
+            # version counters, which writes through `p.data` (legacy optimizers, weight surgery) do not bump
+            backend = getattr(self.policy_net, '_backend', [None])[0]
+            if backend is not None and isinstance(getattr(backend, '__dict__', {}).get('_serve'), dict):
+                backend.__dict__['_serve'].pop('version', None)
             self._stop.clear()
             self._thread = threading.Thread(target=self._loop, name='upamd-action-server', daemon=True)
             self._thread.start()
@@ -228,18 +304,17 @@ class ActionServer:
         while not self._stop.is_set():
             try:
                 self.serve_once(timeout=0.02)
-            except Exception as exc:                # a broken pipe, an OSError from wait(): tell whoever is waiting, keep serving
+            except Exception as exc:                # tell whoever is waiting, keep serving
                 import traceback
                 self.stats['errors'] = self.stats.get('errors', 0) + 1
                 self.last_error = '%s: %s' % (type(exc).__name__, exc)
                 self.last_traceback = traceback.format_exc()
-                for conn in self._server_ends:
-                    try:
-                        if not conn.closed and conn.poll(0):
-                            conn.recv()
-                            conn.send(self.last_error)
-                    except (EOFError, OSError):
-                        conn.close()
+                try:
+                    pend = np.flatnonzero(self._seqs[:, 0] != self._seqs[:, 1])
+                    if pend.size:
+                        self._answer(pend, self.last_error)
+                except Exception:
+                    pass
 
     def stop(self):
         if self._thread is not None:
@@ -248,11 +323,19 @@ class ActionServer:
             self._thread = None
 
     def close(self):
+        import os
         self.stop()
-        for a, b in self.pipes:
-            a.close()
-            b.close()
-        self.shm.close()
+        for fd in [self.doorbell] + self.wakes:
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+        self.wakes, self.doorbell = [], -1
+        self._seqs = self._ctl = self._sizes = self._acts = None       # (views export the mapping's buffer)
+        try:
+            self.shm.close()
+        except BufferError:
+            pass
         try:
             self.shm.unlink()
         except FileNotFoundError:

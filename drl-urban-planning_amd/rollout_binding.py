@@ -25,13 +25,12 @@
     evaluated weights are kept (a CPU ``state_dict``), and ``save_checkpoint`` writes ``best.p`` from THEM, so a best
     checkpoint still pairs a reward with the weights that earned it.
 
-Checkpoints (always on, no switch): ``save_checkpoint`` adds ``'hip_optimizer'`` -- ``PPOUpdater.state_dict()``: Adam
+Checkpoints (on by default; ``UPAMD_CKPT_OPTIMIZER=0`` writes / resumes exactly as the reference does): ``save_checkpoint`` adds ``'hip_optimizer'`` -- ``PPOUpdater.state_dict()``: Adam
 moments, per-group step counts, the first-step clipping flag -- to every file the reference's ``save_checkpoint``
 (:172-194) has just written, and ``load_checkpoint`` (:153-170) of a FRESH process restores it, so a resumed run
 continues the Adam trajectory instead of restarting it (the reference omits optimizer state).  Files without the key load
 as before; a load in the middle of a run (``freeze_land_use``, :215-222) leaves Adam alone, as the reference's does.
 """
-import glob
 import math
 import os
 import pickle
@@ -302,6 +301,8 @@ class CheckpointMixin:
                 state = pickle.load(fh).get('hip_optimizer')
         except (OSError, AttributeError):
             state = None
+        if os.environ.get('UPAMD_CKPT_OPTIMIZER', '1') == '0':
+            state = None                        # resume as the reference does: fresh Adam moments, first-step clip re-armed
         # the updater is built lazily (its hyper-parameters are set by AgentPPO.__init__, which runs AFTER load_checkpoint,
         # urban_planning_agent.py:38-47) and Adam's buffers live on the GPU: parked here, applied by the next update_params
         up = getattr(self, '_upamd_updater', None)
@@ -314,9 +315,20 @@ class CheckpointMixin:
             up.pending_state = state
         return start
 
+    def _upamd_cp_written(self, iteration, best):
+        """The files the reference's ``save_checkpoint`` (:172-194) writes for this call, from ITS conditions -- not guessed from
+        modification times."""
+        cfg, out = self.cfg, []
+        interval = getattr(cfg, 'save_model_interval', 0) or 0
+        if interval > 0 and (iteration + 1) % interval == 0:
+            out.append('{}/iteration_{:04d}.p'.format(cfg.model_dir, iteration + 1))
+        if best:
+            out.append('{}/best.p'.format(cfg.model_dir))
+            out.append('{}/best_reward{:.2f}_iteration_{:04d}.p'.format(cfg.model_dir, self.best_rewards, iteration + 1))
+        return out
+
     def save_checkpoint(self, iteration):
-        model_dir = self.cfg.model_dir
-        before = {p: os.stat(p).st_mtime_ns for p in glob.glob(os.path.join(model_dir, '*.p'))}
+        written = self._upamd_cp_written(iteration, bool(getattr(self, 'save_best_flag', False)))
         swap = getattr(self, '_upamd_eval_sd', None) if (getattr(self, 'save_best_flag', False) and
                                                          os.environ.get('UPAMD_EVAL') == 'overlap') else None
         if swap is None:
@@ -336,16 +348,22 @@ class CheckpointMixin:
             finally:
                 cfg.save_model_interval = interval
                 net.load_state_dict(current)
+        if os.environ.get('UPAMD_CKPT_OPTIMIZER', '1') == '0':
+            return                              # the reference's files as the reference writes them (a resume then restarts Adam, as its does)
         up = getattr(self, '_upamd_updater', None)
         state = up.state_dict() if (up is not None and up.m is not None) else getattr(self, '_upamd_pending_opt', None)
         if state is None:
             return
-        for p in glob.glob(os.path.join(model_dir, '*.p')):
-            if before.get(p) == os.stat(p).st_mtime_ns:
-                continue                        # not written by this call
+        for p in written:
+            if not os.path.exists(p):
+                continue                        # (a stand-in class with its own file policy: nothing to extend)
             with open(p, 'rb') as fh:
                 cp = pickle.load(fh)
             if isinstance(cp, dict) and 'actor_critic_dict' in cp:
                 cp['hip_optimizer'] = state
-                with open(p, 'wb') as fh:
+                tmp = p + '.upamd_tmp'
+                with open(tmp, 'wb') as fh:     # never a truncated checkpoint: written beside it, then renamed over it
                     pickle.dump(cp, fh)
+                    fh.flush()
+                    os.fsync(fh.fileno())
+                os.replace(tmp, p)

@@ -195,8 +195,9 @@ class _ReferenceLikeAgent:
         import pickle
         cp = {'actor_critic_dict': {k: v.detach().cpu() for k, v in self.actor_critic_net.state_dict().items()},
               'loss_iter': self.loss_iter, 'best_rewards': self.best_rewards, 'iteration': iteration}
-        with open('%s/iteration_%04d.p' % (self.cfg.model_dir, iteration + 1), 'wb') as fh:
-            pickle.dump(cp, fh)
+        if self.cfg.save_model_interval > 0 and (iteration + 1) % self.cfg.save_model_interval == 0:       # (:186)
+            with open('%s/iteration_%04d.p' % (self.cfg.model_dir, iteration + 1), 'wb') as fh:
+                pickle.dump(cp, fh)
 
     def load_checkpoint(self, checkpoint, restore_best_rewards):
         import pickle
@@ -231,6 +232,7 @@ def _bound_agent(tmp_path, name, num_threads=3, seed=None, load_sd=True):
     kw = helpers.CASE_MODEL[name]
     cfg = helpers.make_cfg(**kw)
     cfg.model_dir = str(tmp_path)
+    cfg.save_model_interval = 1
     policy_net, value_net, ac = helpers.build_product(cfg, seed=0 if seed is None else seed)
     if load_sd:
         ac.load_state_dict(sd)

@@ -536,6 +536,34 @@ def test_checkpoints_carry_the_optimizer_state_through_the_real_save_and_load(tm
     up.pending_state = None
     ag.load_checkpoint(1, True)                             # mid-run (the updater has stepped): Adam is left alone
     assert up.pending_state is None
+    # the extended file was renamed into place (no temporary left behind), and only the files the reference's conditions name were
+    # touched: a best save adds best.p and best_reward..., both with the key
+    assert not [f for f in os.listdir(ag.cfg.model_dir) if f.endswith('.upamd_tmp')]
+    ag.save_best_flag, ag.best_rewards = True, 1.25
+    ag.save_checkpoint(1)
+    names = sorted(f for f in os.listdir(ag.cfg.model_dir) if f.endswith('.p'))
+    assert names == ['best.p', 'best_reward1.25_iteration_0002.p', 'iteration_0001.p', 'iteration_0002.p'], names
+    assert all('hip_optimizer' in pickle.load(open(os.path.join(ag.cfg.model_dir, f), 'rb')) for f in names)
+
+
+@needs_reference
+def test_checkpoint_optimizer_state_can_be_switched_off(tmp_path, monkeypatch):
+    """UPAMD_CKPT_OPTIMIZER=0: the files are exactly what the reference writes (no extra key, written once), and a resume from a file
+    that HAS the key ignores it -- Adam restarts, as the reference's resumed run does."""
+    ref = ref_import.load_reference()
+    mod = patched_module(tmp_path)
+    ag, _ = _rollout_agent(tmp_path, cls=mod.UrbanPlanningAgent, ref=ref)
+    up = ag._hip_updater()
+    state = {'group_steps': [3, 3, 0], 'loss_iter': 9, 'clip_pending': False, 'group_seen': [True, True, False],
+             'exp_avg': {'x': torch.arange(3.0)}, 'exp_avg_sq': {'x': torch.ones(3)}}
+    up.m, up.state_dict = object(), lambda: state
+    ag.save_checkpoint(0)                                   # with the key
+    monkeypatch.setenv('UPAMD_CKPT_OPTIMIZER', '0')
+    ag.save_checkpoint(1)                                   # without
+    assert 'hip_optimizer' in pickle.load(open(os.path.join(ag.cfg.model_dir, 'iteration_0001.p'), 'rb'))
+    assert 'hip_optimizer' not in pickle.load(open(os.path.join(ag.cfg.model_dir, 'iteration_0002.p'), 'rb'))
+    fresh, _ = _rollout_agent(tmp_path, cls=mod.UrbanPlanningAgent, ref=ref, seed=9)
+    assert fresh.load_checkpoint(1, True) == 1 and fresh._upamd_pending_opt is None
 
 
 @needs_reference

@@ -1,4 +1,4 @@
-"""Rollout transport and batched action serving on the CPU path (forked workers, shared memory, pipes): the same
+"""Rollout transport and batched action serving on the CPU path (forked workers, shared memory, eventfd doorbells): the same
 server object serves the HIP modules on a GPU box (tests/test_gpu_rollout.py)."""
 import multiprocessing as mp
 
@@ -141,16 +141,16 @@ def test_a_silent_server_times_the_client_out_and_a_dead_client_does_not_stall_t
         slow.select_action([rep.states[0]], True)
     assert time.perf_counter() - t0 < 5.0
     # the timed-out request is still in flight on the shared slot: the client is finished (a retry would overwrite the slot
-    # under the server and take the stale 'ok' for its own answer), and the server survives answering into the closed pipe
+    # under the server and take the stale 'ok' for its own answer), and the server survives answering a client that no longer listens
     with pytest.raises(RuntimeError, match='closed'):
         slow.select_action([rep.states[0]], True)
     assert server.serve_once(timeout=0.5) in (0, 1)
-    # client 1 dies after sending its request (its pipe end is closed); client 2 must still get its answer
+    # client 1 dies after posting its request; client 2 must still get its answer
     dead = server.client(1)
     rec = packer.compact_state(rep.states[1])
-    dead._slot()[rollout._align(8 * rollout.ActionClient.MAX_ROWS):][:rec.size] = rec
-    dead.conn.send(([int(rec.size)], True))
-    dead.conn.close()
+    dead._slot()[rollout.ActionClient.REC:][:rec.size] = rec
+    dead.post([int(rec.size)], True)            # ... and nobody will ever wait for the answer
+    dead.close()
     out = []
     t = threading.Thread(target=lambda: out.append(server.client(2).select_action([rep.states[2]], True)))
     t.start()
@@ -165,9 +165,11 @@ def test_a_silent_server_times_the_client_out_and_a_dead_client_does_not_stall_t
     assert out and torch.equal(out[0], want)
     # a request whose sizes do not fit the slot is refused with an error string, not an exception in the serving thread
     bad = server.client(3)
-    bad.conn.send(([1 << 30], True))
+    bad.post([1 << 30], True)
     assert server.serve_once(timeout=0.5) == 1
-    assert 'does not fit' in bad.conn.recv() and 'does not fit' in server.last_error
+    hdr = bad._slot()
+    assert int(hdr[rollout._H_STATUS:rollout._H_STATUS + 4].view(np.uint32)[0]) == 1 and 'does not fit' in server.last_error
+    assert int(hdr[rollout._H_RESP:rollout._H_RESP + 8].view(np.uint64)[0]) == 1          # answered: the worker would wake up with the error
     server.close()
 
 

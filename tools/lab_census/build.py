@@ -99,6 +99,13 @@ patch('edge.hip', [
      '        dbias_part[(int64_t)b * (NP * 32) + p * 32 + pq_pos(which, cc)] = tot;\n    }\n    if (tid == 0) census_end(census_slot);\n}\n', 1),
     ('void set_bwd_nb_global(int on) { g_bwd_nb_global = on ? 1 : 0; }\n',
      'void set_bwd_nb_global(int on) { g_bwd_nb_global = on ? 1 : 0; }\nvoid set_census_edge(void *buf) { census_set_tu(buf); }\n', 1),
+    # lab knob UPAMD_LAB_EDGE_LDS=<bytes>: every message-passing launch asks for at least this much dynamic LDS, i.e. the number of
+    # walk workgroups a CU can hold is set by hand (96 KB -> ONE per CU, with 64 KB left for two 32 KB GEMM workgroups)
+    ('    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool hlds = true) -> int {\n',
+     '    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool hlds = true) -> int {\n        { const char *ev_ = getenv("UPAMD_LAB_EDGE_LDS"); if (ev_ && atoll(ev_) > lds) lds = atoll(ev_); }\n', 1),
+    ('    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool nbg = false) -> int {\n',
+     '    auto go = [&](bool stage, int64_t lds, int aux_cap, int fit, bool nbg = false) -> int {\n        { const char *ev_ = getenv("UPAMD_LAB_EDGE_LDS"); if (ev_ && atoll(ev_) > lds) lds = atoll(ev_); }\n', 1),
+    ('#include <type_traits>\n', '#include <cstdlib>\n#include <type_traits>\n', 1),
 ])
 
 # the census buffer comes in through the (otherwise unused at D = 256) lab hook upamd_tiny_profile

@@ -139,7 +139,8 @@ def main():
     ap.add_argument('--tune', default='')
     ap.add_argument('--rows', type=int, default=2048)
     ap.add_argument('--steps', type=int, default=12)
-    ap.add_argument('--census', type=int, default=1, help='0: time only (product library)')
+    ap.add_argument('--census', type=int, default=1, help='0: time only on the product library; 2: time only on the census build '
+                                                           '(its lab knob UPAMD_LAB_EDGE_LDS included); 1: census build, one step recorded')
     ap.add_argument('--out', default='')
     args = ap.parse_args()
     census_lib = os.path.join(ROOT, 'tools', 'lab_census', 'csrc', 'libupamd.so')
@@ -192,8 +193,9 @@ def main():
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
     res = {'mode': args.mode, 'tune': tune, 'rows_per_round': rows * lanes, 'lanes': lanes, 'ms_per_round': ms,
-           'samples_per_s': rows * lanes / ms * 1e3, 'library': 'census build' if args.census else 'product'}
-    if args.census:
+           'samples_per_s': rows * lanes / ms * 1e3, 'library': 'census build' if args.census else 'product',
+           'edge_lds_floor': os.environ.get('UPAMD_LAB_EDGE_LDS')}
+    if args.census == 1:
         cap = 700000
         buf = torch.zeros(8 + 8 * cap, dtype=torch.int64, device=dev)
         buf[1] = cap
