@@ -212,7 +212,18 @@ class ActionServer:
         cnt = self._ctl[pend, 0].astype(np.int64)
         mean = self._ctl[pend, 1] != 0
         good, states, addrs, sizes_all, owner, rows_of = [], [], [], [], [], []
-        for j, i in enumerate(pend):
+        sb = self.slot_bytes
+        sz1 = self._sizes[pend, 0].astype(np.int64)
+        single = bool((cnt == 1).all() and (sz1 > 0).all() and (ActionClient.REC + sz1 <= sb).all())
+        if single:
+            # the common round -- every worker asks about ONE state (sample_worker, urban_planning_agent.py:60-61): no per-request
+            # arithmetic, one slice per record
+            flat = np.frombuffer(self.shm.buf, dtype=np.uint8)
+            first = pend.astype(np.int64) * sb + ActionClient.REC
+            states = [flat[a:a + z] for a, z in zip(first.tolist(), sz1.tolist())]
+            good, rows_of = pend.tolist(), [1] * pend.size
+            addrs, sizes_all, owner = [self._base + first], [sz1], [mean]
+        for j, i in enumerate(pend if not single else ()):
             n, i = int(cnt[j]), int(i)
             sz = self._sizes[i, :max(min(n, ActionClient.MAX_ROWS), 0)].astype(np.int64)
             off = ActionClient.REC + np.concatenate([[0], np.cumsum((sz[:-1] + _ALIGN - 1) // _ALIGN * _ALIGN)]) if n > 0 else np.zeros(0, np.int64)
