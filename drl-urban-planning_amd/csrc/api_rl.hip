@@ -34,6 +34,23 @@ extern "C" int upamd_ppo_loss_rows(int32_t B, const float *value_dev, const floa
                            dlogp_dev, dent_dev, losses_dev, zero_dev, n_zero, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int upamd_select_actions(const void *packed_dev, const upamd_pack_layout *layout, const upamd_minibatch *mb,
+                                    const float *z_he_dev, const float *z_rn_dev, const uint8_t *greedy_dev,
+                                    const float *uniform_dev, float *actions_dev, void *stream) {
+    if (!packed_dev || !layout || !mb || !greedy_dev || !uniform_dev || !actions_dev)
+        return fail(UPAMD_E_INVALID, "upamd_select_actions: null pointer");
+    if (mb->B <= 0) return fail(UPAMD_E_INVALID, "upamd_select_actions: B must be > 0");
+    if (!mb->idx_dev || !mb->he_off_dev || !mb->rn_off_dev) return fail(UPAMD_E_INVALID, "upamd_select_actions: minibatch schedule pointers are null");
+    if ((mb->n_he > 0 && !z_he_dev) || (mb->n_rn > 0 && !z_rn_dev))
+        return fail(UPAMD_E_INVALID, "upamd_select_actions: the minibatch has candidates but their logits are null");
+    const char *b = static_cast<const char *>(packed_dev);
+    return launch_select_actions(mb->B, reinterpret_cast<const int32_t *>(b + layout->off_meta),
+                                 reinterpret_cast<const int32_t *>(b + layout->off_he_slot),
+                                 reinterpret_cast<const uint16_t *>(b + layout->off_rn_node), mb->idx_dev, mb->he_off_dev,
+                                 mb->rn_off_dev, z_he_dev, z_rn_dev, greedy_dev, uniform_dev, actions_dev,
+                                 static_cast<hipStream_t>(stream));
+}
+
 extern "C" int upamd_gae(int64_t T, const float *rewards_dev, const float *masks_dev, const float *values_dev,
                          double gamma, double tau, float *adv_dev, float *ret_dev, void *stream) {
     if (T <= 0) return fail(UPAMD_E_INVALID, "upamd_gae: T must be > 0");

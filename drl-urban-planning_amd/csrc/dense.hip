@@ -230,4 +230,94 @@ int launch_clip_scale(float *g, int64_t n, const float *sumsq, float max_norm, h
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// select_action (urban_planning/models/policy.py:67-85) for a batch of rows, from the RAGGED pointer-head logits: one wave per
+// row.  The reference builds a Categorical over the PADDED edge / node slots with the pad constant -2^32 + 1 in the masked ones
+// (policy.py:50-52, 59-61): their probability is exactly 0, so the distribution over the row's own candidates is the same
+// distribution, and its arg-max (first maximum in slot order: candidates are stored in slot order) the same arg-max.
+//   greedy[b] != 0 : arg-max                       (mean_action, :76-77 / :82-83)
+//   else           : one draw by inverse CDF with the row's uniform u[b] in [0, 1): the smallest candidate j whose
+//                    running sum of exp(z - max) exceeds u * total  (Categorical.sample's distribution; the uniforms come
+//                    from the caller's generator)
+// A row without any candidate is the reference's uniform Categorical over the padded slots (arg-max: slot 0).
+// Output: actions[b] = (edge slot, 0) for a land-use row, (0, node) for a road row, (0, 0) for any other stage.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void select_actions_kernel(const int32_t *__restrict__ meta, const int32_t *__restrict__ he_slot,
+                                                            const uint16_t *__restrict__ rn_node, const int32_t *__restrict__ idx,
+                                                            const int32_t *__restrict__ he_off, const int32_t *__restrict__ rn_off,
+                                                            const float *__restrict__ z_he, const float *__restrict__ z_rn,
+                                                            const uint8_t *__restrict__ greedy, const float *__restrict__ uniform,
+                                                            float *__restrict__ actions) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int32_t *m = meta + (int64_t)idx[b] * UPAMD_META_STRIDE;
+    const int stage = m[4];
+    float a0 = 0.f, a1 = 0.f;
+    if (stage == 0 || stage == 1) {
+        const int lo = stage == 0 ? he_off[b] : rn_off[b];
+        const int cnt = (stage == 0 ? he_off[b + 1] : rn_off[b + 1]) - lo;
+        const float *z = (stage == 0 ? z_he : z_rn) + lo;
+        float pick;
+        if (cnt <= 0) {
+            const int pad = stage == 0 ? m[8] : m[7];
+            pick = greedy[b] ? 0.f : floorf(fminf(uniform[b], 0.99999994f) * (float)(pad > 0 ? pad : 1));
+        } else {
+            // maximum and its first position
+            float mx = -INFINITY;
+            int arg = 0x7fffffff;
+            for (int j = lane; j < cnt; j += 64) {
+                const float v = z[j];
+                if (v > mx) { mx = v; arg = j; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const float om = __shfl_xor(mx, off);
+                const int oa = __shfl_xor(arg, off);
+                if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+            }
+            int k = arg;
+            if (!greedy[b]) {
+                float tot = 0.f;
+                for (int j = lane; j < cnt; j += 64) tot += __expf(z[j] - mx);
+                for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+                const float target = uniform[b] * tot;
+                float run = 0.f;           // sum of the weights of all candidates before this chunk (wave-uniform)
+                k = -1;
+                for (int j0 = 0; j0 < cnt && k < 0; j0 += 64) {
+                    const int j = j0 + lane;
+                    const float wgt = j < cnt ? __expf(z[j] - mx) : 0.f;
+                    float inc = wgt;       // inclusive prefix sum over the lanes
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const float o = __shfl_up(inc, off);
+                        if (lane >= off) inc += o;
+                    }
+                    const bool hit = j < cnt && run + inc > target;
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask) k = j0 + __ffsll((long long)mask) - 1;
+                    run += __shfl(inc, 63);
+                }
+                if (k < 0) {               // rounding left the target at / above the total: the last candidate with weight > 0
+                    k = arg;
+                    for (int j = cnt - 1; j >= 0; --j)
+                        if (__expf(z[j] - mx) > 0.f) { k = j; break; }
+                }
+            }
+            pick = stage == 0 ? (float)he_slot[m[11] + k] : (float)rn_node[m[12] + k];
+        }
+        if (stage == 0) a0 = pick; else a1 = pick;
+    }
+    if (lane == 0) {
+        actions[2 * b] = a0;
+        actions[2 * b + 1] = a1;
+    }
+}
+
+int launch_select_actions(int B, const int32_t *meta, const int32_t *he_slot, const uint16_t *rn_node, const int32_t *idx,
+                          const int32_t *he_off, const int32_t *rn_off, const float *z_he, const float *z_rn,
+                          const uint8_t *greedy, const float *uniform, float *actions, hipStream_t st) {
+    hipLaunchKernelGGL(select_actions_kernel, dim3((unsigned)B), dim3(64), 0, st, meta, he_slot, rn_node, idx, he_off, rn_off,
+                       z_he, z_rn, greedy, uniform, actions);
+    UPAMD_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace upamd

@@ -291,6 +291,9 @@ int launch_ppo_loss(int B, const float *value, const float *logp, const float *e
                     const float *ret, const float *old_logp, const float *exps, float clip_eps, float cv, float ce,
                     float inv_rows, float inv_ind, float *dvalue, float *dlogp, float *dent, float *losses,
                     float *zero, int64_t nzero, hipStream_t st);
+int launch_select_actions(int B, const int32_t *meta, const int32_t *he_slot, const uint16_t *rn_node, const int32_t *idx,
+                          const int32_t *he_off, const int32_t *rn_off, const float *z_he, const float *z_rn,
+                          const uint8_t *greedy, const float *uniform, float *actions, hipStream_t st);
 int launch_gae(int64_t T, const float *rewards, const float *masks, const float *values, double gamma, double tau,
                float *adv, float *ret, hipStream_t st);
 int launch_adam(int64_t n, float *p, const float *g, float *m, float *v, int step, double lr, double b1, double b2,

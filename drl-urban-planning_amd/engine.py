@@ -209,6 +209,32 @@ class NativeEngine:
             return raw.view(cols.value // 16, rows.value, 16).permute(1, 0, 2).reshape(rows.value, cols.value).clone()
         return raw.view(rows.value, cols.value).clone()
 
+    def ws_view(self, mb, name, slot=0, ws=None):
+        """A named ROW-MAJOR intermediate of the last forward on that workspace as a view (no copy): valid until the next
+        forward on the slot."""
+        off, rows, cols, kind = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        with self.lock, native.tuned(self.tune_overrides):
+            native.check(self.lib.upamd_ws_tensor(self.handle, C.byref(mb), name.encode(), C.byref(off), C.byref(rows),
+                                                  C.byref(cols), C.byref(kind)), 'upamd_ws_tensor')
+            _, _, shift = self._ws_args(slot, ws)
+            buf = self.ws_slots[slot] if ws is None else ws
+        if kind.value != 0:
+            raise ValueError('%s is stored panel-major: use ws_tensor' % name)
+        n = rows.value * cols.value
+        return buf[shift + off.value: shift + off.value + 4 * n].view(torch.float32).view(rows.value, cols.value)
+
+    # ---- rollout inference
+    def select_actions(self, packed, mb, z_he, z_rn, greedy, uniform, actions):
+        """`select_action` (policy.py:67-85) of every row of the minibatch from its ragged pointer-head logits: arg-max where
+        `greedy[b]` (uint8, device), else one inverse-CDF draw with `uniform[b]`; `actions` f32 [B, 2] (device) is written."""
+        assert greedy.dtype == torch.uint8 and uniform.dtype == torch.float32 and actions.dtype == torch.float32
+        assert greedy.numel() >= mb.B and uniform.numel() >= mb.B and actions.numel() >= 2 * mb.B and actions.is_contiguous()
+        with self.lock, native.tuned(self.tune_overrides), self._on_device():
+            native.check(self.lib.upamd_select_actions(_ptr(packed.dev_buf), C.byref(packed.layout), C.byref(mb),
+                                                       _ptr(z_he) if z_he is not None else None,
+                                                       _ptr(z_rn) if z_rn is not None else None, _ptr(greedy), _ptr(uniform),
+                                                       _ptr(actions), self._st()), 'upamd_select_actions')
+
     # ---- PPO math
     def ppo_loss(self, B, value, logp, ent, adv, ret, old_logp, exps, clip_eps, cv, ce, inv_rows, inv_ind, dvalue,
                  dlogp, dent, losses):

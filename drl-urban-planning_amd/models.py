@@ -17,6 +17,7 @@ Two execution paths, selected by where the parameters live:
   tensors.  This path never sees an optimizer step; ``update_params`` refuses to run on it.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -326,10 +327,23 @@ class _HipBackend:
             out = cache['rows'] = torch.empty(3, max(B, 64), device=device)
         with torch.no_grad():
             engine.forward(pk, mb, cache['flat'], out[0, :B], out[1, :B], out[2, :B], keep=False, slot='serve')
-            z_he = engine.ws_tensor(mb, 'z_he', slot='serve').reshape(-1) if int(pk.layout.total_he) else None
-            z_rn = engine.ws_tensor(mb, 'z_rn', slot='serve').reshape(-1) if int(pk.layout.total_rn) else None
-            action = ragged_actions(pk, x, z_he, z_rn, mean_rows, device)
-        return action
+            z_he = engine.ws_view(mb, 'z_he', slot='serve') if int(pk.layout.total_he) else None
+            z_rn = engine.ws_view(mb, 'z_rn', slot='serve') if int(pk.layout.total_rn) else None
+            if os.environ.get('UPAMD_SERVE_SELECT', 'hip') == 'torch':      # (lab A/B: round 5's route through torch ops)
+                return ragged_actions(pk, x, z_he.reshape(-1) if z_he is not None else None,
+                                      z_rn.reshape(-1) if z_rn is not None else None, mean_rows, device)
+            # arg-max / inverse-CDF draw per row in ONE launch (upamd_select_actions); the uniforms come from the device generator
+            sel = cache.get('sel')
+            if sel is None or sel[0].numel() < B:
+                cap = max(B, 64)
+                sel = cache['sel'] = (torch.empty(cap, dtype=torch.uint8, device=device), torch.empty(cap, 2, device=device),
+                                      torch.empty(cap, 2, dtype=torch.float32).pin_memory())
+            g_dev, _ = packer.upload_pinned(np.ascontiguousarray(mean_rows, dtype=np.uint8), device)
+            u = torch.rand(B, device=device)
+            engine.select_actions(pk, mb, z_he, z_rn, g_dev, u, sel[1])
+            sel[2][:B].copy_(sel[1][:B], non_blocking=True)
+            torch.cuda.current_stream(device).synchronize()
+            return sel[2][:B].numpy().copy()
 
     def pointer_logits(self, x):
         """The two pointer heads of a batch as the reference lays them out (policy.py:45-65): logits over the PADDED

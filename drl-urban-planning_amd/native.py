@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # (UPAMD_LIB_PATH: kernel-lab A/B runs load another build of the same ABI, e.g. tools/lab/libupamd_base.so)
 LIB_PATH = os.environ.get('UPAMD_LIB_PATH') or os.path.join(CSRC, 'libupamd.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_MLP = 4
 MAX_EDGE_FC = 4
 META_STRIDE = 16
@@ -70,6 +70,7 @@ SYMBOLS = {
                                 C.c_int32, _P]),
     'upamd_backward': (C.c_int, [_P, _P, C.POINTER(PackLayout), C.POINTER(Minibatch), _P, _P, C.c_int64, _P, _P, _P,
                                  _P, _P]),
+    'upamd_select_actions': (C.c_int, [_P, C.POINTER(PackLayout), C.POINTER(Minibatch), _P, _P, _P, _P, _P, _P]),
     'upamd_grad_buckets': (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'upamd_grad_bucket_wait': (C.c_int, [_P, _P, C.c_int32, _P]),
     'upamd_step_fused_ok': (C.c_int, [_P, C.POINTER(Minibatch)]),

@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define UPAMD_ABI_VERSION 6
+#define UPAMD_ABI_VERSION 7
 
 #define UPAMD_OK 0
 #define UPAMD_E_INVALID (-1)   /* bad argument / unsupported configuration            */
@@ -244,6 +244,19 @@ int upamd_step_fused(upamd_engine *eng, const void *packed_dev, const upamd_pack
  * stage-by-stage parity tests.  kind: 0 = row-major [rows][cols], 1 = panel-major [cols/16][rows][16]. */
 int upamd_ws_tensor(upamd_engine *eng, const upamd_minibatch *mb, const char *name, int64_t *byte_offset,
                     int64_t *rows, int64_t *cols, int32_t *kind);
+
+/* Rollout inference: UrbanPlanningPolicy.select_action (urban_planning/models/policy.py:67-85) for every
+ * row of a minibatch after upamd_forward -- per row the arg-max (greedy_dev[b] != 0: mean_action, :76-77 / :82-83) or one draw from
+ * the Categorical over the row's pointer-head candidates, by inverse CDF with the row's uniform_dev[b] in [0, 1) (the reference draws
+ * with Categorical.sample on the CPU generator, :78-79 / :84-85: the same distribution, another stream).  z_he_dev / z_rn_dev are the
+ * ragged logits upamd_ws_tensor names "z_he" / "z_rn" (land-use rows' / road rows' candidates in minibatch order); the masked slots
+ * of the reference's padded logits hold the pad constant -2^32 + 1 (policy.py:50-52, 59-61), i.e. probability exactly 0, so the
+ * distribution over the candidates alone is the reference's.  A row without candidates is the reference's uniform Categorical over
+ * its padded slots.  actions_dev: f32 [B][2] = (padded edge slot, 0) for a land-use row, (0, node) for a road row -- what
+ * select_action returns (:70-83).  One launch, one wave per row. */
+int upamd_select_actions(const void *packed_dev, const upamd_pack_layout *layout, const upamd_minibatch *mb,
+                         const float *z_he_dev, const float *z_rn_dev, const uint8_t *greedy_dev, const float *uniform_dev,
+                         float *actions_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * PPO minibatch math.

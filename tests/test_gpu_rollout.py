@@ -117,6 +117,53 @@ def test_gpu_action_server_with_sampling_and_eval_clients():
         a.close()
 
 
+def test_select_actions_kernel_is_the_reference_categorical(monkeypatch):
+    """upamd_select_actions (one launch: arg-max or inverse-CDF draw per row over the row's RAGGED candidates) against the
+    reference's semantics (policy.py:67-85): greedy rows equal the oracle's arg-max over the PADDED Categorical and round 5's
+    torch route exactly; sampled rows are always a live candidate, and their frequencies over 4096 draws of one state follow the
+    oracle's probabilities (every slot within 5 standard deviations)."""
+    cfg = helpers.make_cfg(D=32, L=2, heads=2, **PADS)
+    policy_net, value_net, ac = helpers.build_product(cfg, seed=3)
+    sd = helpers.perturbed_state_dict(ac, 4, scale=0.3)
+    ac.load_state_dict(sd)
+    ac.to(DEV)
+    backend = policy_net._backend[0]
+    rep = _states(48, 77)
+    P = helpers.oracle_params(sd, requires_grad=False)
+    with torch.no_grad():
+        land0, road0, stage0 = orc.policy_forward(P, orc.tensorfy(rep.states), 2)
+    want = torch.zeros(48, 2)
+    want[stage0[:, 0].bool(), 0] = land0.probs.argmax(1).float()
+    want[stage0[:, 1].bool(), 1] = road0.probs.argmax(1).float()
+    greedy = backend.serve_actions(rep.states, np.ones(48, dtype=bool))
+    assert np.array_equal(greedy, want.numpy())
+    monkeypatch.setenv('UPAMD_SERVE_SELECT', 'torch')
+    assert np.array_equal(backend.serve_actions(rep.states, np.ones(48, dtype=bool)), greedy)
+    monkeypatch.setenv('UPAMD_SERVE_SELECT', 'hip')
+    # mixed request: even rows greedy, odd rows sampled
+    flags = np.arange(48) % 2 == 0
+    mixed = backend.serve_actions(rep.states, flags)
+    assert np.array_equal(mixed[flags], greedy[flags])
+    for s, a in zip(rep.states, mixed):
+        stage = int(np.argmax(s[8]))
+        assert (s[6] if stage == 0 else s[7])[int(a[stage])] and a[1 - stage] == 0
+    # the distribution of the draws: one land-use state and one road state, 4096 draws each
+    li = int(np.flatnonzero(stage0[:, 0].numpy())[0])
+    ri = int(np.flatnonzero(stage0[:, 1].numpy())[0])
+    lrow = int(stage0[:li + 1, 0].sum()) - 1            # row of that state inside land0 / road0
+    rrow = int(stage0[:ri + 1, 1].sum()) - 1
+    N = 4096
+    torch.manual_seed(11)
+    for src, col, probs in ((li, 0, land0.probs[lrow]), (ri, 1, road0.probs[rrow])):
+        draws = np.concatenate([backend.serve_actions([rep.states[src]] * 512, np.zeros(512, dtype=bool))[:, col] for _ in range(N // 512)])
+        freq = np.bincount(draws.astype(np.int64), minlength=probs.numel())[:probs.numel()] / N
+        p = probs.numpy().astype(np.float64)
+        assert freq[p == 0].sum() == 0                   # a masked slot is never drawn
+        sigma = np.sqrt(np.maximum(p * (1 - p), 1e-12) / N)
+        assert (np.abs(freq - p) <= 5 * sigma + 1e-3).all(), float(np.abs(freq - p).max())
+        assert len(np.unique(draws)) > 1
+
+
 # ------------------------------------------------------------------------------------------------ bound into the agent class
 class _ReferenceLikeAgent:
     """The methods of ``UrbanPlanningAgent`` / ``Agent`` the rollout + checkpoint binding wraps, restated with the reference's
