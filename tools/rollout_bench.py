@@ -88,14 +88,18 @@ def main():
         policy_net.select_action(pool_t[:4], True)              # HIP initialised before the first fork
     if args.profile:
         import cProfile, pstats
-        batch = pool_r[:64]
+        # what one serving round runs for 64 single-state requests (rollout.ActionServer._actions -> serve_actions), in process
+        batch = packer.RecordList(pool_r[:64], np.array([r.ctypes.data for r in pool_r[:64]], dtype=np.uint64),
+                                  np.array([r.size for r in pool_r[:64]], dtype=np.int64))
+        flags = np.zeros(64, dtype=bool)
+        backend = policy_net._backend[0]
         for _ in range(5):
-            policy_net.select_action(batch, False)
+            backend.serve_actions(batch, flags)
         t0 = time.perf_counter()
         pr = cProfile.Profile()
         pr.enable()
         for _ in range(args.profile):
-            policy_net.select_action(batch, False).cpu()
+            backend.serve_actions(batch, flags)
         pr.disable()
         out['inprocess_ms_per_64_row_batch'] = 1e3 * (time.perf_counter() - t0) / args.profile
         pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(28)
