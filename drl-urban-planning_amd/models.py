@@ -312,7 +312,7 @@ class _HipBackend:
             cache['flat'] = engine.flatten(named, out=cache.get('flat') if cache.get('device') == device else None)
             cache['version'], cache['device'] = version, device
         B = len(x)
-        if isinstance(x, packer.RecordList) and x.addr is not None:
+        if getattr(x, 'addr', None) is not None:
             states = x                 # records with their address table (the action server's ring): no per-record Python below
         else:
             states = [s if packer.is_record(s) else

@@ -273,6 +273,34 @@ class RecordList(list):
         self.addr, self.size = addr, size
 
 
+class RecordViews:
+    """The records of one or more byte buffers (rollout arenas) as a read-only sequence that builds the zero-copy ``uint8`` view of
+    a record only when it is ASKED for: ``plan_replay`` takes ``addr`` / ``size`` and never touches an element, so a batch of T
+    records costs no per-record Python on its way into ``update_params`` (T views cost ~1 us each: 8 ms for an 8192-row batch)."""
+
+    def __init__(self, bufs, which, offs, sizes, addr):
+        self._bufs, self._which, self._offs = bufs, np.asarray(which, dtype=np.int64), np.asarray(offs, dtype=np.int64)
+        self.size = np.asarray(sizes, dtype=np.int64)
+        self.addr = np.asarray(addr, dtype=np.uint64)
+
+    def __len__(self):
+        return int(self.size.size)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        o = int(self._offs[i])
+        return self._bufs[int(self._which[i])][o:o + int(self.size[i])]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 def is_record(obj):
     return isinstance(obj, np.ndarray) and obj.dtype == np.uint8 and obj.ndim == 1 and obj.size >= _REC_HEADER.itemsize \
         and int(obj[:4].view('<u4')[0]) == _REC_MAGIC

@@ -490,6 +490,8 @@ class RecordBatch:
         kept for debugging or replay reuse must not read unmapped memory)."""
         import weakref
         states, actions, masks, rewards, exps, addrs, sizes = [], [], [], [], [], [], []
+        bufs, which, offs = [], [], []          # all-arena batches: the record views are built on access (packer.RecordViews)
+        lazy = True
         self._arenas = list(owns)
         self._held = {'states': None}        # shared with the finalizer: the views must go BEFORE the mappings they point into
         self._finalizer = weakref.finalize(self, _release_batch, self._held, self._arenas) if self._arenas else None
@@ -497,11 +499,21 @@ class RecordBatch:
         for m in memory_list:
             arena = getattr(m, 'arena', m if isinstance(m, SharedArena) else None)
             if arena is not None:
-                s, a, mk, rw, ex = arena.rows()
+                n = len(arena)
+                t = arena.table[:n]
+                s, a, mk, rw, ex = None, t[:, 2:4].astype(np.float32), t[:, 4].copy(), t[:, 5].copy(), t[:, 6].copy()
                 ad, sz = arena.record_addresses()
                 addrs.append(ad)
                 sizes.append(sz)
+                which.append(np.full(n, len(bufs), dtype=np.int64))
+                offs.append(t[:, 0].astype(np.int64))
+                bufs.append(arena.data)
+                if not lazy:
+                    s = arena.rows()[0]
             else:                                    # a khrylib Memory: rows of [state, action, mask, next_state, reward, exp]
+                if lazy and bufs:                    # mixed batch: materialise what the arenas before this memory held
+                    states += list(packer.RecordViews(bufs, np.concatenate(which), np.concatenate(offs), np.concatenate(sizes), np.concatenate(addrs)))
+                lazy = False
                 rows = m.sample()
                 s = [_to_record(r[0]) for r in rows]
                 a = np.stack([np.asarray(r[1], dtype=np.float32).reshape(-1)[:2] for r in rows]) if rows else np.zeros((0, 2), np.float32)
@@ -510,14 +522,18 @@ class RecordBatch:
                 ex = np.array([r[5] for r in rows], dtype=np.float64)
                 addrs.append(np.array([r.ctypes.data for r in s], dtype=np.uint64))
                 sizes.append(np.array([r.size for r in s], dtype=np.int64))
-            states += s
+            if s is not None:
+                states += s
             actions.append(a)
             masks.append(mk)
             rewards.append(rw)
             exps.append(ex)
         # (a list of record views that also carries the records' addresses: the packer never touches the T view objects)
-        self._held['states'] = packer.RecordList(states, np.concatenate(addrs) if addrs else None, np.concatenate(sizes) if sizes else None)
-        del states
+        if lazy and bufs:
+            self._held['states'] = packer.RecordViews(bufs, np.concatenate(which), np.concatenate(offs), np.concatenate(sizes), np.concatenate(addrs))
+        else:
+            self._held['states'] = packer.RecordList(states, np.concatenate(addrs) if addrs else None, np.concatenate(sizes) if sizes else None)
+        del states, bufs
         self.actions = np.concatenate(actions) if actions else np.zeros((0, 2), np.float32)
         self.masks = np.concatenate(masks) if masks else np.zeros(0)
         self.rewards = np.concatenate(rewards) if rewards else np.zeros(0)
