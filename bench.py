@@ -1,8 +1,9 @@
 """Benchmark of the hot path: PPO-update samples/s on HLG-shaped graphs (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: re-execs itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # ... or under an external launcher (the driver's form): the same line
 
 One "step" = one PPO optimizer step on one minibatch: SGNN forward (encoder once) + clipped-surrogate /
 value / entropy loss + full backward + (gradient all-reduce) + Adam, exactly what
@@ -19,7 +20,10 @@ rows (edge-balanced split), i.e. the reference's minibatch sequence sharded over
 
 Prints ONE JSON line on rank 0.  Extra objects: ``roofline`` (dominant kernel = the fp32-MFMA node GEMM,
 timed with HIP events on the launch stream inside the timed region) and ``cpu_baseline`` (the oracle =
-PyTorch-CPU port of the reference path, timed on this host's cores on a bounded sample; rank 0, N=1 only).
+PyTorch-CPU port of the reference path, timed on this host's cores on a bounded sample; rank 0, N=1 only); the default
+N = 1 line also carries ``ref_dims``: the reference-YAML-dims workloads hlg_ref and grid_ref (= BASELINE configs[0]) measured by
+child runs of this script.  Multi-rank lines carry ``rccl_ranks_seen``, ``collective_backend``,
+``allreduce_ms`` and ``allreduce_buckets``.
 """
 import argparse
 import json
