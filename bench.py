@@ -389,7 +389,7 @@ def main():
     ones = torch.ones(1, dtype=torch.float32, device=dev)
     if ctx.world > 1:
         ctx.all_reduce_sum(ones)                       # every rank that takes part in the collectives adds 1
-    ranks_seen, backend = int(round(float(ones.item()))), ctx.backend()
+    ranks_seen, backend = int(round(float(ones.item()))), ctx.backend
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     ctx.all_reduce_max(tmax)
     dt = float(tmax.item())

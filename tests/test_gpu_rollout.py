@@ -332,10 +332,11 @@ def test_bound_agent_samples_through_the_server_and_updates_on_the_records(tmp_p
     ep_states = [ag.env.states[t % len(ag.env.states)] for t in range(ag.env.episode_len)]
     with torch.no_grad():
         land0, road0, stage0 = orc.policy_forward(P, orc.tensorfy(ep_states), kw['heads'])
-    acc, margin = 0.0, float('inf')
+    acc, margin, seen = 0.0, float('inf'), [0, 0]
     for t in range(len(ep_states)):
         col = 0 if bool(stage0[t, 0]) else 1
-        probs = (land0 if col == 0 else road0).probs[t]
+        probs = (land0 if col == 0 else road0).probs[seen[col]]         # (a head's Categorical holds the rows of ITS stage only)
+        seen[col] += 1
         top = torch.topk(probs, 2).values
         margin = min(margin, float(top[0] - top[1]))
         a = np.zeros(2)
