@@ -131,6 +131,16 @@ class PPOUpdater:
         self._copy_stream = None
         self.pending_state = None             # a checkpoint's optimizer state waiting for the GPU buffers (load_state_dict at the next update_params)
         self._comm = None
+        # UPAMD_LANES=2 (opt-in, round 6): every minibatch is dealt into two edge-balanced halves (dist.split_minibatch, the deal a
+        # 2-rank data-parallel run uses) whose forward + loss + backward run on TWO streams with their own workspaces and gradient
+        # buffers; the halves' gradients are added before clip / Adam.  Graphs are independent, so one half's GEMMs (matrix pipe) can
+        # meet the other half's message passing (vector ALU) wherever the hardware dispatcher lets them share the chip -- the
+        # stream-level form of "software-pipeline two half-minibatches" (DESIGN section 5a has the measurement).  Same arithmetic as
+        # a 2-rank 'global' run: deterministic, inside every tolerance, NOT the bits of the one-lane step (another summation order).
+        self.lanes = int(os.environ.get('UPAMD_LANES', '1'))
+        if self.lanes not in (1, 2):
+            raise ValueError('UPAMD_LANES must be 1 or 2')
+        self._lane_streams = self._lane_bufs = None
 
     # ------------------------------------------------------------------ buffers
     def _device(self):
@@ -356,10 +366,16 @@ class PPOUpdater:
             local = [list(c) for c in zip(*[count(r) for r in row_lists])] if nb else [[], [], [], []]
             counts = global_counts(d, local, dev) if nb else local
         rows_glob, ind_glob, land_glob, road_glob = counts
+        lanes = self.lanes if (nb and self.lanes > 1 and int(self.engine.desc.D) > 32
+                               and all(len(r) % self.lanes == 0 and len(r) >= 2 * self.lanes for r in row_lists)) else 1
+        if lanes > 1:       # minibatch k -> schedule entries k * lanes + j: the j-th edge-balanced share of its rows
+            row_lists = [split_minibatch(r, meta[r, packer.M_E], j, lanes, self.dp_balance) for r in row_lists for j in range(lanes)]
         sched = packer.Schedule(it.packed, row_lists, dev) if nb else None
         flat_rows = (np.concatenate(row_lists) if nb else np.zeros(0)).astype(np.int64)
         order_dev, _ = packer.upload_pinned(flat_rows, dev)      # (recycled page-locked staging buffer, asynchronous copy)
-        return Epoch(sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob)
+        ep = Epoch(sched, order_dev, nb, rows_glob, ind_glob, land_glob, road_glob)
+        ep.lanes = lanes
+        return ep
 
     # ------------------------------------------------------------------ one optimizer step
     def step(self, it, ep, k, loss_out=None):
@@ -371,6 +387,8 @@ class PPOUpdater:
         nflt = engine.n_floats
         inv_rows = 1.0 / ep.rows_glob[k]
         inv_ind = 1.0 / ep.ind_glob[k] if ep.ind_glob[k] > 0 else float('nan')
+        if getattr(ep, 'lanes', 1) > 1:
+            return self._step_lanes(it, ep, k, loss_out, inv_rows, inv_ind)
         mb, _ = ep.sched.minibatch(k)
         idx = ep.order_dev[k * B:(k + 1) * B]
         if self.fused_small and engine.step_fused_ok(mb):
@@ -387,6 +405,35 @@ class PPOUpdater:
                              dvalue, dlogp, dent, self.grads[nflt:], zero=self.grads[:nflt])
         engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, self.grads)
         self._finish_step(ep, k, loss_out)
+
+    def _step_lanes(self, it, ep, k, loss_out, inv_rows, inv_ind):
+        """One optimizer step as `ep.lanes` half-minibatch steps on their own streams (UPAMD_LANES); see __init__."""
+        engine, L = self.engine, ep.lanes
+        dev, nflt = engine.device, engine.n_floats
+        Bh = self.local_rows() // L
+        if self._lane_streams is None or self._lane_streams[0].device != dev:
+            self._lane_streams = [torch.cuda.Stream(device=dev) for _ in range(L)]
+            self._lane_bufs = None
+        if self._lane_bufs is None or self._lane_bufs[0][0].numel() != Bh:
+            self._lane_bufs = [([torch.empty(Bh, device=dev) for _ in range(6)], torch.zeros(nflt + 4, device=dev)) for _ in range(L)]
+        main = torch.cuda.current_stream(dev)
+        for j, st in enumerate(self._lane_streams):
+            st.wait_stream(main)                # parameters (Adam of the previous step), the schedule upload
+            (value_b, logp_b, ent_b, dvalue, dlogp, dent), g = self._lane_bufs[j]
+            q = k * L + j
+            with torch.cuda.stream(st):
+                mb, _ = ep.sched.minibatch(q)
+                idx = ep.order_dev[q * Bh:(q + 1) * Bh]
+                engine.forward(it.packed, mb, self.flat, value_b, logp_b, ent_b, keep=True, slot=('lane', j))
+                # losses scaled by the counts of the WHOLE minibatch, as a data-parallel rank scales its share
+                engine.ppo_loss_rows(Bh, value_b, logp_b, ent_b, idx, it.adv, it.ret, it.old_logp, it.exps,
+                                     self.clip_epsilon, self.value_pred_coef, self.entropy_coef, inv_rows, inv_ind,
+                                     dvalue, dlogp, dent, g[nflt:], zero=g[:nflt])
+                engine.backward(it.packed, mb, self.flat, dvalue, dlogp, dent, g, slot=('lane', j))
+        for st in self._lane_streams:
+            main.wait_stream(st)
+        torch.add(self._lane_bufs[0][1], self._lane_bufs[1][1], out=self.grads)      # gradients + the 4 loss scalars
+        self._finish_step(ep, k, loss_out, buckets=False)
 
     def _reduce_gradients(self, buckets):
         """The step's gradient all-reduce.  Bucketed: the engine's backward has recorded one event per

@@ -11,6 +11,11 @@ import torch
 from . import native
 
 
+import contextlib
+
+_NULL_CTX = contextlib.nullcontext()
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -29,6 +34,7 @@ class NativeEngine:
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('the HIP engine needs a GPU device (got %s); there is no CPU fallback' % self.device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         h = C.c_void_p()
         native.check(self.lib.upamd_engine_create(C.byref(desc), C.byref(h)), 'upamd_engine_create')
         self.handle = h
@@ -62,6 +68,8 @@ class NativeEngine:
     def _on_device(self):
         """Native launches go to the device that is current in the calling thread (the library never calls
         hipSetDevice): make the engine's device current around every call."""
+        if torch.cuda.current_device() == self._dev_index:
+            return _NULL_CTX                   # already current (the usual case): a device guard costs two runtime calls per native call
         return torch.cuda.device(self.device)
 
     def __del__(self):
