@@ -29,3 +29,18 @@ def _lab_thread_variant():
             from drl_urban_planning_amd import native
             native.check(native.lib().upamd_tune(b'tiny_threads', int(v)), 'upamd_tune')
     yield
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _abort_probe():
+    """UPAMD_ABORT_PROBE=<file>: install tests/abort_probe.c's SIGABRT handler for the session (who raised the signal + the C
+    backtrace of the raising thread go to <file>).  Used by the round-6 flake loop; off by default."""
+    path = os.environ.get('UPAMD_ABORT_PROBE')
+    if path:
+        import ctypes
+        import subprocess
+        so = '/tmp/upamd_abort_probe_%d.so' % os.getuid()
+        src = os.path.join(ROOT, 'tests', 'abort_probe.c')
+        if subprocess.run(['gcc', '-O1', '-g', '-shared', '-fPIC', src, '-o', so], capture_output=True).returncode == 0:
+            ctypes.CDLL(so).upamd_abort_probe_install(path.encode())
+    yield
