@@ -5,6 +5,7 @@ message-passing workgroup ON THE SAME CU at the same time, and what does it do t
 
   serial       the product's default step (GEMMs and walks one after the other on the caller's stream)
   wgrad2       tune knob side_wgrad = 2: layer l's weight-gradient GEMM on a side stream NEXT TO layer l-1's message-passing backward
+  lanes        the product's opt-in UPAMD_LANES=2: one updater, every minibatch as two halves on two streams, gradients added
   two_streams  two half-minibatch steps (rows / 2 each, two engines, two streams) enqueued alternately: one half's GEMMs meet the
                other half's walks wherever the hardware dispatcher lets them -- the stream-level form of "software-pipeline two
                half-minibatches"
@@ -135,7 +136,7 @@ def analyse(rec):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--mode', default='serial', choices=['serial', 'wgrad2', 'two_streams'])
+    ap.add_argument('--mode', default='serial', choices=['serial', 'wgrad2', 'two_streams', 'lanes'])
     ap.add_argument('--tune', default='')
     ap.add_argument('--rows', type=int, default=2048)
     ap.add_argument('--steps', type=int, default=12)
@@ -156,6 +157,8 @@ def main():
         native.tune(k, int(v))
     w = dict(bench.WORKLOADS['hlg_d256'])
     dev = torch.device('cuda', 0)
+    if args.mode == 'lanes':
+        os.environ['UPAMD_LANES'] = '2'         # the PRODUCT's opt-in two-lane step (agent.PPOUpdater._step_lanes)
     lanes = 2 if args.mode == 'two_streams' else 1
     rows = args.rows // lanes
     ups, its, streams = [], [], []
