@@ -173,7 +173,14 @@ constexpr int64_t GRAIN = 16;     // states a worker takes at a time
 template <typename F>
 int parallel_for(int64_t T, int n_threads, F &&fn) {
     if (n_threads <= 0) n_threads = default_pack_threads();
-    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, T / GRAIN));
+    // small batches (action serving packs 8-64 states per round, ~70 us each): a finer grain so that up to 16 workers share them
+    // -- with the 16-state grain a 64-state round ran on 4 threads, 1.1 ms of a 1.7 ms serving round
+    int64_t grain = GRAIN;
+    if (T < GRAIN * n_threads) {
+        const int64_t w = std::min<int64_t>(n_threads, 16);
+        grain = std::min<int64_t>(GRAIN, std::max<int64_t>(1, (T + w - 1) / w));
+    }
+    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, T / grain));
     std::atomic<int> status{0};
     if (n_threads <= 1) {
         for (int64_t t = 0; t < T; ++t) {
@@ -185,9 +192,9 @@ int parallel_for(int64_t T, int n_threads, F &&fn) {
     std::atomic<int64_t> next{0};
     const std::function<void()> job = [&]() {
         for (;;) {
-            int64_t t0 = next.fetch_add(GRAIN);
+            int64_t t0 = next.fetch_add(grain);
             if (t0 >= T || status.load() != 0) return;
-            int64_t t1 = std::min(T, t0 + GRAIN);
+            int64_t t1 = std::min(T, t0 + grain);
             for (int64_t t = t0; t < t1; ++t) {
                 int rc = fn(t);
                 if (rc != 0) {

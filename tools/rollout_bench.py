@@ -22,14 +22,22 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-def _client(client, pid, pool, n_req, q):
+WARM = 30        # untimed requests per client in front of the timed ones: workspaces, page-locked buffers, clocks, every worker up
+
+
+def _client(client, pid, pool, n_req, q, ready, go):
+    for i in range(WARM):
+        client.select_action([pool[(pid * 7 + i) % len(pool)]], False)
+    ready.put(pid)
+    go.wait()                    # all clients start their timed requests together
     lat = np.empty(n_req)
+    t_first = time.time()
     for i in range(n_req):
         s = pool[(pid * 7 + i) % len(pool)]
         t = time.perf_counter()
         client.select_action([s], False)
         lat[i] = time.perf_counter() - t
-    q.put((pid, lat))
+    q.put((pid, lat, t_first, time.time()))
     client.close()
 
 
@@ -49,7 +57,7 @@ def main():
     ap.add_argument('--D', type=int, default=16)
     ap.add_argument('--L', type=int, default=2)
     ap.add_argument('--clients', type=int, nargs='+', default=[8, 16, 32, 64])
-    ap.add_argument('--requests', type=int, default=200, help='requests per client')
+    ap.add_argument('--requests', type=int, default=400, help='timed requests per client (after the warm-up ones)')
     ap.add_argument('--tuples', action='store_true', help='clients hold padded 9-field tuples (compacted per request) instead of records')
     ap.add_argument('--cpu-procs', type=int, nargs='+', default=[1, 8, 16])
     ap.add_argument('--cpu-requests', type=int, default=40)
@@ -105,22 +113,26 @@ def main():
         pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(28)
     for n in args.clients:
         server = rollout.ActionServer(policy_net, n, slot_bytes=1 << 18, mp_context=ctx)
-        q = ctx.Queue()
-        t0 = time.perf_counter()
-        procs = server.launch(_client, [(i, pool, args.requests, q) for i in range(n)], ctx)
-        lats = [q.get(timeout=90)[1] for _ in procs]
-        wall = time.perf_counter() - t0
+        q, ready, go = ctx.Queue(), ctx.Queue(), ctx.Event()
+        procs = server.launch(_client, [(i, pool, args.requests, q, ready, go) for i in range(n)], ctx)
+        for _ in procs:
+            ready.get(timeout=120)              # every client has finished its warm-up requests
+        st0 = dict(server.stats)
+        go.set()
+        res = [q.get(timeout=180) for _ in procs]
         for p in procs:
             p.join()
         server.stop()
-        st = dict(server.stats)
+        st = {k: server.stats[k] - st0.get(k, 0) for k in ('batches', 'requests', 'rows', 'busy_s')}
         server.close()
-        lat = np.concatenate(lats) * 1e3
-        out['serving'].append({'clients': n, 'requests': int(st['requests']), 'actions_per_s': st['requests'] / wall,
+        lat = np.concatenate([r[1] for r in res]) * 1e3
+        wall = max(r[3] for r in res) - min(r[2] for r in res)          # first timed request sent .. last timed answer received
+        out['serving'].append({'clients': n, 'requests': int(st['requests']), 'actions_per_s': n * args.requests / wall,
                                'batches': int(st['batches']), 'mean_rows_per_batch': st['rows'] / max(st['batches'], 1),
-                               'max_rows': int(st['max_rows']), 'latency_ms_p50': float(np.percentile(lat, 50)),
+                               'latency_ms_p50': float(np.percentile(lat, 50)),
                                'latency_ms_p99': float(np.percentile(lat, 99)), 'server_busy_fraction': st['busy_s'] / wall,
-                               'server_ms_per_batch': 1e3 * st['busy_s'] / max(st['batches'], 1)})
+                               'server_ms_per_batch': 1e3 * st['busy_s'] / max(st['batches'], 1),
+                               'window': 'steady state: %d warm-up requests per client first, then %d timed ones started together' % (WARM, args.requests)})
     print(json.dumps(out))
 
 
