@@ -10,10 +10,15 @@ sources are untouched; the copy is not tracked).
 import os
 import shutil
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = os.path.join(ROOT, 'drl-urban-planning_amd', 'csrc')
-DST = os.path.join(ROOT, 'tools', 'lab_census', 'csrc')
+# `python tools/lab_census/build.py nt128` -> tools/lab_census/csrc_nt128: the same census build with the LDS-DMA NT GEMM compiled for
+# <= 128 VGPRs (__launch_bounds__(256, 4): 126 VGPRs, no spills, instead of 82 + 64 AGPRs = 152 allocated), so that TWO of its
+# workgroups fit the registers one resident message-passing workgroup (4 waves x 64 VGPRs per SIMD) leaves free
+NT128 = len(sys.argv) > 1 and sys.argv[1] == 'nt128'
+DST = os.path.join(ROOT, 'tools', 'lab_census', 'csrc_nt128' if NT128 else 'csrc')
 if os.path.isdir(DST):
     shutil.rmtree(DST)
 os.makedirs(DST)
@@ -86,6 +91,10 @@ patch('gemm.hip', [
     ('void set_gemm_lds_pad(int bytes) { g_lds_pad = bytes; }\n',
      'void set_gemm_lds_pad(int bytes) { g_lds_pad = bytes; }\nvoid set_census_gemm(void *buf) { census_set_tu(buf); }\n', 1),
 ])
+
+if NT128:
+    patch('gemm.hip', [('__global__ __launch_bounds__(64 * WM * WN, (TM * TN > 4 ? 2 : 1)) void gemm_nt_dma2_kernel',
+                        '__global__ __launch_bounds__(64 * WM * WN, 4) void gemm_nt_dma2_kernel', 1)])
 
 # message passing: the slot lives in 4 bytes of static LDS (these kernels are built for exactly 64 VGPRs)
 patch('edge.hip', [

@@ -143,8 +143,9 @@ def main():
     ap.add_argument('--census', type=int, default=1, help='0: time only on the product library; 2: time only on the census build '
                                                            '(its lab knob UPAMD_LAB_EDGE_LDS included); 1: census build, one step recorded')
     ap.add_argument('--out', default='')
+    ap.add_argument('--lib-dir', default='csrc', help='csrc | csrc_nt128 (tools/lab_census/build.py nt128)')
     args = ap.parse_args()
-    census_lib = os.path.join(ROOT, 'tools', 'lab_census', 'csrc', 'libupamd.so')
+    census_lib = os.path.join(ROOT, 'tools', 'lab_census', args.lib_dir, 'libupamd.so')
     if args.census:
         os.environ['UPAMD_LIB_PATH'] = census_lib
     import bench
@@ -196,7 +197,7 @@ def main():
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
     res = {'mode': args.mode, 'tune': tune, 'rows_per_round': rows * lanes, 'lanes': lanes, 'ms_per_round': ms,
-           'samples_per_s': rows * lanes / ms * 1e3, 'library': 'census build' if args.census else 'product',
+           'samples_per_s': rows * lanes / ms * 1e3, 'library': ('census build' + ('' if args.lib_dir == 'csrc' else ' ' + args.lib_dir)) if args.census else 'product',
            'edge_lds_floor': os.environ.get('UPAMD_LAB_EDGE_LDS')}
     if args.census == 1:
         cap = 700000
