@@ -414,7 +414,7 @@ class PPOUpdater:
         if self._lane_streams is None or self._lane_streams[0].device != dev:
             self._lane_streams = [torch.cuda.Stream(device=dev) for _ in range(L)]
             self._lane_bufs = None
-        if self._lane_bufs is None or self._lane_bufs[0][0].numel() != Bh:
+        if self._lane_bufs is None or self._lane_bufs[0][0][0].numel() != Bh:
             self._lane_bufs = [([torch.empty(Bh, device=dev) for _ in range(6)], torch.zeros(nflt + 4, device=dev)) for _ in range(L)]
         main = torch.cuda.current_stream(dev)
         for j, st in enumerate(self._lane_streams):
