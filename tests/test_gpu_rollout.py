@@ -2,7 +2,9 @@
 records, the learner process answers every pending request with one GPU forward and on-device sampling; a greedy
 "evaluation" client runs concurrently with the sampling clients (no CPU<->GPU round trip of the model, no serial eval
 phase).  Greedy answers are compared with the oracle's arg-max; the collected arenas feed update_params directly."""
+import json
 import multiprocessing as mp
+import os
 import time
 
 import numpy as np
@@ -306,6 +308,10 @@ def test_bound_agent_samples_through_the_server_and_updates_on_the_records(tmp_p
     assert isinstance(batch, rollout.RecordBatch) and len(batch) == 36 and log.num_episodes == 6
     st = ag._upamd_server_stats
     assert st['requests'] == 36 and st['rows'] == 36, st        # (how many requests share a round is a matter of timing)
+    if os.environ.get('UPAMD_TEST_STATS'):      # flake loop (tools/r06/flake_loop.sh): would round 5's `max_rows >= 2` have held in THIS run?
+        with open(os.environ['UPAMD_TEST_STATS'], 'a') as fh:
+            fh.write(json.dumps({'test': 'bound_agent_first_sample', 'requests': int(st['requests']), 'batches': int(st['batches']),
+                                 'max_rows': int(st['max_rows'])}) + '\n')
     for rec, a in zip(batch.states, batch.actions):
         s = __import__('drl_urban_planning_amd').packer.expand_state(rec, padded=True)
         stage = int(np.argmax(s[8]))

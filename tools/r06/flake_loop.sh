@@ -12,7 +12,7 @@ lane() {
     i=$((i+1))
     local log=$OUT/lane${L}_run${i}.log
     local t1=$(date +%s)
-    UPAMD_ABORT_PROBE=$OUT/abort_lane${L}_run${i}.txt timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $log 2>&1
+    UPAMD_TEST_STATS=$OUT/serving_stats.jsonl UPAMD_ABORT_PROBE=$OUT/abort_lane${L}_run${i}.txt timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $log 2>&1
     local rc=$?
     echo "lane $L run $i rc=$rc $(( $(date +%s) - t1 ))s $(tail -1 $log)" >> $OUT/summary.txt
     if [ $rc -eq 0 ]; then tail -3 $log > $log.tail; rm -f $log; fi      # keep full logs of failures only
