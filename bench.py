@@ -207,6 +207,40 @@ def spawn_ranks(args, argv):
     os.execvpe(sys.executable, cmd, env)
 
 
+def route_overhead(rows_share, timeout_s=150):
+    """What the data-parallel ROUTE adds to one rank's share of a strong-scaling step when there is nothing on the wire: the 256-row
+    step timed by three child runs of this script -- no process group | a one-rank RCCL group with the single collective | the same
+    with the bucketed all-reduce forced on (UPAMD_DIST_FORCE_INIT=1: `nccl` initialised with ONE rank, so the stream / event / work-object
+    plumbing of the real backend runs and the sum is the identity).  Returns ms per step of each and the two differences."""
+    import socket
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--minibatch', str(rows_share), '--steps', '96', '--warmup', '32',
+            '--cpu-baseline', 'off', '--no-kernel-events', '--inclusive-pool', '--no-ref-dims', '--strong-proxy', 'off']
+    out = {}
+    for tag, extra in (('no_group', None), ('single_collective', {'UPAMD_GRAD_BUCKETS': '0'}), ('bucketed', {'UPAMD_GRAD_BUCKETS': 'force'})):
+        env = dict(os.environ)
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'UPAMD_DIST_FORCE_INIT', 'UPAMD_GRAD_BUCKETS'):
+            env.pop(k, None)
+        if extra is not None:
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+            env.update(extra, UPAMD_DIST_FORCE_INIT='1', RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        try:
+            res = subprocess.run(base, capture_output=True, text=True, timeout=timeout_s, env=env)
+            line = [l for l in res.stdout.splitlines() if l.startswith('{')]
+            if res.returncode != 0 or not line:
+                return {'error': '%s: rc=%d %s' % (tag, res.returncode, res.stderr[-300:])}
+            out['ms_' + tag] = json.loads(line[-1])['ms_per_step']
+        except Exception as exc:
+            return {'error': '%s: %s: %s' % (tag, type(exc).__name__, exc)}
+    out['single_collective'] = out['ms_single_collective'] - out['ms_no_group']
+    out['bucketed'] = out['ms_bucketed'] - out['ms_no_group']
+    out['source'] = ('MEASURED by three child runs of this script on this box (%d-row step, 96 steps after 32 warm-up): no process group | one-rank '
+                     'RCCL group, single collective | bucketed all-reduce forced on; nothing is on the wire (one rank)' % rows_share)
+    return out
+
+
 REF_DIMS_KEYS = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'node_steps_per_s', 'host_enqueue_ms_per_step', 'kernel_ms_per_step')
 
 
@@ -249,6 +283,8 @@ def main():
     ap.add_argument('--cpu-baseline', default='quick', choices=['quick', 'full', 'brief', 'off'],
                     help='quick: ~1 min of CPU work (default); full: the whole thread sweep, >= 5 steps per line; brief: one '
                          '16-thread line + its tight-pad twin (~15 s; what the ref_dims child runs use)')
+    ap.add_argument('--no-route-overhead', action='store_true',
+                    help='strong_proxy: use round 5\'s lab constants for the data-parallel route\'s own cost instead of measuring it with child runs')
     ap.add_argument('--no-ref-dims', action='store_true',
                     help='skip the ref_dims object (default run at N = 1: hlg_ref and grid_ref measured by child runs)')
     ap.add_argument('--dp-mode', default='global', choices=['global', 'local'],
@@ -432,12 +468,16 @@ def main():
                                      % (ALPHA_US, LINK_GBPS),
                  'value': ms_full / (ms_share + exposed), 'value_without_collective': ms_full / ms_share,
                  'value_single_collective': ms_full / (ms_share + model(4 * (nfl + 4))), 'ideal': 8.0,
-                 # what the data-parallel route itself adds to a 256-row step under a real RCCL process group, measured with ONE
-                 # rank (nothing on the wire): lab constants of round 5, not measured by this run
-                 'rccl_route_overhead_ms': {'single_collective': 0.035, 'bucketed': 0.115,
-                                            'source': 'profiles/r05_lab_bucket_overhead.md (one-rank RCCL group, round 5)'},
-                 'value_with_route_overhead': ms_full / (ms_share + 0.115 + exposed),
-                 'value_single_collective_with_route_overhead': ms_full / (ms_share + 0.035 + model(4 * (nfl + 4)))}
+                 }
+        # what the data-parallel route itself adds to a 256-row step under a real RCCL process group with ONE rank (nothing on the
+        # wire): measured by child runs (route_overhead); round 5's lab constants only if a child run fails, and labelled so
+        ro = route_overhead(w['B'] // 8) if not args.no_route_overhead else {'error': '--no-route-overhead'}
+        if 'error' in ro:
+            ro = {'single_collective': 0.035, 'bucketed': 0.115, 'fallback_reason': ro['error'],
+                  'source': 'CONSTANTS of profiles/r05_lab_bucket_overhead.md (one-rank RCCL group, round 5): the child runs did not complete'}
+        proxy['rccl_route_overhead_ms'] = ro
+        proxy['value_with_route_overhead'] = ms_full / (ms_share + max(ro['bucketed'], 0.0) + exposed)
+        proxy['value_single_collective_with_route_overhead'] = ms_full / (ms_share + max(ro['single_collective'], 0.0) + model(4 * (nfl + 4)))
 
     kern = {}
     if not args.no_kernel_events:

@@ -62,3 +62,27 @@ def test_ref_dims_line_reduces_a_child_bench_line(monkeypatch):
         return subprocess.CompletedProcess(cmd, 3, '', 'boom')
     monkeypatch.setattr(subprocess, 'run', failing)
     assert 'error' in bench.ref_dims_line('grid_ref')
+
+
+def test_route_overhead_is_the_difference_of_three_child_runs(monkeypatch):
+    import subprocess
+    seen = []
+
+    def fake_run(cmd, capture_output, text, timeout, env):
+        seen.append(env)
+        assert '--minibatch' in cmd and cmd[cmd.index('--minibatch') + 1] == '256' and '--no-ref-dims' in cmd
+        ms = 2.20 if 'UPAMD_DIST_FORCE_INIT' not in env else (2.24 if env['UPAMD_GRAD_BUCKETS'] == '0' else 2.31)
+        return subprocess.CompletedProcess(cmd, 0, json.dumps({'ms_per_step': ms}) + '\n', '')
+
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setenv('WORLD_SIZE', '8')                 # a launcher's variables must not leak into the one-rank children
+    out = bench.route_overhead(256)
+    assert abs(out['single_collective'] - 0.04) < 1e-9 and abs(out['bucketed'] - 0.11) < 1e-9 and out['source'].startswith('MEASURED')
+    assert 'WORLD_SIZE' not in seen[0] and seen[1]['WORLD_SIZE'] == '1' and seen[1]['UPAMD_DIST_FORCE_INIT'] == '1'
+    assert seen[1]['UPAMD_GRAD_BUCKETS'] == '0' and seen[2]['UPAMD_GRAD_BUCKETS'] == 'force'
+    assert seen[1]['MASTER_ADDR'] == '127.0.0.1' and seen[1]['MASTER_PORT'] != seen[2]['MASTER_PORT']
+
+    def failing(cmd, capture_output, text, timeout, env):
+        return subprocess.CompletedProcess(cmd, 1, '', 'no rccl')
+    monkeypatch.setattr(subprocess, 'run', failing)
+    assert 'error' in bench.route_overhead(256)
