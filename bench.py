@@ -231,7 +231,9 @@ def route_overhead(rows_share, timeout_s=150):
             line = [l for l in res.stdout.splitlines() if l.startswith('{')]
             if res.returncode != 0 or not line:
                 return {'error': '%s: rc=%d %s' % (tag, res.returncode, res.stderr[-300:])}
-            out['ms_' + tag] = json.loads(line[-1])['ms_per_step']
+            child = json.loads(line[-1])
+            out['ms_' + tag] = child['ms_per_step']
+            out['host_enqueue_ms_' + tag] = child.get('host_enqueue_ms_per_step')      # the launch thread's share of the step
         except Exception as exc:
             return {'error': '%s: %s: %s' % (tag, type(exc).__name__, exc)}
     out['single_collective'] = out['ms_single_collective'] - out['ms_no_group']
