@@ -39,7 +39,7 @@ import time
 import numpy as np
 import torch
 
-from . import packer
+from . import native, packer
 from .dist import DistContext, batch_fingerprint, global_counts, split_minibatch, states_fingerprint
 from .models import backend_of
 
@@ -257,7 +257,8 @@ class PPOUpdater:
         T = len(batch.states)
         packed = packer.plan_replay(batch.states, np.asarray(batch.actions), agent.node_dim,
                                     agent.numerical_feature_size, n_threads=self.pack_threads,
-                                    reuse=self._pack_cache, exact=exact_plan)
+                                    reuse=self._pack_cache, exact=exact_plan,
+                                    mlp_fields=int(engine.desc.encoder) == native.ENCODER_MLP)
         # the small per-row arrays first, through the recycled page-locked ring: a pageable upload later on would make the host
         # wait for every kernel queued before it
         exps_np = np.asarray(batch.exps, dtype=np.float32)

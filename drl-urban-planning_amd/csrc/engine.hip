@@ -272,8 +272,8 @@ PackedView make_view(const void *packed_dev, const upamd_pack_layout &L) {
     v.hinc_ptr = reinterpret_cast<const int32_t *>(b + L.off_hinc_ptr);
     v.hinc_nbr = reinterpret_cast<const uint16_t *>(b + L.off_hinc_nbr);
     v.hinc_he = reinterpret_cast<const uint16_t *>(b + L.off_hinc_he);
-    v.he_sel = reinterpret_cast<const uint16_t *>(b + L.off_he_sel);
-    v.xbar = reinterpret_cast<const float *>(b + L.off_xbar);
+    v.he_sel = L.off_he_sel >= 0 ? reinterpret_cast<const uint16_t *>(b + L.off_he_sel) : nullptr;      // (absent in a replay planned
+    v.xbar = L.off_xbar >= 0 ? reinterpret_cast<const float *>(b + L.off_xbar) : nullptr;                //  without the rl-mlp fields)
     v.numerical = reinterpret_cast<const float *>(b + L.off_numerical);
     v.cur = reinterpret_cast<const float *>(b + L.off_cur);
     v.Fn = L.numerical_dim;
@@ -294,6 +294,8 @@ int check_args(upamd_engine *eng, const void *packed, const upamd_pack_layout *l
     if (!eng || !packed || !layout || !mb || !params || !ws) return fail(UPAMD_E_INVALID, "null argument");
     if (mb->B <= 0 || mb->n_nodes <= 0) return fail(UPAMD_E_INVALID, "empty minibatch (B=%d, nodes=%lld)", mb->B, (long long)mb->n_nodes);
     if (!mb->idx_dev || !mb->node_off_dev || !mb->he_off_dev || !mb->rn_off_dev) return fail(UPAMD_E_INVALID, "minibatch schedule pointers are null");
+    if (eng->d.encoder == UPAMD_ENCODER_MLP && (layout->off_xbar < 0 || layout->off_he_sel < 0))
+        return fail(UPAMD_E_INVALID, "this replay was planned without the rl-mlp fields (upamd_pack_plan_ex flag 2): an rl-mlp engine cannot read it");
     if (layout->node_dim != eng->d.node_dim || layout->numerical_dim != eng->d.numerical_dim)
         return fail(UPAMD_E_INVALID, "packed replay feature sizes (%d,%d) do not match the model (%d,%d)", layout->node_dim,
                     layout->numerical_dim, eng->d.node_dim, eng->d.numerical_dim);

@@ -259,6 +259,8 @@ extern "C" int upamd_pack_plan_ex(int64_t T, const uint64_t *ptrs, const int32_t
         return upamd::fail(UPAMD_E_INVALID, "upamd_pack_plan: null argument or T <= 0");
     if (node_dim <= 0 || node_dim > UPAMD_NODE_PAD)
         return upamd::fail(UPAMD_E_INVALID, "upamd_pack_plan: node_dim must be in [1, 24]");
+    const bool no_mlp_fields = (exact & 2) != 0;      // flag bit 1: leave out what only the rl-mlp encoder reads (he_sel, xbar)
+    exact &= 1;
     int rc = parallel_for(T, n_threads, [&](int64_t t) -> int {
         StateView s = view(ptrs, T, t);
         const int N = pad_n[t], E = pad_e[t];
@@ -349,8 +351,12 @@ extern "C" int upamd_pack_plan_ex(int64_t T, const uint64_t *ptrs, const int32_t
     L.off_hinc_ptr = place((nodes + T) * 4);
     L.off_hinc_nbr = place(2 * he * 2);
     L.off_hinc_he = place(2 * he * 2);
-    L.off_he_sel = place(he * 2);
-    L.off_xbar = place(T * UPAMD_NODE_PAD * 4);
+    if (no_mlp_fields) {
+        L.off_he_sel = L.off_xbar = -1;                // not present: upamd_pack_fill* skips them, an rl-mlp engine refuses the replay
+    } else {
+        L.off_he_sel = place(he * 2);
+        L.off_xbar = place(T * UPAMD_NODE_PAD * 4);
+    }
     L.total_bytes = off;
     *layout = L;
     return UPAMD_OK;
@@ -384,8 +390,12 @@ extern "C" int upamd_pack_fill_range(int64_t T, const uint64_t *ptrs, const int3
     int32_t *hinc_ptr = reinterpret_cast<int32_t *>(base + L.off_hinc_ptr);
     uint16_t *hinc_nbr = reinterpret_cast<uint16_t *>(base + L.off_hinc_nbr);
     uint16_t *hinc_he = reinterpret_cast<uint16_t *>(base + L.off_hinc_he);
-    uint16_t *he_sel = reinterpret_cast<uint16_t *>(base + L.off_he_sel);
-    float *xbar = reinterpret_cast<float *>(base + L.off_xbar);
+    // rl-mlp fields (he_sel, xbar): the mean of the selected endpoints' features walks every live edge with a 14-way arg-max and
+    // 23 double adds -- two thirds of a state's fill time (95 of 140 us on the build container).  An SGNN replay is planned without
+    // them (upamd_pack_plan_ex flag 2) and skips all of it.
+    const bool mlp_fields = L.off_xbar >= 0 && L.off_he_sel >= 0;
+    uint16_t *he_sel = mlp_fields ? reinterpret_cast<uint16_t *>(base + L.off_he_sel) : nullptr;
+    float *xbar = mlp_fields ? reinterpret_cast<float *>(base + L.off_xbar) : nullptr;
     const int F = L.node_dim, Fn = L.numerical_dim;
 
     int rc = parallel_for(t_end - t_begin, n_threads, [&](int64_t tt) -> int {
@@ -418,7 +428,7 @@ extern "C" int upamd_pack_fill_range(int64_t T, const uint64_t *ptrs, const int3
                 if (xj[c] > xj[best]) best = c;
             return best == UPAMD_MLP_FEASIBLE ? j : i;
         };
-        {
+        if (mlp_fields) {
             double acc[UPAMD_NODE_PAD] = {0};
             for (int k = 0; k < E; ++k)
                 if (s.edge_mask[k]) {
@@ -440,7 +450,7 @@ extern "C" int upamd_pack_fill_range(int64_t T, const uint64_t *ptrs, const int3
                     he_src[o_he + q] = live ? (uint16_t)s.edge_index[2 * k] : 0;
                     he_dst[o_he + q] = live ? (uint16_t)s.edge_index[2 * k + 1] : 0;
                     he_live[o_he + q] = live ? 1 : 0;
-                    he_sel[o_he + q] = live ? (uint16_t)selected(k) : 0;
+                    if (mlp_fields) he_sel[o_he + q] = live ? (uint16_t)selected(k) : 0;
                     he_slot[o_he + q] = k;
                     ++q;
                 }

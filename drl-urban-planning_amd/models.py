@@ -239,6 +239,11 @@ class _HipBackend:
         self.value_net = None
         self._engine = None
 
+    def needs_mlp_fields(self):
+        """Only the rl-mlp encoder reads the replay's he_sel / xbar sections; an SGNN replay is packed without them (two thirds of a
+        state's fill time on the host, packer.plan_replay)."""
+        return isinstance(self.shared_net, MLPStateEncoder)
+
     def desc(self):
         kind = native.ENCODER_MLP if isinstance(self.shared_net, MLPStateEncoder) else native.ENCODER_SGNN
         return native.make_desc(self.shared_net.cfg, self.policy_cfg, self.value_cfg, self.shared_net.agent.node_dim,
@@ -288,7 +293,7 @@ class _HipBackend:
         else:
             act = action.detach().cpu().numpy().astype(np.float32).reshape(B, 2)
         pk = packer.pack_replay(states, act, self.shared_net.agent.node_dim,
-                                self.shared_net.agent.numerical_feature_size, reuse=reuse).to(device)
+                                self.shared_net.agent.numerical_feature_size, reuse=reuse, mlp_fields=self.needs_mlp_fields()).to(device)
         sched = packer.Schedule(pk, [np.arange(B)], device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.named_params().values())
         runner = _Runner(engine, pk, sched, need_grad, private_ws)
@@ -324,7 +329,8 @@ class _HipBackend:
                       [f.detach().cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in s] for s in x]
         torch.cuda.current_stream(device).synchronize()      # (the previous round's copies have left the recycled staging buffer)
         pk = packer.pack_replay(states, np.zeros((B, 2), dtype=np.float32), self.shared_net.agent.node_dim,
-                                self.shared_net.agent.numerical_feature_size, reuse=cache.setdefault('pack', {})).to(device)
+                                self.shared_net.agent.numerical_feature_size, reuse=cache.setdefault('pack', {}),
+                                mlp_fields=self.needs_mlp_fields()).to(device)
         sched = packer.Schedule(pk, [np.arange(B)], device)
         mb, _ = sched.minibatch(0)
         out = cache.get('rows')

@@ -75,7 +75,7 @@ class PackedReplay:
                 (L.off_he_slot, 4, h0, h1), (L.off_rn_node, 2, r0, r1), (L.off_numerical, 4 * Fn, t0, t1),
                 (L.off_cur, 4 * NP, t0, t1), (L.off_order, 2, n0, n1), (L.off_hinc_ptr, 4, p0, p1), (L.off_hinc_nbr, 4, h0, h1),
                 (L.off_hinc_he, 4, h0, h1), (L.off_he_sel, 2, h0, h1), (L.off_xbar, 4 * NP, t0, t1)]
-        return [(int(off) + w * lo, int(off) + w * hi) for off, w, lo, hi in spec if hi > lo]
+        return [(int(off) + w * lo, int(off) + w * hi) for off, w, lo, hi in spec if hi > lo and off >= 0]      # (off < 0: section not planned)
 
     def alloc_device(self, device):
         if self.dev_buf is None or self.dev_buf.numel() != self.host_buf.numel() or self.dev_buf.device != torch.device(device):
@@ -348,20 +348,20 @@ def expand_state(record, padded=False):
     return out
 
 
-def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None, reuse=None):
+def pack_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None, reuse=None, mlp_fields=True):
     """states: list[T] of list[9] arrays (or tensors); actions: f32[T,2] (padded-slot indices).
     ``reuse``: optional dict owned by the caller; its pinned staging buffer is recycled across iterations
     (pinning ~1 GB per PPO iteration is otherwise a measurable part of the set-up time)."""
     try:
-        pk = plan_replay(states, actions, node_dim, numerical_dim, n_threads, pin, reuse, exact=False)
+        pk = plan_replay(states, actions, node_dim, numerical_dim, n_threads, pin, reuse, exact=False, mlp_fields=mlp_fields)
         pk.fill(0, pk.T)
     except NeedsExactPlan:
-        pk = plan_replay(states, actions, node_dim, numerical_dim, n_threads, pin, reuse, exact=True)
+        pk = plan_replay(states, actions, node_dim, numerical_dim, n_threads, pin, reuse, exact=True, mlp_fields=mlp_fields)
         pk.fill(0, pk.T)
     return pk
 
 
-def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None, reuse=None, exact=True):
+def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None, reuse=None, exact=True, mlp_fields=True):
     """The first half of ``pack_replay``: address tables, the counting pass (``upamd_pack_plan_ex``: meta table + layout) and
     the host buffer -- NOT yet filled: ``PackedReplay.fill(t0, t1)`` packs a range of states.  ``exact=False``: the counting
     pass reads the masks only and ``fill`` raises ``NeedsExactPlan`` if a live edge lies beyond the extent they give (never
@@ -427,7 +427,8 @@ def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     meta = np.zeros((T, native.META_STRIDE), dtype=np.int32)
     layout = native.PackLayout()
     native.check(L.upamd_pack_plan_ex(T, ptrs.ctypes.data, pad_n.ctypes.data, pad_e.ctypes.data, actions.ctypes.data,
-                                      int(node_dim), int(numerical_dim), int(n_threads), 1 if exact else 0, meta.ctypes.data,
+                                      int(node_dim), int(numerical_dim), int(n_threads), (1 if exact else 0) | (0 if mlp_fields else 2),
+                                      meta.ctypes.data,
                                       C.byref(layout)), 'upamd_pack_plan_ex')
     if pin is None:
         pin = torch.cuda.is_available()

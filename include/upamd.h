@@ -154,7 +154,10 @@ int upamd_record_table(int64_t T, const uint64_t *rec_ptrs, const int64_t *rec_s
 /* exact = 1: upamd_pack_plan.  exact = 0: the counting pass reads the masks only (not the int64 edge list: a 16th of the host bytes)
  * and takes every graph's extent n from its node / road masks -- true for every state the extractor emits, whose edges join live
  * nodes (observation_extractor.py:84-132).  upamd_pack_fill* verifies each live endpoint against that extent and returns
- * UPAMD_E_REPLAN if one lies beyond it; the caller then plans again with exact = 1 (the host wrapper does). */
+ * UPAMD_E_REPLAN if one lies beyond it; the caller then plans again with exact = 1 (the host wrapper does).
+ * `exact` is a flag word: bit 0 = exact counting pass, bit 1 (value 2) = plan WITHOUT the two sections only the rl-mlp encoder reads
+ * (off_he_sel = off_xbar = -1; upamd_pack_fill* then skips the per-edge feature mean, two thirds of a state's fill time) -- an SGNN
+ * engine never touches them, an rl-mlp engine refuses such a replay. */
 int upamd_pack_plan_ex(int64_t T, const uint64_t *ptrs, const int32_t *pad_n, const int32_t *pad_e, const float *actions,
                        int32_t node_dim, int32_t numerical_dim, int32_t n_threads, int32_t exact, int32_t *meta,
                        upamd_pack_layout *layout);

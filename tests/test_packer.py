@@ -106,15 +106,17 @@ def test_action_outside_candidates_maps_to_minus_one():
     assert pk.meta[4, 5] == -1
 
 
-def _sections(pk, Fn):
+def _sections(pk, Fn, mlp_fields=True):
     """Every section of a pack as arrays (the alignment gaps between sections are not written by the packer)."""
     L, T = pk.layout, pk.T
     N, E, H, R = int(L.total_nodes), int(L.total_edges), int(L.total_he), int(L.total_rn)
     spec = [('meta', np.int32, T * native.META_STRIDE), ('x', np.float32, N * native.NODE_PAD), ('nmask', np.uint8, N),
             ('rowptr', np.int32, N + T), ('inc_nbr', np.uint16, 2 * E), ('he_src', np.uint16, H), ('he_dst', np.uint16, H),
-            ('he_live', np.uint8, H), ('rn_node', np.uint16, R), ('numerical', np.float32, T * Fn),
+            ('he_live', np.uint8, H), ('he_slot', np.int32, H), ('rn_node', np.uint16, R), ('numerical', np.float32, T * Fn),
             ('cur', np.float32, T * native.NODE_PAD), ('order', np.uint16, N), ('hinc_ptr', np.int32, N + T),
             ('hinc_nbr', np.uint16, 2 * H), ('hinc_he', np.uint16, 2 * H)]
+    if mlp_fields:
+        spec += [('he_sel', np.uint16, H), ('xbar', np.float32, T * native.NODE_PAD)]
     return {name: pk.section(name, dt, cnt).copy() for name, dt, cnt in spec}
 
 
@@ -293,3 +295,20 @@ def test_masks_only_plan_equals_the_exact_plan_and_falls_back_when_it_must():
     want.fill(0, want.T)
     assert want.meta[4, packer.M_N] == n + 1
     assert _same_pack(packer.pack_replay(states, rep.actions, 23, Fn, pin=False), want, Fn)
+
+
+def test_replay_without_the_rl_mlp_fields_is_the_same_everywhere_else():
+    """``plan_replay(mlp_fields=False)`` (what an SGNN model asks for): the two sections only the rl-mlp encoder reads -- ``he_sel``,
+    ``xbar`` -- are not planned (offset -1) and not computed (two thirds of a state's fill time: the per-edge feature mean); every
+    other section holds the same bytes."""
+    rep = synth.make_replay(24, 'hlg', max_nodes=64, max_edges=200, seed=5, road_fraction=0.4, n_range=(20, 55))
+    full = packer.pack_replay(rep.states, rep.actions, 23, 52, pin=False)
+    lean = packer.pack_replay(rep.states, rep.actions, 23, 52, pin=False, mlp_fields=False)
+    assert lean.layout.off_xbar == -1 and lean.layout.off_he_sel == -1 and lean.layout.total_bytes < full.layout.total_bytes
+    a, b = _sections(full, 52), _sections(lean, 52, mlp_fields=False)
+    assert set(a) - set(b) == {'he_sel', 'xbar'}
+    for k in b:
+        assert np.array_equal(a[k], b[k]), k
+    for t0, t1 in ((0, 24), (5, 17)):
+        for lo, hi in lean.byte_ranges(t0, t1):
+            assert 0 <= lo < hi <= lean.layout.total_bytes
