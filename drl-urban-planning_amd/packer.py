@@ -381,7 +381,7 @@ def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
     addr = getattr(states, 'addr', None)
     size = getattr(states, 'size', None)
     nd = np.ndarray       # (a padded state is a list / tuple of nine arrays: only an ndarray can be a record -- the type test first)
-    if addr is None and all(type(s) is nd and is_record(s) for s in states):
+    if addr is None and all(isinstance(s, nd) and is_record(s) for s in states):
         addr = np.fromiter((s.ctypes.data for s in states), dtype=np.uint64, count=T)
         size = np.fromiter((s.size for s in states), dtype=np.int64, count=T)
     if addr is not None:
@@ -392,7 +392,7 @@ def plan_replay(states, actions, node_dim, numerical_dim, n_threads=0, pin=None,
         native.check(L.upamd_record_table(T, addr.ctypes.data, size.ctypes.data, int(node_dim), int(numerical_dim),
                                           ptrs.ctypes.data, pad_n.ctypes.data, pad_e.ctypes.data), 'upamd_record_table')
         first_slow = T
-    elif any(type(s) is nd and is_record(s) for s in states):      # records and padded tuples mixed: zero-copy views of the records
+    elif any(isinstance(s, nd) and is_record(s) for s in states):      # records and padded tuples mixed: zero-copy views of the records
         states = [expand_state(s) if is_record(s) else s for s in states]
     helper = _host_helper() if addr is None else None
     if helper is not None:
