@@ -5,8 +5,8 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r06
 timeout 300 python bench.py --workload hlg_ref --steps 256 --warmup 256 > $O/bench_hlg_ref.json 2>/dev/null
 timeout 300 python bench.py --workload grid_ref --steps 100 --warmup 200 > $O/bench_grid_ref.json 2>/dev/null
 for c in 1 2 4; do UPAMD_PREPARE_CHUNKS=$c timeout 300 python bench.py --workload hlg_ref --steps 64 --warmup 256 --cpu-baseline off > $O/bench_hlg_ref_chunks$c.json 2>/dev/null; done
-timeout 300 python tools/inclusive_breakdown.py hlg_ref > $O/breakdown_hlg_ref.json 2> $O/breakdown_hlg_ref.err
-timeout 300 python tools/inclusive_breakdown.py hlg_d256 > $O/breakdown_hlg_d256.json 2> $O/breakdown_hlg_d256.err
+timeout 300 python tools/inclusive_breakdown.py --workload hlg_ref --unique > $O/breakdown_hlg_ref.json 2> $O/breakdown_hlg_ref.err
+timeout 300 python tools/inclusive_breakdown.py --workload hlg_d256 --unique > $O/breakdown_hlg_d256.json 2> $O/breakdown_hlg_d256.err
 timeout 300 python tools/rollout_bench.py --D 16 --L 2 > $O/rollout_d16.json 2> $O/rollout_d16.err
 timeout 300 python tools/rollout_bench.py --D 256 --L 3 --clients 8 16 32 64 --cpu-procs 1 16 --cpu-requests 10 > $O/rollout_d256.json 2> $O/rollout_d256.err
 python tools/evidence/lines.py $O/bench_hlg_ref*.json $O/bench_grid_ref.json
