@@ -54,7 +54,8 @@ def main():
         agent = policy_net.agent
         ph = {}
         sync(); t = time.perf_counter()
-        pk = packer.plan_replay(replay.states, np.asarray(replay.actions), agent.node_dim, agent.numerical_feature_size, reuse=up._pack_cache)
+        pk = packer.plan_replay(replay.states, np.asarray(replay.actions), agent.node_dim, agent.numerical_feature_size, reuse=up._pack_cache,
+                                 mlp_fields=up.backend.needs_mlp_fields())
         ph['plan'] = time.perf_counter() - t; t = time.perf_counter()
         pk.fill(0, T)
         ph['fill'] = time.perf_counter() - t; t = time.perf_counter()
