@@ -555,7 +555,7 @@ def main():
                                     'replay_states': T, 'unique_host_states': unique_incl,
                                     'host_working_set_bytes': host_bytes, 'prepare_s': incl['prepare'], 'loop_s': incl['loop'],
                                     'fraction_of_step_rate': (incl['steps'] * incl['rows_per_step'] / t_incl) / value,
-                                    'prepare_pipeline_chunks': int(up.pipeline_chunks) or (8 if w['D'] > 32 else 1),
+                                    'prepare_pipeline_chunks': int(up.pipeline_chunks) or (8 if w['D'] > 32 else 2),
                                     'note': 'one update_params(batch) call from host numpy states: pack | H2D | pre-pass (pipelined '
                                             'over chunks of the replay) + GAE + all epochs + write-back; T distinct host states unless '
                                             '--inclusive-pool (then the packer re-reads a small working set: an upper bound)'},

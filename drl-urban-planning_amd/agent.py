@@ -125,8 +125,9 @@ class PPOUpdater:
         self._comm_priority = int(os.environ.get('UPAMD_COMM_PRIORITY', '0'))
         self.last_buckets = None              # [(begin, end)] of the last bucketed step (tests, bench.py)
         # prepare(): the replay is packed / uploaded / swept in about this many chunks (1 = no pipeline)
-        # 0 = auto: 8 where the pre-pass is worth hiding (gcn_node_dim > 32), 1 for the small models, whose prepare() is bound by the
-        # host packer alone -- there the per-chunk overhead cost 8 % of the call (profiles/r05_lab_prepare.md)
+        # 0 = auto: 8 where the pre-pass is worth hiding (gcn_node_dim > 32), 2 for the small models (round 6: with the fill three times
+        # faster the H2D of one half hides under the fill of the other: 49.3 vs 52.5 ms per call at hlg_ref, 42.3 vs 44.5 from records,
+        # profiles/r06_bench_hlg_ref_chunks{1,2,4}.json; round 5's 8 chunks cost 8 % there, profiles/r05_lab_prepare.md)
         self.pipeline_chunks = int(os.environ.get('UPAMD_PREPARE_CHUNKS', '0'))
         self._copy_stream = None
         self.pending_state = None             # a checkpoint's optimizer state waiting for the GPU buffers (load_state_dict at the next update_params)
@@ -279,7 +280,7 @@ class PPOUpdater:
         row_lists = [np.arange(i, min(i + R, T)) for i in range(0, T, R)]
         sched = packer.Schedule(packed, row_lists, dev)       # (needs the meta table only: known since the plan)
         # pack-chunks: whole pre-pass minibatches, about `pipeline_chunks` of them over the replay
-        chunks = int(self.pipeline_chunks) or (8 if int(engine.desc.D) > 32 else 1)
+        chunks = int(self.pipeline_chunks) or (8 if int(engine.desc.D) > 32 else 2)
         per = max(1, -(-len(row_lists) // max(1, chunks)))
         main = torch.cuda.current_stream(dev)
         if self._copy_stream is None or self._copy_stream.device != dev:
