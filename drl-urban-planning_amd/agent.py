@@ -116,7 +116,7 @@ class PPOUpdater:
         # the backward marks final too early is invisible to a one-rank RCCL group (its sum is the identity) and caught under gloo
         # only by chance of timing; this sees it on one GPU.
         self._buckets_check = os.environ.get('UPAMD_GRAD_BUCKETS') == 'check'
-        self._bucket_check_shift = 0          # tests only (negative control): snapshot range j + shift behind event j -- must mismatch
+        self._bucket_check_selftest = False   # tests only: every snapshot gets one float changed -- the comparison must count exactly those
         self.bucket_check_mismatches = None   # device int64 scalar (check mode)
         self.bucket_checks = 0                # ranges compared so far (check mode)
         # lab knobs of the bucketed route, read once (profiles/r05_lab_bucket_overhead.md)
@@ -501,11 +501,13 @@ class PPOUpdater:
         if self.bucket_check_mismatches is None:
             self.bucket_check_mismatches = torch.zeros((), dtype=torch.int64, device=dev)
         snaps = []
-        for j in range(len(ranges) - 1 - self._bucket_check_shift):      # (the last range is final with the backward's last launch by definition)
-            b, e = ranges[j + self._bucket_check_shift]
+        for j, (b, e) in enumerate(ranges[:-1]):          # (the last range is final with the backward's last launch by definition)
             self.engine.grad_bucket_wait(j, self._comm)
             with torch.cuda.stream(self._comm):
-                snaps.append((b, e, self.grads[b:e].clone()))
+                snap = self.grads[b:e].clone()
+                if self._bucket_check_selftest:
+                    snap[0] += 1.0                        # a float that differs from the final gradient for certain
+                snaps.append((b, e, snap))
         cur = torch.cuda.current_stream(dev)
         cur.wait_stream(self._comm)
         for b, e, snap in snaps:
