@@ -158,7 +158,8 @@ class ActionServer:
         self.policy_net = policy_net
         self.num_clients, self.slot_bytes, self.linger_s = num_clients, _align(max(slot_bytes, ActionClient.REC + 4096)), linger_s
         self.shm = shared_memory.SharedMemory(create=True, size=num_clients * self.slot_bytes)
-        np.ndarray((num_clients * self.slot_bytes,), dtype=np.uint8, buffer=self.shm.buf)[:] = 0
+        # (a fresh POSIX shared-memory object is zero-filled by the kernel: sequence numbers start at 0 without touching the slots,
+        # 64 MB for 64 clients, here)
         self.doorbell = _eventfd()                      # every client rings this one: ONE wake-up of the serving thread per round
         self.wakes = [_eventfd() for _ in range(num_clients)]
         n, sb, buf = num_clients, self.slot_bytes, self.shm.buf

@@ -228,3 +228,29 @@ def test_ragged_actions_equal_the_padded_categorical_route():
     freq = np.bincount(draws[:, b, 0].astype(int), minlength=p.size) / draws.shape[0]
     assert np.abs(freq - p).max() < 0.12
     assert (draws[:, 3, 0] >= 0).all() and len(set(draws[:, 3, 0].tolist())) > 3       # the candidate-less row: uniform over the pads
+
+
+def test_record_views_are_built_on_access_and_pack_like_a_list():
+    """``packer.RecordViews`` (what ``RecordBatch.states`` is over arenas): a sequence that carries the records' addresses and sizes
+    and builds a record's zero-copy view only when it is asked for -- ``plan_replay`` never touches an element.  It must index,
+    slice, iterate and pack exactly like the list of views it replaces."""
+    rep = _states(12, 21)
+    arena = rollout.SharedArena(16, 1 << 20)
+    for t, s in enumerate(rep.states):
+        arena.append(s, rep.actions[t], 1, 0.0, 1)
+    batch = rollout.RecordBatch([rollout.ArenaMemory(arena)])
+    views = batch.states
+    assert isinstance(views, packer.RecordViews) and len(views) == 12 and views.addr.shape == (12,) and views.size.shape == (12,)
+    eager, _, _, _, _ = arena.rows()
+    assert all(np.array_equal(a, b) for a, b in zip(views, eager))
+    assert np.array_equal(views[-1], eager[-1]) and [bytes(v) for v in views[3:6]] == [bytes(v) for v in eager[3:6]]
+    with pytest.raises(IndexError):
+        views[12]
+    a = packer.pack_replay(views, batch.actions, 23, 52, pin=False)
+    b = packer.pack_replay(eager, batch.actions, 23, 52, pin=False)
+    from test_packer import _sections           # (section by section: the alignment gaps of the buffer are never written)
+    sa, sb = _sections(a, 52), _sections(b, 52)
+    assert all(np.array_equal(sa[k], sb[k]) for k in sa) and np.array_equal(a.meta, b.meta)
+    del views, eager, a, b
+    batch.close()
+    arena.close()
