@@ -26,7 +26,7 @@ GPU; the reference is single-process, urban_planning/train.py:49-55, so all of t
   is created with a long watchdog time-out (``UPAMD_DIST_TIMEOUT_S``, 4 h by default; RCCL's own default of 10 minutes would abort a
   long sampling phase); and rank 0 forks its env workers AFTER RCCL has been initialised -- safe as long as the children never touch
   the GPU runtime or the process group (the reference's workers run CPU modules only; the ``UPAMD_ROLLOUT=server`` children talk to
-  the learner through pipes and shared memory only), which is why ``rollout_binding`` empties ``sample_modules`` in the child.
+  the learner through shared memory and eventfd doorbells only), which is why ``rollout_binding`` empties ``sample_modules`` in the child.
 * **who evaluates** -- rank 0 runs ``eval_agent`` (:402-467) and the log object is broadcast, so ``best_rewards`` /
   ``best_plans`` / ``save_best_flag`` (:373-381) are the same on every rank;
 * **who writes** -- rank 0 only: TensorBoard scalars and checkpoints (:172-194) have a single writer, the other ranks get
